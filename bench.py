@@ -1,0 +1,185 @@
+"""bench.py -- utterances/sec (fwd + loss + bwd) of the MM-DFN hot path on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--ragged]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = zero_grad -> DialogueGNNModel forward -> FocalLoss -> backward (+ the data-parallel
+gradient all-reduce when N > 1) on one synthetic IEMOCAP-shaped batch already resident in HBM.
+Weak scaling: every rank processes its own batch of the configured size (dialogues are independent;
+the only collective is the flat-bucket gradient all-reduce over RCCL).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     live HIP-event timing of the dominant graph kernel (K6 propagate) vs the HBM roofline
+  "cpu_baseline": the CPU oracle (port of the reference algorithm) timed on this host, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def time_propagate(adj_builder, lay_d, iters=50):
+    """Average duration (ms) of one K6 propagate launch, HIP events on the launch stream."""
+    from mm_dfn_amd import ops
+    adj, H = adj_builder()
+    s = torch.cuda.current_stream()
+    for _ in range(5):
+        ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    e1.record(s)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(cfg, batch, state, threads, budget_s=20.0):
+    """Times the oracle (reference op structure: dense adjacency, looped party GRUs, aten GRU) on the host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mmdfn_oracle as O
+    if threads > 0:
+        torch.set_num_threads(threads)
+    used = torch.get_num_threads()
+    # bounded sample: the first `nb` dialogues of the batch (reference CPU throughput peaks near B=16)
+    nb = min(len(batch["lengths"]), 8)
+    lens = batch["lengths"][:nb]
+    L = max(lens)
+    sl = lambda t: t[:L, :nb].contiguous()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state.items()}
+    ocfg = O.default_cfg(cfg["nlayers"], dropout=0.0)
+    label = O.flatten_labels(batch["label"][:nb, :L].cpu(), lens)
+    args = (sl(batch["textf"].cpu()), sl(batch["qmask"].cpu()), batch["umask"][:nb, :L].cpu(), lens,
+            sl(batch["acouf"].cpu()), sl(batch["visuf"].cpu()))
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        logp = O.forward(params, *args, ocfg, training=True, engine="aten")
+        O.focal_loss(logp, label, 0.5).backward()
+
+    step()  # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 20:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": sum(lens) / dt, "unit": "utterances/s", "cores": used, "kind": "port",
+            "sample": "%d dialogues (L<=%d, N=%d utt) of the bench batch, %d fwd+bwd steps, oracle/mmdfn_oracle.py "
+                      "(dense adjacency, per-speaker GRU passes, aten GRU), %.2f s/step" % (nb, L, sum(lens), n, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from mm_dfn_amd import FocalLoss, synthetic, train, ops, distributed
+
+    if world > 1:
+        distributed.init(backend="nccl")
+
+    cfg = dict(synthetic.CONFIGS[a.config])
+    model = synthetic.build_model(dropout=a.dropout, **cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
+    model = model.to(dev).train()
+    batch = synthetic.make_batch(2021 + rank, ragged=a.ragged, device=dev, **cfg)
+    lengths = batch["lengths"]
+    n_utt = sum(lengths)
+    label = train.flatten_labels(batch["label"], lengths)
+    loss_f = FocalLoss(gamma=0.5)
+    dp = distributed.GradientBucket(model) if world > 1 else None
+    total_utt = distributed.all_reduce_scalar(n_utt) if world > 1 else n_utt
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
+        loss = loss_f(logp, label)
+        if dp is not None:
+            loss = loss * (n_utt * world / total_utt)   # mean over the GLOBAL utterance count after averaging
+        loss.backward()
+        if dp is not None:
+            dp.all_reduce()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant graph kernel at this workload (K6 propagate forward, d = 100)
+        feats = torch.randn(3, n_utt, 200, device=dev)
+        d = 100
+
+        def mk():
+            adj = ops.build_adjacency(feats, lengths)
+            return adj, torch.randn(3 * n_utt, d, device=dev)
+
+        ms = time_propagate(mk, d)
+        lay = ops.DialogueLayout.get(lengths, 3, dev)
+        alg_bytes = lay.propagate_bytes(d)
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        out = {
+            "metric": "utterances/sec (fwd+bwd), IEMOCAP-shaped batch", "value": total_utt * a.steps / dt,
+            "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: B=%d dialogues/GPU, L=%s, dims %d/%d/%d, %d GCN layers, P=%d, dropout %.2f"
+                                   % (a.config, cfg["B"], "ragged<=%d" % cfg["L"] if a.ragged else cfg["L"], cfg["D_t"],
+                                      cfg["D_a"], cfg["D_v"], cfg["nlayers"], cfg["P"], a.dropout),
+                       "utterances_per_gpu": n_utt, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "propagate_kernel (K6 fwd, d=100)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3, "traffic": None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+/*
+ * mmdfn_hip.h -- C ABI of libmmdfn_hip.so: the MI355X (gfx950) kernels behind
+ * the MM-DFN graph dynamic-fusion hot path.
+ *
+ * The reference (zerohd4869/MM-DFN) has no FFI layer: its "operators" are
+ * torch ops called from nn.Module.forward.  Each entry point below replaces
+ * the reference call site cited next to it; the Python host side
+ * (the mm_dfn_amd Python package) binds them with ctypes and keeps the reference's
+ * nn.Module signatures (see INTEGRATION.md for the stub a maintainer adds).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (the PyTorch
+ *     caching allocator); kernels never allocate or free;
+ *   - fp32 row-major contiguous data, int32 / int64 index arrays;
+ *   - asynchronous enqueue on `stream` (a hipStream_t passed as void*), no
+ *     internal synchronisation, no global state, re-entrant;
+ *   - return value 0 = success, otherwise a hipError_t (or -1 for an invalid
+ *     argument); nothing throws across the ABI.
+ *
+ * Dialogue layout shared by the graph kernels ("block-tile adjacency"):
+ *   B dialogues of lengths dia_len[i]; row_start[i] = sum_{j<i} dia_len[j]
+ *   (B+1 entries, row_start[B] = N).  M modalities.  Node (m, r) of the
+ *   multimodal dialogue graph is row m*N + r of every (M*N, d) feature matrix
+ *   (the reference's cat([a, v, l], 0) order, model_mm.py:98).
+ *   The normalised adjacency is never materialised densely; it is stored as
+ *     tiles : for dialogue i, modality m a dia_len[i] x dia_len[i] fp32 tile,
+ *             row-major with leading dimension ld_i = round_up(dia_len[i], 4),
+ *             at float offset tile_base[i] + m * dia_len[i] * ld_i
+ *             (tile_base: B+1 int64 entries, multiples of 4); pad columns are 0;
+ *     cross : for each unordered modality pair (m<n), in lexicographic order,
+ *             N fp32 values: entry r is A[(m,r),(n,r)] = A[(n,r),(m,r)].
+ */
+#ifndef MMDFN_HIP_H
+#define MMDFN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / device sanity: returns the ABI version (currently 1). */
+int mmdfn_abi_version(void);
+
+/* ---------------------------------------------------------------------------
+ * K6  scatter-propagate  out = A_hat . H        (replaces torch.spmm(adj, input),
+ *                                                model_GCN.py:178)
+ *   out[(m,r),:] = sum_q tile_{i,m}[r,q] * H[(m,q),:] + sum_{n!=m} cross_{mn}[r] * H[(n,r),:]
+ *   transpose != 0 uses tile^T (for dH = A^T . dO when tiles are not symmetric).
+ *   H, out: (M*N, d) fp32, d % 4 == 0.  max_len = max_i dia_len[i].
+ * ------------------------------------------------------------------------- */
+int mmdfn_propagate(const float* tiles, const float* cross, const float* H, float* out,
+                    const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                    int B, int M, int N, int d, int max_len, int transpose, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K6 backward w.r.t. the adjacency, restricted to the stored pattern
+ * (autograd of model_GCN.py:178 w.r.t. adj; the reference gets a dense
+ * (MN x MN) gradient from SpmmBackward):
+ *   dtiles_{i,m}[p,q] (+)= X[(m,p),:] . Y[(m,q),:]
+ *   dcross_{mn}[r]    (+)= X[(m,r),:].Y[(n,r),:] + X[(n,r),:].Y[(m,r),:]
+ *   with X = dOut, Y = H.  accumulate != 0 adds into dtiles/dcross.
+ * ------------------------------------------------------------------------- */
+int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, float* dcross,
+                     const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                     int B, int M, int N, int d, int max_len, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K5  adjacency build (replaces MM_GCN.create_big_adj, model_mm.py:122-180)
+ *   feats  : (M, N, D) fp32 (modality-major stack of the encoder outputs)
+ *   unit   : (M, N, D) out, x / ||x||              (saved for backward)
+ *   norm   : (M, N)    out, ||x||
+ *   cosg   : tile-shaped out, raw cosine Gram G    (saved for backward)
+ *   cdot   : (npairs, N) out, raw cross cosines    (saved for backward)
+ *   rdeg   : (M, N)    out, degree^-1/2
+ *   tiles, cross : the normalised adjacency (layout above)
+ *   sim(c) = 1 - acos(0.99999 c)/pi ; cross entries are scaled by modal_weight.
+ * ------------------------------------------------------------------------- */
+int mmdfn_adj_build(const float* feats, float* unit, float* norm, float* cosg, float* cdot,
+                    float* rdeg, float* tiles, float* cross,
+                    const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                    int B, int M, int N, int D, int max_len, float modal_weight, void* stream);
+
+/* Backward of mmdfn_adj_build: given dtiles / dcross (gradients of the stored
+ * entries) produce dfeats (M, N, D).  `wsym` (tile-shaped), `etile`
+ * (tile-shaped), `ecross` (npairs, N), `ddeg` (M, N) and `dunit` (M, N, D) are
+ * caller-provided scratch. */
+int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross,
+                        const float* unit, const float* norm, const float* cosg, const float* cdot,
+                        const float* rdeg, const float* tiles, const float* cross,
+                        float* wsym, float* etile, float* ecross, float* ddeg, float* dunit,
+                        float* dfeats,
+                        const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                        int B, int M, int N, int D, int max_len, float modal_weight, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMDFN_HIP_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libmmdfn_hip.so (the C ABI declared in include/mmdfn_hip.h).
+
+There is no CPU fallback: if the library is missing, stale or a kernel returns
+an error, the product path raises.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes; must list every symbol of include/mmdfn_hip.h
+SIGNATURES = {
+    "mmdfn_abi_version": [],
+    "mmdfn_propagate": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_tile_outer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_adj_build": [_P] * 8 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
+    "mmdfn_adj_build_bwd": [_P] * 15 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
+}
+
+ABI_VERSION = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIBPATH
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            "libmmdfn_hip.so not built (%s missing): run `python -m mm_dfn_amd.build` "
+            "(needs hipcc); the MI355X path has no CPU fallback" % path)
+    handle = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HipLibraryError("libmmdfn_hip.so lacks symbol %s (stale build?)" % name) from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    if handle.mmdfn_abi_version() != ABI_VERSION:
+        raise HipLibraryError("libmmdfn_hip.so ABI version mismatch")
+    _lib = handle
+    return _lib
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipLibraryError("%s failed with code %d" % (what, rc))
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError("the MM-DFN HIP path needs tensors on an MI355X device (got %s); "
+                                  "there is no CPU fallback" % t.device)

@@ -1,0 +1,78 @@
+"""Build recipe for libmmdfn_hip.so (hipcc, gfx950 only, in-tree output).
+
+``python -m mm_dfn_amd.build`` or ``__graft_entry__.build()``.  hipcc
+cross-compiles without a GPU; the resulting shared object is git-ignored but
+travels to the GPU box with the repo snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libmmdfn_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest():
+    h = hashlib.sha256()
+    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    files.append(os.path.join(INCLUDE, "mmdfn_hip.h"))
+    for f in files:
+        h.update(f.encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libmmdfn_hip.so cannot be built")
+    return exe
+
+
+def build(force=False, verbose=True):
+    """Compile every csrc/*.hip for gfx950 into lib/libmmdfn_hip.so."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "libmmdfn_hip.sha256")
+    digest = _digest()
+    if not force and os.path.exists(LIBPATH) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == digest:
+                return LIBPATH
+    objs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIBPATH] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(digest)
+    return LIBPATH
+
+
+def is_stale():
+    stamp = os.path.join(LIBDIR, "libmmdfn_hip.sha256")
+    if not (os.path.exists(LIBPATH) and os.path.exists(stamp)):
+        return True
+    with open(stamp) as fh:
+        return fh.read().strip() != _digest()
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

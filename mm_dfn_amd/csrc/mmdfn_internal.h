@@ -1,0 +1,46 @@
+// Internal helpers shared by the gfx950 kernels of libmmdfn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MMDFN_CHECK_LAUNCH()                         \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+// sim(c) = 1 - acos(0.99999 c) / pi          (model_mm.py:149-150, 166-167)
+#define MMDFN_COS_SHRINK 0.99999f
+#define MMDFN_PI_F 3.14159265358979323846f
+
+__device__ __forceinline__ float mmdfn_sim(float c) {
+    return 1.0f - acosf(c * MMDFN_COS_SHRINK) / MMDFN_PI_F;
+}
+// d sim / d c = a / (pi sqrt(1 - (a c)^2))
+__device__ __forceinline__ float mmdfn_dsim(float c) {
+    float ac = c * MMDFN_COS_SHRINK;
+    return MMDFN_COS_SHRINK / (MMDFN_PI_F * sqrtf(1.0f - ac * ac));
+}
+
+// index of the unordered modality pair (m < n) in lexicographic order
+__host__ __device__ __forceinline__ int mmdfn_pair_index(int m, int n, int M) {
+    return m * (2 * M - m - 1) / 2 + (n - m - 1);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// launchers implemented in propagate.hip / tile_dot.hip, used by adjacency.hip
+int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* H, float* out,
+                           const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                           int B, int M, int N, int d, int max_len, int transpose, hipStream_t s);
+
+// EPI 0: dtiles (+)= X.Y^T ; EPI 1: cosine Gram + raw similarity + row degree
+int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
+                          const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                          int B, int M, int N, int K, int max_len, int epi, int accumulate, hipStream_t s);

@@ -1,0 +1,172 @@
+// Tile-pattern dot products  tiles_{i,m}[p,q] = X[(m,p),:] . Y[(m,q),:].
+//
+//  EPI 0 (outer):  gradient of the propagate step w.r.t. the stored adjacency
+//                  entries (dA = dOut . H^T restricted to the block-tile
+//                  pattern; the reference's SpmmBackward produces the dense
+//                  (MN x MN) matrix, model_GCN.py:178).
+//  EPI 1 (gram):   cosine Gram of the unit feature rows + angular similarity
+//                  + row degree (model_mm.py:145-151, 176).
+//
+// Both operands are k-contiguous, so both MFMA fragments are loaded straight
+// from global memory with one 16-byte load per lane per 16-wide k-chunk
+// (lane (row, g) holds k = k0+4g .. k0+4g+3; the same k-permutation on A and
+// B).  The A strip (16 rows x K) of each wave stays in registers for the whole
+// sweep over q; no LDS is needed.
+#include "mmdfn_internal.h"
+#include "../../include/mmdfn_hip.h"
+
+namespace {
+
+template <int NW, int KC, int EPI>
+__global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
+    const float* __restrict__ X, const float* __restrict__ Y, float* __restrict__ out_tiles,
+    float* __restrict__ out_aux, float* __restrict__ deg, const int32_t* __restrict__ dia_len,
+    const int32_t* __restrict__ row_start, const int64_t* __restrict__ tile_base, int M, int N, int K,
+    int max_rb, int accumulate) {
+    constexpr int BM = 16 * NW;
+    const int i = blockIdx.x / max_rb;
+    const int rb = blockIdx.x % max_rb;
+    const int m = blockIdx.y;
+    const int L = dia_len[i];
+    const int r0 = rb * BM;
+    if (r0 >= L) return;
+    const int ld = (L + 3) & ~3;
+    const int rs = row_start[i];
+    const int64_t toff = tile_base[i] + (int64_t)m * L * ld;
+    const float* Xm = X + ((int64_t)m * N + rs) * K;
+    const float* Ym = Y + ((int64_t)m * N + rs) * K;
+
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int frow = lane & 15;
+    const int g = lane >> 4;
+    const int prow = r0 + 16 * w + frow;
+    if (r0 + 16 * w >= L) return;  // whole wave out of range (no barriers in this kernel)
+
+    float4 a[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const int k = 16 * kc + 4 * g;
+        a[kc] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (prow < L && k < K) a[kc] = *reinterpret_cast<const float4*>(Xm + (int64_t)prow * K + k);
+    }
+
+    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < ld; q0 += 16) {
+        const int qrow = q0 + frow;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int k = 16 * kc + 4 * g;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qrow < L && k < K) b = *reinterpret_cast<const float4*>(Ym + (int64_t)qrow * K + k);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].w, b.w, acc, 0, 0, 0);
+        }
+        // C/D layout: col = lane&15 (q), row = 4g + r (p)
+        const int q = q0 + frow;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = r0 + 16 * w + 4 * g + r;
+            const bool ok = (p < L) && (q < ld);
+            const int64_t off = toff + (int64_t)p * ld + q;
+            if (EPI == 0) {
+                if (ok) {
+                    float v = acc[r];
+                    if (accumulate) v += out_tiles[off];
+                    out_tiles[off] = v;
+                }
+            } else {
+                float s = 0.f;
+                if (ok) {
+                    const float gq = (q < L) ? acc[r] : 0.f;
+                    s = (q < L) ? mmdfn_sim(gq) : 0.f;
+                    out_aux[off] = gq;    // raw cosine (saved for backward)
+                    out_tiles[off] = s;   // raw similarity; normalised by a later kernel
+                }
+                // reduce over the 16 lanes (q) that share this row
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                s += __shfl_xor(s, 8, 64);
+                rowsum[r] += s;
+            }
+        }
+    }
+    if (EPI == 1 && frow == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = r0 + 16 * w + 4 * g + r;
+            if (p < L) deg[(int64_t)m * N + rs + p] += rowsum[r];  // single writer per row
+        }
+    }
+}
+
+template <int NW, int KC>
+int launch(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg, const int32_t* dia_len,
+           const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int max_len, int epi,
+           int accumulate, hipStream_t s) {
+    const int BM = 16 * NW;
+    const int max_rb = (max_len + BM - 1) / BM;
+    dim3 grid(B * max_rb, M);
+    dim3 block(64 * NW);
+    if (epi == 0)
+        hipLaunchKernelGGL((tile_dot_kernel<NW, KC, 0>), grid, block, 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
+                           row_start, tile_base, M, N, K, max_rb, accumulate);
+    else
+        hipLaunchKernelGGL((tile_dot_kernel<NW, KC, 1>), grid, block, 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
+                           row_start, tile_base, M, N, K, max_rb, accumulate);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+// dcross_{mn}[r] (+)= X[(m,r)].Y[(n,r)] + X[(n,r)].Y[(m,r)]   -- one wave per row
+__global__ __launch_bounds__(256) void cross_dot_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                        float* __restrict__ dcross, int M, int N, int K,
+                                                        int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    for (int m = 0; m < M; ++m)
+        for (int n = m + 1; n < M; ++n) {
+            const float* xm = X + ((int64_t)m * N + row) * K;
+            const float* xn = X + ((int64_t)n * N + row) * K;
+            const float* ym = Y + ((int64_t)m * N + row) * K;
+            const float* yn = Y + ((int64_t)n * N + row) * K;
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += xm[k] * yn[k] + xn[k] * ym[k];
+            s = wave_sum(s);
+            if (lane == 0) {
+                const int64_t o = (int64_t)mmdfn_pair_index(m, n, M) * N + row;
+                dcross[o] = accumulate ? dcross[o] + s : s;
+            }
+        }
+}
+
+}  // namespace
+
+int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
+                          const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                          int B, int M, int N, int K, int max_len, int epi, int accumulate, hipStream_t s) {
+    if (B <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 3) || max_len <= 0) return -1;
+    if (K <= 112) return launch<4, 7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, max_len, epi, accumulate, s);
+    if (K <= 208) return launch<4, 13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, max_len, epi, accumulate, s);
+    if (K <= 512) return launch<4, 32>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, max_len, epi, accumulate, s);
+    return -1;
+}
+
+extern "C" int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, float* dcross,
+                                const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                                int B, int M, int N, int d, int max_len, int accumulate, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = mmdfn_launch_tile_dot(X, Y, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, d, max_len,
+                                   0, accumulate, s);
+    if (rc) return rc;
+    if (M > 1 && dcross) {
+        hipLaunchKernelGGL(cross_dot_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, accumulate);
+        MMDFN_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,217 @@
+"""DialogueGNNModel, MM-DFN configuration (reference model.py:784-1407).
+
+Same constructor and ``forward(U, qmask, umask, seq_lengths, U_a, U_v,
+test_label)`` signature and the same 86 ``state_dict`` keys as the reference,
+restricted to the configuration MM-DFN trains (base_model='LSTM',
+multi_modal=True, graph_type='GDF', use_crn_speaker=True).  Other ablation
+branches of the reference constructor raise NotImplementedError.
+
+Host-side structure differs from the reference on purpose (MI355X-first):
+  * the B*P*2*3 Python slice-assign loops of the speaker-party encoder
+    (model.py:1076-1087) become one device-side gather / scatter driven by a
+    prefix sum over qmask, and the 3*P separate ``rnn_parties`` calls
+    (model.py:1082,1112,1145) become ONE batched call (weights are shared);
+  * padding is stripped with one index_select producing the (M, N, 200)
+    modality-major stack the graph kernels consume (model.py:553-565, :98);
+  * the adjacency is never dense (layout.py / csrc/adjacency.hip).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .mm_gcn import MM_GCN
+
+_FLAT_CACHE = {}
+
+
+def _flat_index(lengths, L, B, device):
+    """Row ids t*B+b of the (L*B) padded grid in dialogue-major order (simple_batch_graphify)."""
+    key = (tuple(lengths), L, B, str(device))
+    idx = _FLAT_CACHE.get(key)
+    if idx is None:
+        if len(_FLAT_CACHE) > 64:
+            _FLAT_CACHE.clear()
+        parts = [np.arange(int(n), dtype=np.int64) * B + j for j, n in enumerate(lengths)]
+        idx = torch.from_numpy(np.concatenate(parts)).to(device)
+        _FLAT_CACHE[key] = idx
+    return idx
+
+
+class _Scalar(nn.Module):
+    def __init__(self, i, o, bias):
+        super().__init__()
+        self.scalar = nn.Linear(i, o, bias=bias)
+
+
+class _Transform(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.transform = nn.Linear(i, o, bias=True)
+
+
+class _MlpAttention(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(2 * dim).uniform_(-0.05, 0.05))
+        self.w_k = nn.Linear(dim, dim)
+        self.w_q = nn.Linear(dim, dim)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _EdgeAttentionParams(nn.Module):
+    """Parameters of the reference's MaskedEdgeAttention (model.py:420-445): constructed
+    by the reference for every graph type, used only by graph_type='relation'."""
+
+    def __init__(self, dim, max_seq_len):
+        super().__init__()
+        self.scalar = nn.Linear(dim, max_seq_len, bias=False)
+        self.matchatt = _Transform(dim, dim)
+        self.simpleatt = _Scalar(dim, 1, False)
+        self.att = _MlpAttention(dim)
+
+
+class _GatedAttentionParams(nn.Module):
+    """Parameters of the reference's MMGatedAttention('general') (model.py:718-740);
+    unreachable under graph_type='GDF' (SURVEY.md §2)."""
+
+    def __init__(self, mem_dim, cand_dim):
+        super().__init__()
+        self.transform_l = nn.Linear(mem_dim, cand_dim)
+        self.transform_v = nn.Linear(mem_dim, cand_dim)
+        self.transform_a = nn.Linear(mem_dim, cand_dim)
+        self.transform_av = nn.Linear(mem_dim * 3, 1)
+        self.transform_al = nn.Linear(mem_dim * 3, 1)
+        self.transform_vl = nn.Linear(mem_dim * 3, 1)
+
+
+class DialogueGNNModel(nn.Module):
+
+    def __init__(self, base_model, D_m, D_g, D_p, D_e, D_h, D_a, graph_hidden_size, n_speakers, max_seq_len,
+                 window_past, window_future, n_classes=7, listener_state=False, context_attention='simple',
+                 dropout_rec=0.5, dropout=0.5, nodal_attention=True, avec=False, no_cuda=False,
+                 graph_type='relation', use_topic=False, alpha=0.1, lamda=0.5, multiheads=6,
+                 graph_construct='direct', use_GCN=False, use_residue=True, dynamic_edge_w=False, D_m_v=512,
+                 D_m_a=100, modals='avl', att_type='gated', av_using_lstm=False, Deep_GCN_nlayers=64,
+                 dataset='IEMOCAP', use_speaker=True, use_modal=False, reason_flag=False, multi_modal=True,
+                 use_crn_speaker=False, speaker_weights='1-1-1', modal_weight=1.0):
+        super().__init__()
+        if base_model != 'LSTM' or not multi_modal or graph_type != 'GDF':
+            raise NotImplementedError("mm_dfn_amd implements the MM-DFN hot path only: base_model='LSTM', "
+                                      "multi_modal=True, graph_type='GDF' (got %r, %r, %r)"
+                                      % (base_model, multi_modal, graph_type))
+        if att_type != 'concat_subsequently':
+            raise NotImplementedError("only att_type='concat_subsequently' (--mm_fusion_mthd of the MM-DFN scripts)")
+        if av_using_lstm:
+            raise NotImplementedError("av_using_lstm=True is not part of the MM-DFN configuration")
+        if sorted(modals) != ['a', 'l', 'v']:
+            raise NotImplementedError("the GDF path is trimodal ('avl')")
+        if 2 * D_e != 200:
+            raise NotImplementedError("the reference hard-codes a 200-wide encoder (model.py:847-849,1074); D_e must be 100")
+        self.base_model = base_model
+        self.no_cuda = no_cuda
+        self.graph_type = graph_type
+        self.alpha = alpha
+        self.lamda = lamda
+        self.dropout = dropout
+        self.use_residue = use_residue
+        self.return_feature = True
+        self.modals = [x for x in modals]
+        self.use_speaker = use_speaker
+        self.use_modal = use_modal
+        self.att_type = att_type
+        self.reason_flag = reason_flag
+        self.multi_modal = multi_modal
+        self.n_speakers = n_speakers
+        self.use_crn_speaker = use_crn_speaker
+        self.speaker_weights = list(map(float, speaker_weights.split('-')))
+        self.modal_weight = modal_weight
+        self.dataset = dataset
+        self.window_past = window_past
+        self.window_future = window_future
+        self.nodal_attention = nodal_attention
+
+        hidden = 2 * D_e
+        self.linear_a = nn.Linear(D_m_a, hidden)
+        self.linear_v = nn.Linear(D_m_v, hidden)
+        self.linear_l = nn.Linear(D_m, hidden)
+        self.lstm_l = nn.GRU(input_size=hidden, hidden_size=D_e, num_layers=2, bidirectional=True, dropout=dropout)
+        self.rnn_parties = nn.GRU(input_size=hidden, hidden_size=D_e, num_layers=2, bidirectional=True,
+                                  dropout=dropout)
+        self.att_model = _EdgeAttentionParams(hidden, max_seq_len)
+        self.graph_model = MM_GCN(a_dim=hidden, v_dim=hidden, l_dim=hidden, n_dim=hidden, nlayers=Deep_GCN_nlayers,
+                                  nhidden=graph_hidden_size, nclass=n_classes, dropout=dropout, lamda=lamda,
+                                  alpha=alpha, variant=True, return_feature=True, use_residue=use_residue,
+                                  n_speakers=n_speakers, modals=self.modals, use_speaker=use_speaker,
+                                  use_modal=use_modal, reason_flag=reason_flag, modal_weight=modal_weight)
+        self.gatedatt = _GatedAttentionParams(hidden + graph_hidden_size, graph_hidden_size)
+        self.dropout_ = nn.Dropout(dropout)
+        width = (hidden + graph_hidden_size) if use_residue else graph_hidden_size
+        self.smax_fc = nn.Linear(width * len(self.modals), n_classes)
+
+    # ------------------------------------------------------------------ encoders
+    @staticmethod
+    def _party_plan(qmask):
+        """Device-side gather/scatter plan of the speaker-party encoder.
+
+        qmask: (L, B, P).  rank[t,b,p] = position of utterance t among speaker p's
+        utterances of dialogue b; src[k,b,p] = time index of the k-th such utterance
+        (L = "none": reads a zero row)."""
+        L, B, P = qmask.shape
+        mask = qmask != 0
+        rank = torch.cumsum(mask.to(torch.int64), 0) - 1
+        t_grid = torch.arange(L, device=qmask.device).view(L, 1, 1).expand(L, B, P)
+        src = torch.full((L + 1, B, P), L, dtype=torch.int64, device=qmask.device)
+        src.scatter_(0, torch.where(mask, rank, torch.full_like(rank, L)), t_grid)
+        src = src[:L]
+        # the reference scatters speaker by speaker, so with a non-one-hot qmask the last speaker wins
+        later = torch.flip(torch.cumsum(torch.flip(mask, [2]).to(torch.int64), 2), [2]) - mask.to(torch.int64)
+        sel = mask & (later == 0)
+        return src, rank.clamp_(min=0), sel
+
+    def _party_encode(self, X_list, plan):
+        """X_list: per-modality (L, B, H) projections -> per-modality U_p (L, B, H); one batched BiGRU call."""
+        src, rank, sel = plan
+        L, B, P = src.shape
+        Mn = len(X_list)
+        X = torch.stack(X_list, 0)                                      # (Mn, L, B, H)
+        H = X.shape[-1]
+        Xp = torch.cat([X, X.new_zeros(Mn, 1, B, H)], 1)               # zero row at index L
+        g_idx = src.view(1, L, B, P, 1).expand(Mn, L, B, P, H)
+        S = Xp.unsqueeze(3).expand(Mn, L + 1, B, P, H).gather(1, g_idx)  # (Mn, L, B, P, H)
+        S = S.permute(1, 0, 2, 3, 4).reshape(L, Mn * B * P, H)
+        E = self.rnn_parties(S)[0]                                       # (L, Mn*B*P, H)
+        E = E.view(L, Mn, B, P, H).permute(1, 0, 2, 3, 4)               # (Mn, L, B, P, H)
+        s_idx = rank.view(1, L, B, P, 1).expand(Mn, L, B, P, H)
+        back = E.gather(1, s_idx) * sel.view(1, L, B, P, 1).to(E.dtype)
+        U = back.sum(3)                                                  # (Mn, L, B, H)
+        return [U[i] for i in range(Mn)]
+
+    def encode(self, U, qmask, seq_lengths, U_a, U_v):
+        """Projection + context BiGRU (text) + speaker-party BiGRU (all modalities) ->
+        (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209)."""
+        Xa = self.linear_a(U_a)
+        Xv = self.linear_v(U_v)
+        Xl = self.linear_l(U)
+        ctx = self.lstm_l(Xl)[0]
+        ea, ev, el = Xa, Xv, ctx
+        if self.use_crn_speaker:
+            plan = self._party_plan(qmask)
+            Pa, Pv, Pl = self._party_encode([Xa, Xv, Xl], plan)
+            w = self.speaker_weights
+            ea = ea + w[0] * Pa
+            ev = ev + w[1] * Pv
+            el = el + w[2] * Pl
+        L, B, H = Xa.shape
+        idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
+        return torch.stack([ea, ev, el], 0).reshape(3, L * B, H).index_select(1, idx)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, U, qmask, umask, seq_lengths, U_a=None, U_v=None, test_label=False):
+        if U_a is None or U_v is None:
+            raise ValueError("the trimodal GDF path needs U_a and U_v")
+        feats = self.encode(U, qmask, seq_lengths, U_a, U_v)
+        fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label)
+        z = F.relu(self.dropout_(fused))
+        log_prob = F.log_softmax(self.smax_fc(z), 1)
+        return log_prob, None, None, None, None

@@ -1,0 +1,101 @@
+"""GraphConvolution (GCNII layer) and GCNII_lyc (GCNII stack with the LSTM
+"dynamic fusion" gate) -- drop-in counterparts of reference model_GCN.py:157-189
+and :412-488 with the same constructor / forward signatures and state_dict keys.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .layout import BlockTileAdjacency
+
+
+class GraphConvolution(nn.Module):
+    """out = theta * [A.x || h0] W + (1-theta) * ((1-alpha) A.x + alpha h0)   (variant=True)."""
+
+    def __init__(self, in_features, out_features, residual=False, variant=False):
+        super().__init__()
+        self.variant = variant
+        self.in_features = 2 * in_features if variant else in_features
+        self.out_features = out_features
+        self.residual = residual
+        self.weight = Parameter(torch.empty(self.in_features, self.out_features))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.out_features)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+
+    def forward(self, input, adj, h0, lamda, alpha, l):
+        theta = math.log(lamda / l + 1)
+        if isinstance(adj, BlockTileAdjacency):
+            hi = ops.propagate(adj, input)           # HIP K6
+        else:
+            hi = torch.mm(adj, input)                # caller supplied a dense matrix
+        if self.variant:
+            support = torch.cat([hi, h0], 1)
+            r = (1 - alpha) * hi + alpha * h0
+        else:
+            support = (1 - alpha) * hi + alpha * h0
+            r = support
+        out = theta * torch.mm(support, self.weight) + (1 - theta) * r
+        if self.residual:
+            out = out + input
+        return out
+
+
+class GCNII_lyc(nn.Module):
+    def __init__(self, nfeat, nlayers, nhidden, nclass, dropout, lamda, alpha, variant, return_feature, use_residue,
+                 new_graph=False, reason_flag=False):
+        super().__init__()
+        self.return_feature = return_feature
+        self.use_residue = use_residue
+        self.new_graph = new_graph
+        self.convs = nn.ModuleList([GraphConvolution(nhidden, nhidden, variant=variant) for _ in range(nlayers)])
+        self.fcs = nn.ModuleList([nn.Linear(nfeat, nhidden)])
+        if not return_feature:
+            self.fcs.append(nn.Linear(nfeat + nhidden, nclass))
+        self.act_fn = nn.ReLU()
+        self.dropout = dropout
+        self.alpha = alpha
+        self.lamda = lamda
+        self.rnn_layer = 1
+        self.rnn = nn.LSTM(nhidden, nhidden, self.rnn_layer)   # one cell shared by all layers, seq_len 1
+        self.reason_flag = reason_flag
+
+    def _gate(self, q, h, c):
+        """One LSTM-cell step (gate order i, f, g, o), state carried layer to layer."""
+        g = F.linear(q, self.rnn.weight_ih_l0, self.rnn.bias_ih_l0) + F.linear(h, self.rnn.weight_hh_l0,
+                                                                              self.rnn.bias_hh_l0)
+        i, f, gg, o = g.chunk(4, 1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        return h, c
+
+    def forward(self, x, dia_len, topicLabel, adj=None, test_label=False):
+        if adj is None:
+            raise NotImplementedError("GCNII_lyc without an explicit adjacency (reference model_GCN.py:490-584) "
+                                      "is outside the MM-DFN hot path; pass adj from MM_GCN.create_big_adj")
+        x = F.dropout(x, self.dropout, training=self.training)
+        h0 = self.act_fn(self.fcs[0](x))
+        cur = F.dropout(h0, self.dropout, training=self.training)
+        h = torch.zeros_like(cur)
+        c = torch.zeros_like(cur)
+        for i, con in enumerate(self.convs):
+            q = cur
+            if self.reason_flag:
+                h, c = self._gate(q, h, c)
+                cur = h
+            cur = self.act_fn(con(cur, adj, h0, self.lamda, self.alpha, i + 1))
+            cur = F.dropout(cur, self.dropout, training=self.training)
+            if self.reason_flag:
+                cur = cur + q
+        if self.use_residue:
+            cur = torch.cat([x, cur], dim=-1)
+        if not self.return_feature:
+            cur = F.log_softmax(self.fcs[-1](cur), dim=1)
+        return cur

@@ -1,0 +1,118 @@
+"""Dialogue layout and the block-tile adjacency of the multimodal dialogue graph.
+
+The reference stores the graph as one dense (M*N x M*N) fp32 matrix
+(model_mm.py:125).  Its structure is block-sparse: per dialogue and modality a
+dense L_i x L_i tile plus M(M-1) cross-modal diagonals.  ``BlockTileAdjacency``
+keeps exactly that content (layout documented in include/mmdfn_hip.h).
+"""
+import numpy as np
+import torch
+
+_LAYOUT_CACHE = {}
+_LAYOUT_CACHE_MAX = 64
+
+
+def pair_list(M):
+    return [(m, n) for m in range(M) for n in range(m + 1, M)]
+
+
+class DialogueLayout:
+    """Index arrays describing a batch of B dialogues x M modalities."""
+
+    def __init__(self, lengths, M, device):
+        lens = np.asarray([int(x) for x in lengths], dtype=np.int64)
+        if lens.ndim != 1 or lens.size == 0 or (lens <= 0).any():
+            raise ValueError("dialogue lengths must be a non-empty list of positive ints")
+        self.lengths = [int(x) for x in lens]
+        self.B = int(lens.size)
+        self.M = int(M)
+        self.device = torch.device(device)
+        row_start = np.zeros(self.B + 1, dtype=np.int64)
+        row_start[1:] = np.cumsum(lens)
+        ld = (lens + 3) & ~3
+        tile_base = np.zeros(self.B + 1, dtype=np.int64)
+        tile_base[1:] = np.cumsum(self.M * lens * ld)
+        self.N = int(row_start[-1])
+        self.max_len = int(lens.max())
+        self.tile_elems = int(tile_base[-1])
+        self.npairs = self.M * (self.M - 1) // 2
+        self.nnz = int((self.M * lens * lens + self.M * (self.M - 1) * lens).sum())
+        self.row_start_host = row_start
+        self.tile_base_host = tile_base
+        self.ld_host = ld
+        i32 = np.concatenate([lens.astype(np.int32), row_start.astype(np.int32)])
+        self._i32 = torch.from_numpy(i32).to(self.device)
+        self.dia_len = self._i32[:self.B]
+        self.row_start = self._i32[self.B:]
+        self.tile_base = torch.from_numpy(tile_base).to(self.device)
+
+    @staticmethod
+    def get(lengths, M, device):
+        key = (tuple(int(x) for x in lengths), int(M), str(device))
+        lay = _LAYOUT_CACHE.get(key)
+        if lay is None:
+            if len(_LAYOUT_CACHE) >= _LAYOUT_CACHE_MAX:
+                _LAYOUT_CACHE.clear()
+            lay = DialogueLayout(lengths, M, device)
+            _LAYOUT_CACHE[key] = lay
+        return lay
+
+    # algorithmic bytes / flops of one propagate call
+    def propagate_bytes(self, d):
+        return 4 * self.nnz + 8 * self.M * self.N * d
+
+    def propagate_flops(self, d):
+        return 2 * d * self.nnz
+
+
+class BlockTileAdjacency:
+    """Normalised adjacency in block-tile storage (never dense on the hot path)."""
+
+    def __init__(self, layout, tiles, cross, symmetric=False, stacked_feats=None):
+        self.layout = layout
+        self.tiles = tiles
+        self.cross = cross
+        self.symmetric = bool(symmetric)
+        self.stacked_feats = stacked_feats  # (M, N, D) view of cat([a, v, l], 0), if available
+
+    @property
+    def requires_grad(self):
+        return self.tiles.requires_grad or self.cross.requires_grad
+
+    @property
+    def shape(self):
+        n = self.layout.M * self.layout.N
+        return (n, n)
+
+    def to_dense(self):
+        """Dense (MN x MN) matrix (tests / interoperability only)."""
+        lay = self.layout
+        M, N = lay.M, lay.N
+        dense = self.tiles.new_zeros(M * N, M * N)
+        for i, L in enumerate(lay.lengths):
+            ld = int(lay.ld_host[i])
+            rs = int(lay.row_start_host[i])
+            base = int(lay.tile_base_host[i])
+            for m in range(M):
+                t = self.tiles[base + m * L * ld: base + (m + 1) * L * ld].view(L, ld)[:, :L]
+                dense[m * N + rs:m * N + rs + L, m * N + rs:m * N + rs + L] = t
+        ar = torch.arange(N, device=self.tiles.device)
+        for k, (m, n) in enumerate(pair_list(M)):
+            dense[m * N + ar, n * N + ar] = self.cross[k]
+            dense[n * N + ar, m * N + ar] = self.cross[k]
+        return dense
+
+    @staticmethod
+    def from_parts(layout, tile_list, cross, device=None, symmetric=False):
+        """Pack per-(dialogue, modality) L x L tensors (dialogue-major, then modality) + cross (npairs, N)."""
+        device = device or layout.device
+        flat = torch.zeros(layout.tile_elems, dtype=torch.float32, device=device)
+        it = iter(tile_list)
+        for i, L in enumerate(layout.lengths):
+            ld = int(layout.ld_host[i])
+            base = int(layout.tile_base_host[i])
+            for m in range(layout.M):
+                t = next(it).to(device=device, dtype=torch.float32)
+                flat[base + m * L * ld: base + (m + 1) * L * ld].view(L, ld)[:, :L] = t
+        cross = cross.to(device=device, dtype=torch.float32).contiguous()
+        return BlockTileAdjacency(layout, flat, cross, symmetric)

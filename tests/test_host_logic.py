@@ -1,0 +1,115 @@
+"""CPU: host-side logic of the drop-in modules (no HIP calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mmdfn_oracle as O
+from mm_dfn_amd import synthetic, train
+from mm_dfn_amd.dialogue_model import DialogueGNNModel
+from mm_dfn_amd.layout import BlockTileAdjacency, DialogueLayout, pair_list
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_state_dict_keys_match_reference_fixture():
+    want = [l.split() for l in open(os.path.join(GOLD, "state_dict_keys_iemocap.txt")).read().strip().splitlines()]
+    m = synthetic.build_model(D_t=100, D_a=1582, D_v=342, P=2, C=6, nlayers=2)
+    got = [[k, "x".join(map(str, v.shape))] for k, v in m.state_dict().items()]
+    assert sorted(map(tuple, got)) == sorted(map(tuple, want))
+    assert len(got) == 86
+
+
+def test_layout_offsets():
+    lay = DialogueLayout([5, 3, 8], 3, "cpu")
+    assert lay.N == 16 and lay.max_len == 8 and lay.npairs == 3
+    assert lay.row_start.tolist() == [0, 5, 8, 16]
+    assert lay.tile_base.tolist() == [0, 3 * 5 * 8, 3 * 5 * 8 + 3 * 3 * 4, 3 * 5 * 8 + 3 * 3 * 4 + 3 * 8 * 8]
+    assert lay.nnz == sum(3 * L * L + 6 * L for L in (5, 3, 8))
+    assert lay.propagate_bytes(100) == 4 * lay.nnz + 8 * 3 * 16 * 100
+    # L=110, M=3, d=100 -> 411 840 B per dialogue-layer
+    assert DialogueLayout([110], 3, "cpu").propagate_bytes(100) == 411840
+
+
+def test_block_tile_dense_roundtrip():
+    rs = np.random.RandomState(0)
+    lengths, M = [4, 7, 1], 3
+    lay = DialogueLayout(lengths, M, "cpu")
+    tiles = [torch.from_numpy(rs.randn(L, L).astype(np.float32)) for L in lengths for _ in range(M)]
+    cross = torch.from_numpy(rs.randn(lay.npairs, lay.N).astype(np.float32))
+    adj = BlockTileAdjacency.from_parts(lay, tiles, cross)
+    flat = torch.cat([t.reshape(-1) for t in tiles])
+    # oracle packs without row padding; compare through the dense form
+    dense = adj.to_dense()
+    N = lay.N
+    assert torch.equal(dense[0:4, 0:4], tiles[0])
+    assert torch.equal(dense[N + 4:N + 11, N + 4:N + 11], tiles[4])
+    assert torch.equal(dense[2 * N + 11, 2 * N + 11], tiles[8][0, 0])
+    for k, (m, n) in enumerate(pair_list(M)):
+        assert torch.equal(dense[m * N + 3, n * N + 3], cross[k, 3]) and torch.equal(dense[n * N + 3, m * N + 3], cross[k, 3])
+    assert float(dense[0, 5]) == 0.0
+
+
+@pytest.mark.parametrize("P,lengths", [(2, [15, 9, 1, 6]), (9, [12, 12, 3]), (3, [1])])
+def test_encoders_match_oracle(P, lengths):
+    cfg = dict(B=len(lengths), L=max(lengths), P=P, C=6, nlayers=2, D_t=100, D_a=32, D_v=64)
+    m = synthetic.build_model(**cfg).eval()
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 3))
+    b = synthetic.make_batch(4, lengths=lengths, **cfg)
+    with torch.no_grad():
+        got = m.encode(b["textf"], b["qmask"], b["lengths"], b["acouf"], b["visuf"])
+        want = O.encoders(dict(m.state_dict()), b["textf"], b["qmask"], b["lengths"], b["acouf"], b["visuf"],
+                          O.default_cfg(2))
+    for i in range(3):
+        assert (got[i] - want[i]).abs().max() < 1e-5
+
+
+def test_party_plan_non_one_hot_last_speaker_wins():
+    """The reference scatters speaker by speaker (model.py:1084-1087): with two speakers flagged on one
+    utterance the later speaker's encoding overwrites the earlier one."""
+    cfg = dict(B=1, L=6, P=2, C=6, nlayers=2, D_t=100, D_a=32, D_v=64)
+    m = synthetic.build_model(**cfg).eval()
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 5))
+    b = synthetic.make_batch(6, lengths=[6], **cfg)
+    q = b["qmask"].clone()
+    q[2, 0, :] = 1.0
+    X = torch.randn(6, 1, 200)
+    with torch.no_grad():
+        got = m._party_encode([X], m._party_plan(q))[0]
+        # literal restatement of the reference loops
+        U_ = X.transpose(0, 1)
+        q_ = q.transpose(0, 1)
+        parts = [torch.zeros_like(U_) for _ in range(2)]
+        for p in range(2):
+            idx = torch.nonzero(q_[0][:, p]).squeeze(-1)
+            parts[p][0][:idx.numel()] = U_[0][idx]
+        E = [m.rnn_parties(parts[p].transpose(0, 1))[0].transpose(0, 1) for p in range(2)]
+        want = torch.zeros(1, 6, 200)
+        for p in range(2):
+            idx = torch.nonzero(q_[0][:, p]).squeeze(-1)
+            want[0][idx] = E[p][0][:idx.numel()]
+    assert (got.transpose(0, 1) - want).abs().max() < 1e-6
+
+
+def test_lengths_and_label_flatten():
+    b = synthetic.make_batch(1, B=4, L=9, P=2, C=6, D_t=8, D_a=8, D_v=8, lengths=[9, 2, 5, 1])
+    assert train.lengths_from_umask(b["umask"]) == [9, 2, 5, 1] == O.lengths_from_umask(b["umask"])
+    assert torch.equal(train.flatten_labels(b["label"], [9, 2, 5, 1]), O.flatten_labels(b["label"], [9, 2, 5, 1]))
+
+
+def test_synthetic_batch_contract():
+    b = synthetic.make_batch(2, ragged=True, **synthetic.CONFIGS["cfg3"])
+    L, B = b["textf"].shape[:2]
+    assert b["visuf"].shape == (L, B, 342) and b["acouf"].shape == (L, B, 300) and b["qmask"].shape == (L, B, 9)
+    assert b["umask"].shape == (B, L) and b["label"].shape == (B, L) and max(b["lengths"]) == L
+    for j, n in enumerate(b["lengths"]):
+        assert float(b["textf"][n:, j].abs().sum()) == 0 and float(b["qmask"][n:, j].sum()) == 0
+        assert torch.equal(b["qmask"][:n, j].sum(1), torch.ones(n))
+
+
+def test_out_of_scope_configurations_raise():
+    with pytest.raises(NotImplementedError):
+        DialogueGNNModel('DialogRNN', 100, 150, 150, 100, 100, 100, 100, 2, 200, 10, 10, graph_type='GDF')
+    with pytest.raises(NotImplementedError):
+        DialogueGNNModel('LSTM', 100, 150, 150, 100, 100, 100, 100, 2, 200, 10, 10, graph_type='relation')

@@ -1,0 +1,170 @@
+"""GPU: the drop-in modules (HIP path) against the golden vectors of the real reference
+and against the CPU oracle.  Logits within 1e-4 abs (north_star), gradients 1e-4..2e-4 rel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mmdfn_oracle as O
+from mm_dfn_amd import FocalLoss, GCNII_lyc, synthetic, train, ops
+from test_oracle_golden import E2E, GOLD, _digest, load
+from util import abs_err, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def hip_model(cfg, seed, dropout=0.0):
+    m = synthetic.build_model(dropout=dropout, **cfg)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), seed))
+    return m.to(DEV)
+
+
+def run(m, b):
+    return m(b["textf"].to(DEV), b["qmask"].to(DEV), b["umask"].to(DEV), b["lengths"], b["acouf"].to(DEV),
+             b["visuf"].to(DEV))[0]
+
+
+@pytest.mark.parametrize("name", sorted(E2E))
+def test_end_to_end_against_reference_golden(name):
+    cfg, seed, lengths = E2E[name]
+    g = load("e2e_%s.npz" % name)
+    b = synthetic.make_batch(seed + 1, lengths=lengths, **cfg)
+    m = hip_model(cfg, seed).eval()
+    with torch.no_grad():
+        logp = run(m, b)
+    assert np.abs(logp.cpu().numpy() - g["log_prob"]).max() < 1e-4
+    m.train()  # dropout p = 0
+    logp = run(m, b)
+    label = train.flatten_labels(b["label"].to(DEV), b["lengths"])
+    loss = FocalLoss(gamma=0.5)(logp, label)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    live = [str(x) for x in g["live_params"]]
+    for k in live:
+        want = g["gd/" + k]
+        assert grads[k] is not None, k
+        got = _digest(grads[k])
+        assert abs(got[1] - want[1]) / (want[1] + 1e-12) < 5e-4, k
+    for k, gr in grads.items():
+        if k not in live:
+            assert gr is None or float(gr.abs().max()) == 0.0, k
+    for k in [x[2:] for x in g.files if x.startswith("g/")]:
+        want = g["g/" + k]
+        assert np.abs(grads[k].cpu().numpy() - want).max() / np.abs(want).max() < 2e-4, k
+
+
+def test_gcnii_module_against_golden():
+    g = load("gcnii.npz")
+    for ci in range(3):
+        nl, reason = [int(x) for x in g["cfg%d" % ci]]
+        rs = np.random.RandomState(300 + ci)
+        lengths = [9, 4]
+        N = sum(lengths)
+        net = GCNII_lyc(nfeat=200, nlayers=nl, nhidden=100, nclass=6, dropout=0.0, lamda=0.5, alpha=0.2, variant=True,
+                        return_feature=True, use_residue=True, reason_flag=bool(reason))
+        net.load_state_dict(synthetic.seeded_state_dict(net.state_dict(), 300 + ci))
+        net = net.to(DEV).train()
+        x = torch.from_numpy(rs.randn(3 * N, 200).astype(np.float32)).to(DEV).requires_grad_(True)
+        feats = torch.stack([torch.from_numpy(rs.randn(N, 200).astype(np.float32)) for _ in range(3)], 0).to(DEV)
+        adj = ops.build_adjacency(feats, lengths)
+        R = torch.from_numpy(rs.randn(3 * N, 300).astype(np.float32)).to(DEV)
+        y = net(x, lengths, None, adj)
+        assert np.abs(y.detach().cpu().numpy() - g["y%d" % ci]).max() < 2e-5
+        (y * R).sum().backward()
+        assert rel_err(x.grad, torch.from_numpy(g["dx%d" % ci])) < 1e-4
+        assert rel_err(net.convs[0].weight.grad, torch.from_numpy(g["dW0_%d" % ci])) < 1e-4
+        # a dense adjacency tensor is accepted too (drop-in signature)
+        y2 = net(x.detach(), lengths, None, adj.to_dense())
+        assert abs_err(y2, y) < 2e-5
+
+
+def test_adjacency_against_golden():
+    g = load("adjacency.npz")
+    m = hip_model(E2E["deep16"][0], 1)
+    for ci in range(3):
+        lengths = [int(x) for x in g["lengths%d" % ci]]
+        rs = np.random.RandomState(200 + ci)
+        N = sum(lengths)
+        feats = [torch.from_numpy(rs.randn(N, 200).astype(np.float32)).to(DEV).requires_grad_(True) for _ in range(3)]
+        R = torch.from_numpy(rs.randn(3 * N, 3 * N).astype(np.float32)).to(DEV)
+        adj = m.graph_model.create_big_adj(feats[0], feats[1], feats[2], lengths, ['a', 'v', 'l'])
+        dense = adj.to_dense()
+        assert np.abs(dense.detach().cpu().numpy() - g["adj%d" % ci]).max() < 2e-5
+        (dense * R).sum().backward()
+        got = np.stack([f.grad.cpu().numpy() for f in feats], 0)
+        want = g["dfeats%d" % ci]
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-4
+
+
+@pytest.mark.parametrize("cfgname,ragged", [("cfg2", False), ("cfg2", True), ("cfg3", True)])
+def test_full_size_against_oracle_forward(cfgname, ragged):
+    """BASELINE.json sizes, eval logits vs the CPU oracle (aten GRU engine)."""
+    cfg = dict(synthetic.CONFIGS[cfgname])
+    b = synthetic.make_batch(41, ragged=ragged, **cfg)
+    m = hip_model(cfg, 40).eval()
+    with torch.no_grad():
+        got = run(m, b)
+        want = O.forward({k: v.cpu() for k, v in m.state_dict().items()}, b["textf"], b["qmask"], b["umask"],
+                         b["lengths"], b["acouf"], b["visuf"], O.default_cfg(cfg["nlayers"]), engine="aten")
+    assert abs_err(got, want) < 1e-4
+
+
+def test_three_step_training_trace_against_golden():
+    g = load("train_trace.npz")
+    cfg = dict(B=3, L=24, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+    m = hip_model(cfg, 500)
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4)
+    loss_f = FocalLoss(gamma=0.5)
+    names = ["c%d" % i for i in range(6)]
+    losses, preds = [], []
+    for s, lengths in enumerate([[24, 11, 17], [9, 24, 2], [13, 13, 20]]):
+        b = synthetic.make_batch(600 + s, lengths=lengths, **cfg)
+        data = [b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"], ["v%d" % s]]
+        res = train.train_or_eval_graph_model(m, loss_f, [data], 0, True, opt, True, 'avl', names)
+        losses.append(res[2])
+        preds.append(res[5])
+    assert np.abs(np.array(losses) - g["losses"]).max() < 2e-4
+    assert (np.concatenate(preds) == g["preds"]).mean() > 0.99
+    assert np.abs(m.smax_fc.weight.detach().cpu().numpy() - g["smax_fc.weight"]).max() < 1e-5
+    assert np.abs(m.graph_model.graph_net.convs[1].weight.detach().cpu().numpy() - g["convs1"]).max() < 1e-5
+    assert np.abs(m.linear_a.bias.detach().cpu().numpy() - g["linear_a.bias"]).max() < 1e-5
+
+
+def test_size_independent_properties_at_full_size():
+    """cfg4 shard size: propagate is linear in H; every normalised-adjacency row block reproduces
+    D^-1/2 A D^-1/2 (rows of A_hat . sqrt(deg) == sqrt(deg))."""
+    cfg = dict(synthetic.CONFIGS["cfg4"])
+    rs = np.random.RandomState(9)
+    lengths = synthetic.make_lengths(rs, cfg["B"], cfg["L"], True)
+    N = sum(lengths)
+    feats = torch.from_numpy(rs.randn(3, N, 200).astype(np.float32)).to(DEV)
+    adj = ops.build_adjacency(feats, lengths)
+    H1 = torch.randn(3 * N, 100, device=DEV)
+    H2 = torch.randn(3 * N, 100, device=DEV)
+    lhs = ops.propagate(adj, 2.0 * H1 - 0.5 * H2)
+    rhs = 2.0 * ops.propagate(adj, H1) - 0.5 * ops.propagate(adj, H2)
+    assert rel_err(lhs, rhs) < 1e-5
+    # A_hat = R A R with R = deg^-1/2, so A_hat . (1/r) = R . (A . 1) = R . deg = 1/r
+    unit = feats / feats.norm(dim=2, keepdim=True)
+    # recover r from the diagonal: A_hat[p,p] = S_pp r_p^2, S_pp = sim(|u|^2)
+    lay = adj.layout
+    diag = []
+    for i, L in enumerate(lengths):
+        ld = int(lay.ld_host[i]); base = int(lay.tile_base_host[i])
+        for m_ in range(3):
+            diag.append(adj.tiles[base + m_ * L * ld: base + (m_ + 1) * L * ld].view(L, ld).diagonal())
+    # reorder (dialogue-major, modality) -> modality-major rows
+    r2 = torch.zeros(3, N, device=DEV)
+    k = 0
+    start = 0
+    for i, L in enumerate(lengths):
+        for m_ in range(3):
+            r2[m_, start:start + L] = diag[k]; k += 1
+        start += L
+    spp = 1.0 - torch.acos((unit * unit).sum(2) * 0.99999) / np.pi
+    inv_r = torch.sqrt(spp / r2).reshape(3 * N, 1).repeat(1, 4)
+    out = ops.propagate(adj, inv_r.contiguous())
+    assert rel_err(out, inv_r) < 1e-4
