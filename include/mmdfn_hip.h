@@ -93,6 +93,30 @@ int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross,
                         const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                         int B, int M, int N, int D, int max_len, float modal_weight, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K2  fused GRU recurrence (replaces the time loop inside nn.GRU for ``lstm_l``
+ * and ``rnn_parties``: model.py:866,868, called at :1082,1112,1132,1145).
+ * One layer, both directions, `ngroups` independent GRUs in one launch
+ * (host arrays of device pointers, one entry per group; ngroups <= 4):
+ *   gi[g]    : (T, rows, 2, 3H)  X W_ih^T + b_ih for both directions (dir-major columns)
+ *   w_hh[g]  : (2, 3H, H), b_hh[g] : (2, 3H)        gate order r, z, n
+ *   y[g]     : (T, rows, 2H) out; direction 1 runs t = T-1 .. 0; zero initial state
+ *   gates[g] : (T, rows, 2, 4, H) out: r, z, n and W_hn h + b_hn (saved for backward)
+ * H must be 100 (the reference hard-codes D_e = 100).
+ * ------------------------------------------------------------------------- */
+int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const float* const* w_hh,
+                      const float* const* b_hh, float* const* y, float* const* gates,
+                      const int* rows, const int* T, int H, void* stream);
+
+/* Backward through time of the same recurrence: given dy[g] (T, rows, 2H) writes
+ *   dgi[g], dgh[g] : (T, rows, 2, 3H)  gradients of the input-side / hidden-side gate
+ *   pre-activations (they differ only in the n gate: dgh_n = dgi_n * r).
+ * Weight gradients are dense contractions of these done by the caller. */
+int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const float* const* y,
+                      const float* const* gates, const float* const* w_hh,
+                      float* const* dgi, float* const* dgh,
+                      const int* rows, const int* T, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

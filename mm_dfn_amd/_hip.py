@@ -23,6 +23,8 @@ SIGNATURES = {
     "mmdfn_tile_outer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_adj_build": [_P] * 8 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
     "mmdfn_adj_build_bwd": [_P] * 15 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
+    "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 
 ABI_VERSION = 1
@@ -76,3 +78,12 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise HipLibraryError("the MM-DFN HIP path needs tensors on an MI355X device (got %s); "
                                   "there is no CPU fallback" % t.device)
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (one per group) for the grouped entry points."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import gru as fused_gru
 from .mm_gcn import MM_GCN
 
 _FLAT_CACHE = {}
@@ -169,8 +170,9 @@ class DialogueGNNModel(nn.Module):
         sel = mask & (later == 0)
         return src, rank.clamp_(min=0), sel
 
-    def _party_encode(self, X_list, plan):
-        """X_list: per-modality (L, B, H) projections -> per-modality U_p (L, B, H); one batched BiGRU call."""
+    @staticmethod
+    def _party_gather(X_list, plan):
+        """Per-modality (L, B, H) projections -> (L, Mn*B*P, H) speaker-compacted party sequences."""
         src, rank, sel = plan
         L, B, P = src.shape
         Mn = len(X_list)
@@ -179,29 +181,47 @@ class DialogueGNNModel(nn.Module):
         Xp = torch.cat([X, X.new_zeros(Mn, 1, B, H)], 1)               # zero row at index L
         g_idx = src.view(1, L, B, P, 1).expand(Mn, L, B, P, H)
         S = Xp.unsqueeze(3).expand(Mn, L + 1, B, P, H).gather(1, g_idx)  # (Mn, L, B, P, H)
-        S = S.permute(1, 0, 2, 3, 4).reshape(L, Mn * B * P, H)
-        E = self.rnn_parties(S)[0]                                       # (L, Mn*B*P, H)
+        return S.permute(1, 0, 2, 3, 4).reshape(L, Mn * B * P, H)
+
+    @staticmethod
+    def _party_scatter(E, plan, Mn):
+        """(L, Mn*B*P, H) party encodings -> per-modality U_p (L, B, H) at the speakers' own positions."""
+        src, rank, sel = plan
+        L, B, P = src.shape
+        H = E.shape[-1]
         E = E.view(L, Mn, B, P, H).permute(1, 0, 2, 3, 4)               # (Mn, L, B, P, H)
         s_idx = rank.view(1, L, B, P, 1).expand(Mn, L, B, P, H)
         back = E.gather(1, s_idx) * sel.view(1, L, B, P, 1).to(E.dtype)
         U = back.sum(3)                                                  # (Mn, L, B, H)
         return [U[i] for i in range(Mn)]
 
+    def _run_grus(self, xs, grus):
+        """Always the fused HIP recurrence (raises on CPU tensors: there is no fallback)."""
+        return fused_gru.bigru2(xs, grus, self.dropout, self.training)
+
+    def _party_encode(self, X_list, plan):
+        E = self._run_grus([self._party_gather(X_list, plan)], [self.rnn_parties])[0]
+        return self._party_scatter(E, plan, len(X_list))
+
     def encode(self, U, qmask, seq_lengths, U_a, U_v):
         """Projection + context BiGRU (text) + speaker-party BiGRU (all modalities) ->
-        (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209)."""
+        (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209).
+        The context GRU and the batched party GRU are independent and share every recurrence launch."""
         Xa = self.linear_a(U_a)
         Xv = self.linear_v(U_v)
         Xl = self.linear_l(U)
-        ctx = self.lstm_l(Xl)[0]
-        ea, ev, el = Xa, Xv, ctx
         if self.use_crn_speaker:
             plan = self._party_plan(qmask)
-            Pa, Pv, Pl = self._party_encode([Xa, Xv, Xl], plan)
+            S = self._party_gather([Xa, Xv, Xl], plan)
+            ctx, E = self._run_grus([Xl, S], [self.lstm_l, self.rnn_parties])
+            Pa, Pv, Pl = self._party_scatter(E, plan, 3)
             w = self.speaker_weights
-            ea = ea + w[0] * Pa
-            ev = ev + w[1] * Pv
-            el = el + w[2] * Pl
+            ea = Xa + w[0] * Pa
+            ev = Xv + w[1] * Pv
+            el = ctx + w[2] * Pl
+        else:
+            ea, ev = Xa, Xv
+            el = self._run_grus([Xl], [self.lstm_l])[0]
         L, B, H = Xa.shape
         idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
         return torch.stack([ea, ev, el], 0).reshape(3, L * B, H).index_select(1, idx)

@@ -1,0 +1,89 @@
+"""2-layer bidirectional GRU encoders on the fused HIP recurrence (csrc/gru.hip).
+
+``bigru2(xs, grus, ...)`` evaluates several *independent* nn.GRU(200, 100, 2 layers, bidirectional)
+modules (the reference's ``lstm_l`` and ``rnn_parties``, model.py:866,868) layer by layer:
+per layer ONE dense input GEMM per module (all timesteps, both directions) and ONE persistent
+recurrence launch shared by all modules.  The nn.GRU modules only hold the parameters (so the
+state_dict keys stay the reference's); their own forward (MIOpen) is never called.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _hip
+
+H = 100
+
+
+class _GruRecurrence(torch.autograd.Function):
+    """args = (gi_0, w_hh_0, b_hh_0, gi_1, w_hh_1, b_hh_1, ...) -> (y_0, y_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        n = len(args) // 3
+        gis = [args[3 * g].contiguous() for g in range(n)]
+        whh = [args[3 * g + 1].contiguous() for g in range(n)]
+        bhh = [args[3 * g + 2].contiguous() for g in range(n)]
+        _hip.require_cuda(*gis)
+        ys, gates, rows, Ts = [], [], [], []
+        for gi in gis:
+            T, R = gi.shape[0], gi.shape[1]
+            ys.append(torch.empty(T, R, 2 * H, dtype=torch.float32, device=gi.device))
+            gates.append(torch.empty(T, R, 2, 4, H, dtype=torch.float32, device=gi.device))
+            rows.append(R)
+            Ts.append(T)
+        rc = _hip.lib().mmdfn_gru_seq_fwd(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
+                                          _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
+                                          _hip.int_array(Ts), H, _hip.stream())
+        _hip.check(rc, "mmdfn_gru_seq_fwd")
+        ctx.n = n
+        ctx.save_for_backward(*ys, *gates, *whh)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        ys, gates, whh = saved[:n], saved[n:2 * n], saved[2 * n:]
+        dys = [dy.contiguous() if dy is not None else torch.zeros_like(y) for dy, y in zip(dys, ys)]
+        dgi = [torch.empty(y.shape[0], y.shape[1], 6 * H, dtype=torch.float32, device=y.device) for y in ys]
+        dgh = [torch.empty_like(t) for t in dgi]
+        rows = [y.shape[1] for y in ys]
+        Ts = [y.shape[0] for y in ys]
+        rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
+                                          _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
+                                          _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
+        _hip.check(rc, "mmdfn_gru_seq_bwd")
+        out = []
+        for g in range(n):
+            y, d = ys[g], dgh[g]
+            # dW_hh = sum_t dgh_t (x) h_{t-1}: forward direction h_{t-1} = y[t-1], reverse h_{t-1} = y[t+1]
+            dwf = d[1:, :, :3 * H].reshape(-1, 3 * H).t() @ y[:-1, :, :H].reshape(-1, H)
+            dwr = d[:-1, :, 3 * H:].reshape(-1, 3 * H).t() @ y[1:, :, H:].reshape(-1, H)
+            out += [dgi[g], torch.stack([dwf, dwr], 0), d.sum((0, 1)).view(2, 3 * H)]
+        return tuple(out)
+
+
+def _layer_params(gru, layer):
+    sfx = "_l%d" % layer
+    w_ih = torch.cat([getattr(gru, "weight_ih" + sfx), getattr(gru, "weight_ih" + sfx + "_reverse")], 0)
+    b_ih = torch.cat([getattr(gru, "bias_ih" + sfx), getattr(gru, "bias_ih" + sfx + "_reverse")], 0)
+    w_hh = torch.stack([getattr(gru, "weight_hh" + sfx), getattr(gru, "weight_hh" + sfx + "_reverse")], 0)
+    b_hh = torch.stack([getattr(gru, "bias_hh" + sfx), getattr(gru, "bias_hh" + sfx + "_reverse")], 0)
+    return w_ih, b_ih, w_hh, b_hh
+
+
+def bigru2(xs, grus, dropout=0.0, training=False):
+    """xs[g]: (T, rows_g, 200) -> ys[g]: (T, rows_g, 200); grus[g]: the nn.GRU holding group g's weights."""
+    for gru in grus:
+        if gru.hidden_size != H or gru.num_layers != 2 or not gru.bidirectional or gru.batch_first:
+            raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
+    cur = list(xs)
+    for layer in range(2):
+        args = []
+        for x, gru in zip(cur, grus):
+            w_ih, b_ih, w_hh, b_hh = _layer_params(gru, layer)
+            args += [F.linear(x, w_ih, b_ih), w_hh, b_hh]      # hoisted input contraction (all t, both directions)
+        cur = list(_GruRecurrence.apply(*args))
+        if layer == 0 and training and dropout > 0:
+            cur = [F.dropout(y, dropout, True) for y in cur]
+    return cur
