@@ -1,0 +1,85 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (flat gradient bucket + global-N loss scaling)
+reproduces the single-process gradient of one big batch.  The model here is a small torch stand-in
+(the HIP modules need a GPU); what is under test is mm_dfn_amd.distributed itself."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from mm_dfn_amd import distributed
+from mm_dfn_amd.loss import FocalLoss
+
+
+class Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16)
+        self.dead = torch.nn.Linear(3, 3)     # never reached: must stay out of the bucket
+        self.b = torch.nn.Linear(16, 6)
+
+    def forward(self, x):
+        return torch.log_softmax(self.b(torch.relu(self.a(x))), 1)
+
+
+def make_data():
+    rs = np.random.RandomState(0)
+    lengths = [9, 4, 7, 2, 5, 11]
+    xs = [torch.from_numpy(rs.randn(n, 8).astype(np.float32)) for n in lengths]
+    ys = [torch.from_numpy(rs.randint(0, 6, size=n)) for n in lengths]
+    return lengths, xs, ys
+
+
+def worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    distributed.init(backend="gloo")
+    torch.manual_seed(0)
+    model = Tiny()
+    lengths, xs, ys = make_data()
+    mine = distributed.shard_dialogues(lengths, world, rank)
+    x = torch.cat([xs[i] for i in mine])
+    y = torch.cat([ys[i] for i in mine])
+    n_local = x.shape[0]
+    n_global = distributed.all_reduce_scalar(n_local, device="cpu")
+    bucket = distributed.GradientBucket(model)
+    loss_f = FocalLoss(gamma=0.5)
+    for _ in range(2):   # second step exercises the re-attached views
+        model.zero_grad(set_to_none=True)
+        loss = loss_f(model(x), y) * (n_local * world / n_global)
+        loss.backward()
+        flat = bucket.all_reduce()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    if rank == 0:
+        torch.save({"grads": grads, "n_global": n_global, "bucket": flat.numel(), "shard": mine}, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_single_process(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    model = Tiny()
+    lengths, xs, ys = make_data()
+    FocalLoss(gamma=0.5)(model(torch.cat(xs)), torch.cat(ys)).backward()
+    assert got["n_global"] == sum(lengths)
+    assert got["bucket"] == sum(p.numel() for n, p in model.named_parameters() if not n.startswith("dead"))
+    assert "dead.weight" not in got["grads"]
+    for k, p in model.named_parameters():
+        if k.startswith("dead"):
+            continue
+        assert (got["grads"][k] - p.grad).abs().max() < 1e-6, k
+
+
+def test_shard_dialogues_balanced_and_complete():
+    lengths = [110, 27, 64, 90, 33, 110, 45, 71]
+    parts = [distributed.shard_dialogues(lengths, 4, r) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(8))
+    loads = [sum(lengths[i] ** 2 for i in p) for p in parts]
+    assert max(loads) / min(loads) < 1.6
