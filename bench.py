@@ -35,22 +35,30 @@ def parse():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
 
-def time_propagate(adj_builder, lay_d, iters=50):
-    """Average duration (ms) of one K6 propagate launch, HIP events on the launch stream."""
+def time_propagate(adj_builder, lay_d, iters=200):
+    """Average duration (ms) of one K6 propagate launch: `iters` back-to-back launches captured in a hipGraph
+    (so the host is out of the picture) and bracketed by HIP events on the replay stream."""
     from mm_dfn_amd import ops
     adj, H = adj_builder()
-    s = torch.cuda.current_stream()
     for _ in range(5):
         ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            out = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    g.replay()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record(s)
-    for _ in range(iters):
-        ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    g.replay()
     e1.record(s)
     e1.synchronize()
     return e0.elapsed_time(e1) / iters
@@ -120,16 +128,32 @@ def main():
     dp = distributed.GradientBucket(model) if world > 1 else None
     total_utt = distributed.all_reduce_scalar(n_utt) if world > 1 else n_utt
 
-    def step():
-        model.zero_grad(set_to_none=True)
+    scale = (n_utt * world / total_utt) if dp is not None else 1.0
+
+    def fwd_bwd():
         logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
         loss = loss_f(logp, label)
         if dp is not None:
-            loss = loss * (n_utt * world / total_utt)   # mean over the GLOBAL utterance count after averaging
+            loss = loss * scale        # mean over the GLOBAL utterance count once the bucket is averaged
         loss.backward()
-        if dp is not None:
-            dp.all_reduce()
         return loss
+
+    if a.no_graph:
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss = fwd_bwd()
+            if dp is not None:
+                dp.all_reduce()
+            return loss
+    else:
+        from mm_dfn_amd.graphs import CapturedStep
+        captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
+
+        def step():
+            loss = captured.replay()
+            if dp is not None:
+                dp.all_reduce_attached()
+            return loss
 
     for _ in range(a.warmup):
         step()
@@ -165,7 +189,7 @@ def main():
             "metric": "utterances/sec (fwd+bwd), IEMOCAP-shaped batch", "value": total_utt * a.steps / dt,
             "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "launch": "eager" if a.no_graph else "hipGraph replay of the whole step",
             "config": {"workload": "%s: B=%d dialogues/GPU, L=%s, dims %d/%d/%d, %d GCN layers, P=%d, dropout %.2f"
                                    % (a.config, cfg["B"], "ragged<=%d" % cfg["L"] if a.ragged else cfg["L"], cfg["D_t"],
                                       cfg["D_a"], cfg["D_v"], cfg["nlayers"], cfg["P"], a.dropout),

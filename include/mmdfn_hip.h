@@ -47,11 +47,14 @@ int mmdfn_abi_version(void);
  *                                                model_GCN.py:178)
  *   out[(m,r),:] = sum_q tile_{i,m}[r,q] * H[(m,q),:] + sum_{n!=m} cross_{mn}[r] * H[(n,r),:]
  *   transpose != 0 uses tile^T (for dH = A^T . dO when tiles are not symmetric).
- *   H, out: (M*N, d) fp32, d % 4 == 0.  max_len = max_i dia_len[i].
+ *   H, out: M*N rows of d fp32 with row strides ldh / ldo floats (>= d, multiples of 4, so a
+ *   column slice of a wider matrix can be read or written in place); d % 4 == 0.
+ *   max_len = max_i dia_len[i].
  * ------------------------------------------------------------------------- */
 int mmdfn_propagate(const float* tiles, const float* cross, const float* H, float* out,
                     const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                    int B, int M, int N, int d, int max_len, int transpose, void* stream);
+                    int B, int M, int N, int d, int ldh, int ldo, int max_len, int transpose,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------
  * K6 backward w.r.t. the adjacency, restricted to the stored pattern
@@ -59,11 +62,12 @@ int mmdfn_propagate(const float* tiles, const float* cross, const float* H, floa
  * (MN x MN) gradient from SpmmBackward):
  *   dtiles_{i,m}[p,q] (+)= X[(m,p),:] . Y[(m,q),:]
  *   dcross_{mn}[r]    (+)= X[(m,r),:].Y[(n,r),:] + X[(n,r),:].Y[(m,r),:]
- *   with X = dOut, Y = H.  accumulate != 0 adds into dtiles/dcross.
+ *   with X = dOut, Y = H (row strides ldx / ldy floats).  accumulate != 0 adds into dtiles/dcross.
  * ------------------------------------------------------------------------- */
 int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, float* dcross,
                      const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                     int B, int M, int N, int d, int max_len, int accumulate, void* stream);
+                     int B, int M, int N, int d, int ldx, int ldy, int max_len, int accumulate,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------
  * K5  adjacency build (replaces MM_GCN.create_big_adj, model_mm.py:122-180)
@@ -116,6 +120,32 @@ int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const float* const* y
                       const float* const* gates, const float* const* w_hh,
                       float* const* dgi, float* const* dgh,
                       const int* rows, const int* T, int H, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K8  LSTM-cell gate math of the "reasoning" / dynamic-fusion module (replaces the pointwise part
+ * of nn.LSTM with seq_len 1, model_GCN.py:433,466; gate order i, f, g, o):
+ *   G (R, 4H) = x W_ih^T + b_ih + h W_hh^T + b_hh   (dense contractions done by the caller)
+ *   c = sig(f) c_prev + sig(i) tanh(g) ;  h = sig(o) tanh(c).   c_prev may be NULL (zero state).
+ * Backward: dG (R, 4H), dc_prev (R, H) from dh, dc_next (either may be NULL = zero).
+ * ------------------------------------------------------------------------- */
+int mmdfn_lstm_pointwise_fwd(const float* G, const float* c_prev, float* h_out, float* c_out,
+                             int64_t R, int H, void* stream);
+int mmdfn_lstm_pointwise_bwd(const float* G, const float* c_prev, const float* c_new,
+                             const float* dh, const float* dc_next, float* dG, float* dc_prev,
+                             int64_t R, int H, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K7  GCNII update (replaces model_GCN.py:179-186 variant branch + :469-472):
+ *   S2 (R, 2d) = [A.x | h0],  P (R, d) = S2 . W  (contraction done by the caller)
+ *   out = relu(theta P + (1-theta)((1-alpha) A.x + alpha h0)) * mask + q
+ *   mask (dropout keep-mask already scaled by 1/(1-p)) and q may be NULL.
+ * Backward: dP (R, d) and dS2 (R, 2d) from dout (dq = dout is the caller's).
+ * ------------------------------------------------------------------------- */
+int mmdfn_gcnii_combine_fwd(const float* P, const float* S2, const float* q, const float* mask,
+                            float* out, float theta, float alpha, int64_t R, int d, void* stream);
+int mmdfn_gcnii_combine_bwd(const float* P, const float* S2, const float* mask, const float* dout,
+                            float* dP, float* dS2, float theta, float alpha, int64_t R, int d,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,16 +15,21 @@ _lib = None
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
+_L = ctypes.c_int64
 
 # name -> argtypes; must list every symbol of include/mmdfn_hip.h
 SIGNATURES = {
     "mmdfn_abi_version": [],
-    "mmdfn_propagate": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "mmdfn_tile_outer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_propagate": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_tile_outer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_adj_build": [_P] * 8 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
     "mmdfn_adj_build_bwd": [_P] * 15 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
     "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "mmdfn_lstm_pointwise_fwd": [_P, _P, _P, _P, _L, _I, _P],
+    "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
+    "mmdfn_gcnii_combine_bwd": [_P, _P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
 }
 
 ABI_VERSION = 1

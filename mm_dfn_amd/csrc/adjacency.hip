@@ -227,8 +227,8 @@ extern "C" int mmdfn_adj_build(const float* feats, float* unit, float* norm, flo
     hipLaunchKernelGGL(unit_cross_kernel, dim3((N + 3) / 4), dim3(256), 0, s, feats, unit, norm, cdot, cross, rdeg, M,
                        N, D, modal_weight);
     MMDFN_CHECK_LAUNCH();
-    int rc = mmdfn_launch_tile_dot(unit, unit, tiles, cosg, rdeg, dia_len, row_start, tile_base, B, M, N, D, max_len,
-                                   1, 0, s);
+    int rc = mmdfn_launch_tile_dot(unit, unit, tiles, cosg, rdeg, dia_len, row_start, tile_base, B, M, N, D, D, D,
+                                   max_len, 1, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(rdeg_cross_kernel, dim3((N + 255) / 256), dim3(256), 0, s, rdeg, cross, M, N);
     MMDFN_CHECK_LAUNCH();
@@ -261,8 +261,8 @@ extern "C" int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross, con
     hipLaunchKernelGGL(bwd_ecross_kernel, dim3((N + 255) / 256), dim3(256), 0, s, dcross, cdot, rdeg, ddeg, ecross, M,
                        N, modal_weight);
     MMDFN_CHECK_LAUNCH();
-    int rc = mmdfn_launch_propagate(etile, ecross, unit, dunit, dia_len, row_start, tile_base, B, M, N, D, max_len, 0,
-                                    s);
+    int rc = mmdfn_launch_propagate(etile, ecross, unit, dunit, dia_len, row_start, tile_base, B, M, N, D, D, D, max_len,
+                                    0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(unit_bwd_kernel, dim3((unsigned)(((int64_t)M * N + 3) / 4)), dim3(256), 0, s, unit, norm,
                        dunit, dfeats, (int64_t)M * N, D);

@@ -38,9 +38,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // launchers implemented in propagate.hip / tile_dot.hip, used by adjacency.hip
 int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* H, float* out,
                            const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                           int B, int M, int N, int d, int max_len, int transpose, hipStream_t s);
+                           int B, int M, int N, int d, int ldh, int ldo, int max_len, int transpose, hipStream_t s);
 
 // EPI 0: dtiles (+)= X.Y^T ; EPI 1: cosine Gram + raw similarity + row degree
 int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
                           const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                          int B, int M, int N, int K, int max_len, int epi, int accumulate, hipStream_t s);
+                          int B, int M, int N, int K, int ldx, int ldy, int max_len, int epi, int accumulate, hipStream_t s);

@@ -26,7 +26,7 @@ template <int NW, int NCT, bool TRANS>
 __global__ __launch_bounds__(64 * NW) void propagate_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
-    const int64_t* __restrict__ tile_base, int M, int N, int d, int max_rb) {
+    const int64_t* __restrict__ tile_base, int M, int N, int d, int ldh, int ldo, int max_rb) {
     constexpr int BM = 16 * NW;
     constexpr int CB = 16 * NCT;
     constexpr int LDH = CB + 2;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * NW) void propagate_kernel(
     const int ld = (L + 3) & ~3;
     const int rs = row_start[i];
     const float* T = tiles + tile_base[i] + (int64_t)m * L * ld;
-    const float* Hm = H + ((int64_t)m * N + rs) * d;
+    const float* Hm = H + ((int64_t)m * N + rs) * ldh;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * NW) void propagate_kernel(
             const int k = k0 + kk;
             const int c = c0 + 4 * c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < L && c < d) v = *reinterpret_cast<const float4*>(Hm + (int64_t)k * d + c);
+            if (k < L && c < d) v = *reinterpret_cast<const float4*>(Hm + (int64_t)k * ldh + c);
             float2* dst = reinterpret_cast<float2*>(&Hs[kk * LDH + 4 * c4]);
             dst[0] = make_float2(v.x, v.y);
             dst[1] = make_float2(v.z, v.w);
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(64 * NW) void propagate_kernel(
             const int col = c0 + ct * 16 + frow;
             if (col >= d) continue;
             float v = acc[ct][r];
-            for (int e = 0; e < nc; ++e) v += cw[e] * H[((int64_t)cn[e] * N + grow) * d + col];
-            out[((int64_t)m * N + grow) * d + col] = v;
+            for (int e = 0; e < nc; ++e) v += cw[e] * H[((int64_t)cn[e] * N + grow) * ldh + col];
+            out[((int64_t)m * N + grow) * ldo + col] = v;
         }
     }
 }
@@ -154,7 +154,7 @@ template <int NWR, int NWC, int NCTW, int BKT, int RPW>
 __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_v2_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
-    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int max_rb, int ncb, int abl) {
+    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl) {
     // RPW = 16-row tiles per wave: every B fragment read from LDS feeds RPW MFMAs, and the H rows are
     // staged once per 16*RPW*NWR output rows (L2 -> LDS traffic scales with 1 / (RPW*NWR)).
     constexpr int NT = 64 * NWR * NWC;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
     const int ld = (L + 3) & ~3;
     const int rs = row_start[i];
     const float* T = tiles + tile_base[i] + (int64_t)m * L * ld;
-    const float* Hm = H + ((int64_t)m * N + rs) * d;
+    const float* Hm = H + ((int64_t)m * N + rs) * ldh;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
     do {                                                                                                  \
         _Pragma("unroll") for (int e = 0; e < NH4; ++e) {                                                 \
             const int k_ = (K0) + s_kk[e];                                                                \
-            hset[SET][e] = *reinterpret_cast<const float4*>(s_ptr[e] + (int64_t)(k_ < L ? k_ : L - 1) * d); \
+            hset[SET][e] = *reinterpret_cast<const float4*>(s_ptr[e] + (int64_t)(k_ < L ? k_ : L - 1) * ldh); \
         }                                                                                                 \
         _Pragma("unroll") for (int rp = 0; rp < RPW; ++rp)                                                \
             _Pragma("unroll") for (int h = 0; h < NSUB; ++h) {                                            \
@@ -338,13 +338,13 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
                 const int n = q + (q >= m ? 1 : 0);
                 const int pk = (m < n) ? mmdfn_pair_index(m, n, M) : mmdfn_pair_index(n, m, M);
                 const float cwt = cross[(int64_t)pk * N + grow];
-                const float4 h = *reinterpret_cast<const float4*>(H + ((int64_t)n * N + grow) * d + c0 + 4 * c4);
+                const float4 h = *reinterpret_cast<const float4*>(H + ((int64_t)n * N + grow) * ldh + c0 + 4 * c4);
                 v.x = fmaf(cwt, h.x, v.x);
                 v.y = fmaf(cwt, h.y, v.y);
                 v.z = fmaf(cwt, h.z, v.z);
                 v.w = fmaf(cwt, h.w, v.w);
             }
-            *reinterpret_cast<float4*>(out + ((int64_t)m * N + grow) * d + c0 + 4 * c4) = v;
+            *reinterpret_cast<float4*>(out + ((int64_t)m * N + grow) * ldo + c0 + 4 * c4) = v;
         }
     }
 }
@@ -356,8 +356,8 @@ int ablation() {
 
 template <int NWR, int NWC, int NCTW, int BKT, int RPW>
 int launch_v2(const float* tiles, const float* cross, const float* H, float* out, const int32_t* dia_len,
-              const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int d, int max_len,
-              hipStream_t s) {
+              const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int d, int ldh, int ldo,
+              int max_len, hipStream_t s) {
     const int BM = 16 * NWR * RPW;
     const int CB = 16 * NCTW * NWC;
     const int max_rb = (max_len + BM - 1) / BM;
@@ -365,7 +365,7 @@ int launch_v2(const float* tiles, const float* cross, const float* H, float* out
     dim3 grid(((B + 7) / 8) * 8 * M * max_rb * ncb);
     dim3 block(64 * NWR * NWC);
     hipLaunchKernelGGL((propagate_v2_kernel<NWR, NWC, NCTW, BKT, RPW>), grid, block, 0, s, tiles, cross, H, out, dia_len,
-                       row_start, tile_base, B, M, N, d, max_rb, ncb, ablation());
+                       row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, ablation());
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -377,18 +377,18 @@ int tuning_override() {
 
 template <int NW, int NCT>
 int launch(const float* tiles, const float* cross, const float* H, float* out, const int32_t* dia_len,
-           const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int d, int max_len,
-           int transpose, hipStream_t s) {
+           const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int d, int ldh, int ldo,
+           int max_len, int transpose, hipStream_t s) {
     const int BM = 16 * NW;
     const int max_rb = (max_len + BM - 1) / BM;
     dim3 grid(B * max_rb, M, (d + 16 * NCT - 1) / (16 * NCT));
     dim3 block(64 * NW);
     if (transpose)
         hipLaunchKernelGGL((propagate_kernel<NW, NCT, true>), grid, block, 0, s, tiles, cross, H, out, dia_len,
-                           row_start, tile_base, M, N, d, max_rb);
+                           row_start, tile_base, M, N, d, ldh, ldo, max_rb);
     else
         hipLaunchKernelGGL((propagate_kernel<NW, NCT, false>), grid, block, 0, s, tiles, cross, H, out, dia_len,
-                           row_start, tile_base, M, N, d, max_rb);
+                           row_start, tile_base, M, N, d, ldh, ldo, max_rb);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -396,22 +396,23 @@ int launch(const float* tiles, const float* cross, const float* H, float* out, c
 }  // namespace
 
 #define V2(NWR, NWC, NCTW, BKT, RPW) \
-    launch_v2<NWR, NWC, NCTW, BKT, RPW>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len, s)
+    launch_v2<NWR, NWC, NCTW, BKT, RPW>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, s)
 
 int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* H, float* out,
                            const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                           int B, int M, int N, int d, int max_len, int transpose, hipStream_t s) {
+                           int B, int M, int N, int d, int ldh, int ldo, int max_len, int transpose, hipStream_t s) {
     if (B <= 0 || M <= 0 || M > 9 || N <= 0 || d <= 0 || (d & 3) || max_len <= 0) return -1;
+    if (ldh < d || ldo < d || (ldh & 3) || (ldo & 3)) return -1;
     if (transpose) {
         const bool small_rows = max_len <= 48;
         if (d <= 112)
-            return small_rows ? launch<2, 7>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len, 1, s)
-                              : launch<4, 7>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len, 1, s);
+            return small_rows ? launch<2, 7>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s)
+                              : launch<4, 7>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s);
         if (d <= 208)
-            return small_rows ? launch<2, 13>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len, 1, s)
-                              : launch<4, 13>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len, 1, s);
-        return small_rows ? launch<2, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len, 1, s)
-                          : launch<4, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len, 1, s);
+            return small_rows ? launch<2, 13>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s)
+                              : launch<4, 13>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s);
+        return small_rows ? launch<2, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s)
+                          : launch<4, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s);
     }
     const int ov = tuning_override();
     if (ov >= 0) {
@@ -444,7 +445,8 @@ extern "C" int mmdfn_abi_version(void) { return 1; }
 
 extern "C" int mmdfn_propagate(const float* tiles, const float* cross, const float* H, float* out,
                                const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                               int B, int M, int N, int d, int max_len, int transpose, void* stream) {
-    return mmdfn_launch_propagate(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, max_len,
+                               int B, int M, int N, int d, int ldh, int ldo, int max_len, int transpose,
+                               void* stream) {
+    return mmdfn_launch_propagate(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len,
                                   transpose, (hipStream_t)stream);
 }

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
     const float* __restrict__ X, const float* __restrict__ Y, float* __restrict__ out_tiles,
     float* __restrict__ out_aux, float* __restrict__ deg, const int32_t* __restrict__ dia_len,
     const int32_t* __restrict__ row_start, const int64_t* __restrict__ tile_base, int M, int N, int K,
-    int max_rb, int accumulate) {
+    int ldx, int ldy, int max_rb, int accumulate) {
     constexpr int BM = 16 * NW;
     const int i = blockIdx.x / max_rb;
     const int rb = blockIdx.x % max_rb;
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
     const int ld = (L + 3) & ~3;
     const int rs = row_start[i];
     const int64_t toff = tile_base[i] + (int64_t)m * L * ld;
-    const float* Xm = X + ((int64_t)m * N + rs) * K;
-    const float* Ym = Y + ((int64_t)m * N + rs) * K;
+    const float* Xm = X + ((int64_t)m * N + rs) * ldx;
+    const float* Ym = Y + ((int64_t)m * N + rs) * ldy;
 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
     for (int kc = 0; kc < KC; ++kc) {
         const int k = 16 * kc + 4 * g;
         a[kc] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (prow < L && k < K) a[kc] = *reinterpret_cast<const float4*>(Xm + (int64_t)prow * K + k);
+        if (prow < L && k < K) a[kc] = *reinterpret_cast<const float4*>(Xm + (int64_t)prow * ldx + k);
     }
 
     float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
         for (int kc = 0; kc < KC; ++kc) {
             const int k = 16 * kc + 4 * g;
             float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qrow < L && k < K) b = *reinterpret_cast<const float4*>(Ym + (int64_t)qrow * K + k);
+            if (qrow < L && k < K) b = *reinterpret_cast<const float4*>(Ym + (int64_t)qrow * ldy + k);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].y, b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].z, b.z, acc, 0, 0, 0);
@@ -106,18 +106,18 @@ __global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
 
 template <int NW, int KC>
 int launch(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg, const int32_t* dia_len,
-           const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int max_len, int epi,
-           int accumulate, hipStream_t s) {
+           const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx, int ldy,
+           int max_len, int epi, int accumulate, hipStream_t s) {
     const int BM = 16 * NW;
     const int max_rb = (max_len + BM - 1) / BM;
     dim3 grid(B * max_rb, M);
     dim3 block(64 * NW);
     if (epi == 0)
         hipLaunchKernelGGL((tile_dot_kernel<NW, KC, 0>), grid, block, 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
-                           row_start, tile_base, M, N, K, max_rb, accumulate);
+                           row_start, tile_base, M, N, K, ldx, ldy, max_rb, accumulate);
     else
         hipLaunchKernelGGL((tile_dot_kernel<NW, KC, 1>), grid, block, 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
-                           row_start, tile_base, M, N, K, max_rb, accumulate);
+                           row_start, tile_base, M, N, K, ldx, ldy, max_rb, accumulate);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -125,16 +125,16 @@ int launch(const float* X, const float* Y, float* out_tiles, float* out_aux, flo
 // dcross_{mn}[r] (+)= X[(m,r)].Y[(n,r)] + X[(n,r)].Y[(m,r)]   -- one wave per row
 __global__ __launch_bounds__(256) void cross_dot_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                         float* __restrict__ dcross, int M, int N, int K,
-                                                        int accumulate) {
+                                                        int ldx, int ldy, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
     for (int m = 0; m < M; ++m)
         for (int n = m + 1; n < M; ++n) {
-            const float* xm = X + ((int64_t)m * N + row) * K;
-            const float* xn = X + ((int64_t)n * N + row) * K;
-            const float* ym = Y + ((int64_t)m * N + row) * K;
-            const float* yn = Y + ((int64_t)n * N + row) * K;
+            const float* xm = X + ((int64_t)m * N + row) * ldx;
+            const float* xn = X + ((int64_t)n * N + row) * ldx;
+            const float* ym = Y + ((int64_t)m * N + row) * ldy;
+            const float* yn = Y + ((int64_t)n * N + row) * ldy;
             float s = 0.f;
             for (int k = lane; k < K; k += 64) s += xm[k] * yn[k] + xn[k] * ym[k];
             s = wave_sum(s);
@@ -149,23 +149,26 @@ __global__ __launch_bounds__(256) void cross_dot_kernel(const float* __restrict_
 
 int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
                           const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                          int B, int M, int N, int K, int max_len, int epi, int accumulate, hipStream_t s) {
+                          int B, int M, int N, int K, int ldx, int ldy, int max_len, int epi, int accumulate,
+                          hipStream_t s) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 3) || max_len <= 0) return -1;
-    if (K <= 112) return launch<4, 7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, max_len, epi, accumulate, s);
-    if (K <= 208) return launch<4, 13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, max_len, epi, accumulate, s);
-    if (K <= 512) return launch<4, 32>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, max_len, epi, accumulate, s);
+    if (ldx < K || ldy < K || (ldx & 3) || (ldy & 3)) return -1;
+    if (K <= 112) return launch<4, 7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
+    if (K <= 208) return launch<4, 13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
+    if (K <= 512) return launch<4, 32>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
     return -1;
 }
 
 extern "C" int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, float* dcross,
                                 const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                                int B, int M, int N, int d, int max_len, int accumulate, void* stream) {
+                                int B, int M, int N, int d, int ldx, int ldy, int max_len, int accumulate,
+                                void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    int rc = mmdfn_launch_tile_dot(X, Y, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, d, max_len,
-                                   0, accumulate, s);
+    int rc = mmdfn_launch_tile_dot(X, Y, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, d, ldx, ldy,
+                                   max_len, 0, accumulate, s);
     if (rc) return rc;
     if (M > 1 && dcross) {
-        hipLaunchKernelGGL(cross_dot_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, accumulate);
+        hipLaunchKernelGGL(cross_dot_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy, accumulate);
         MMDFN_CHECK_LAUNCH();
     }
     return 0;

@@ -71,6 +71,19 @@ class GradientBucket:
         self.flat = flat
         self.params = params
 
+    def attach(self):
+        """Make every live parameter's .grad a view of the flat bucket (keeps current values)."""
+        if self.flat is None:
+            self._materialise()
+        return self.flat
+
+    def all_reduce_attached(self):
+        """All-reduce when the .grad views are known to be attached (captured-graph steps)."""
+        dist.all_reduce(self.flat)
+        if self.average:
+            self.flat.div_(dist.get_world_size())
+        return self.flat
+
     def all_reduce(self):
         if self.flat is None:
             self._materialise()

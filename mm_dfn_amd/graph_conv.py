@@ -80,6 +80,45 @@ class GCNII_lyc(nn.Module):
         if adj is None:
             raise NotImplementedError("GCNII_lyc without an explicit adjacency (reference model_GCN.py:490-584) "
                                       "is outside the MM-DFN hot path; pass adj from MM_GCN.create_big_adj")
+        fused = isinstance(adj, BlockTileAdjacency) and all(c.variant and not c.residual for c in self.convs)
+        return self._forward_fused(x, adj) if fused else self._forward_generic(x, adj)
+
+    def _dropout_mask(self, like):
+        """Keep-mask already scaled by 1/(1-p) (one launch), or None when dropout is inactive."""
+        if not self.training or self.dropout <= 0:
+            return None
+        return F.dropout(torch.ones_like(like), self.dropout, True)
+
+    def _forward_fused(self, x, adj):
+        """MI355X path: per layer = gate GEMM(s) + fused LSTM-cell kernel + propagate (writes [A.x | h0] in
+        place) + support GEMM + fused GCNII update kernel."""
+        x = F.dropout(x, self.dropout, training=self.training)
+        h0 = self.act_fn(self.fcs[0](x))
+        cur = F.dropout(h0, self.dropout, training=self.training)
+        h = c = None
+        if self.reason_flag:
+            w_ih, w_hh = self.rnn.weight_ih_l0, self.rnn.weight_hh_l0
+            bias = self.rnn.bias_ih_l0 + self.rnn.bias_hh_l0
+        for i, con in enumerate(self.convs):
+            q = cur
+            if self.reason_flag:
+                G = F.linear(q, w_ih, bias)
+                if h is not None:
+                    G = torch.addmm(G, h, w_hh.t())
+                h, c = ops.lstm_pointwise(G, c)
+                cur = h
+            theta = math.log(self.lamda / (i + 1) + 1)
+            S2 = ops.propagate_concat(adj, cur, h0)
+            P = torch.mm(S2, con.weight)
+            cur = ops.gcnii_combine(P, S2, q if self.reason_flag else None, self._dropout_mask(P), theta, self.alpha)
+        if self.use_residue:
+            cur = torch.cat([x, cur], dim=-1)
+        if not self.return_feature:
+            cur = F.log_softmax(self.fcs[-1](cur), dim=1)
+        return cur
+
+    def _forward_generic(self, x, adj):
+        """Literal op-by-op composition (dense adjacency tensors, non-variant / residual layers)."""
         x = F.dropout(x, self.dropout, training=self.training)
         h0 = self.act_fn(self.fcs[0](x))
         cur = F.dropout(h0, self.dropout, training=self.training)

@@ -1,0 +1,39 @@
+"""hipGraph capture of one whole training step (forward + loss + backward).
+
+At IEMOCAP sizes a step is a few hundred short kernels; launched eagerly the host (Python + autograd
+dispatch) is the bottleneck, not the GPU.  For a fixed batch signature (same dialogue lengths) the step is
+static, so it is captured once into a hipGraph and replayed: one launch per step.  Gradients are written
+into persistent tensors (views of the data-parallel flat bucket when one is given), so an eager RCCL
+all-reduce / optimizer step can follow each replay.
+"""
+import torch
+
+
+class CapturedStep:
+    def __init__(self, model, step_fn, warmup=3, bucket=None):
+        """step_fn() must run forward + backward on STATIC input tensors and return the loss tensor."""
+        self.model = model
+        self.bucket = bucket
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                model.zero_grad(set_to_none=False)
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.params = [p for p in model.parameters() if p.grad is not None]
+        if bucket is not None:
+            bucket.attach()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            if bucket is not None:
+                bucket.flat.zero_()
+            else:
+                for p in self.params:
+                    p.grad.zero_()
+            self.loss = step_fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.loss
