@@ -68,8 +68,9 @@ def cpu_baseline(cfg, batch, state, threads, budget_s=20.0):
     """Times the oracle (reference op structure: dense adjacency, looped party GRUs, aten GRU) on the host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mmdfn_oracle as O
-    if threads > 0:
-        torch.set_num_threads(threads)
+    # torch's default (all hardware threads) oversubscribes badly on a 256-thread host for these small
+    # ops; 16 intra-op threads was the fastest setting measured (8/16/32/64 tried), override with --cpu-threads
+    torch.set_num_threads(threads if threads > 0 else min(16, os.cpu_count() or 1))
     used = torch.get_num_threads()
     # bounded sample: the first `nb` dialogues of the batch (reference CPU throughput peaks near B=16)
     nb = min(len(batch["lengths"]), 8)
@@ -126,6 +127,7 @@ def main():
     label = train.flatten_labels(batch["label"], lengths)
     loss_f = FocalLoss(gamma=0.5)
     dp = distributed.GradientBucket(model) if world > 1 else None
+    flat_bucket = dp if dp is not None else distributed.GradientBucket(model)   # one zero-fill per step
     total_utt = distributed.all_reduce_scalar(n_utt) if world > 1 else n_utt
 
     scale = (n_utt * world / total_utt) if dp is not None else 1.0
@@ -147,7 +149,7 @@ def main():
             return loss
     else:
         from mm_dfn_amd.graphs import CapturedStep
-        captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
+        captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=flat_bucket)
 
         def step():
             loss = captured.replay()

@@ -17,3 +17,9 @@ def pytest_configure(config):
 def reference_available():
     import ref_shim
     return ref_shim.available()
+
+
+def pytest_sessionstart(session):
+    # the CPU oracle is many small torch ops: a few threads beat the 256-thread default of the GPU box
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
