@@ -147,6 +147,32 @@ int mmdfn_gcnii_combine_bwd(const float* P, const float* S2, const float* mask, 
                             float* dP, float* dS2, float theta, float alpha, int64_t R, int d,
                             void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K3 / K4  speaker-party gather / scatter + pad strip (replaces the per-(dialogue, speaker) Python
+ * slice-assign loops model.py:1076-1087 (x3 modalities) and simple_batch_graphify model.py:553-565).
+ *   X[m]   : Mn host-array entries, each a device (L, B, H) fp32 projection (Mn <= 4)
+ *   qmask  : (L, B, P) fp32 speaker flags (non-zero = speaker p utters t in dialogue b)
+ *   S      : (L, Mn*B*P, H) out: column ((m*B+b)*P+p) holds speaker p's utterances of dialogue b
+ *            compacted to the front in time order, zero rows behind (the party-GRU input)
+ *   rank   : (L, B, P) int32 out: position of utterance t inside its party sequence, -1 otherwise
+ * combine: out[m][n][:] = base[m][t,b,:] + weights[m] * E[rank[t,b,p*], ((m*B+b)*P+p*), :]
+ *   with flat_idx[n] = t*B + b (dialogue-major order), p* = LAST flagged speaker (the reference
+ *   scatters speaker by speaker), E = party-GRU output (L, Mn*B*P, H) or NULL; out: (Mn, N, H).
+ *   `weights` is a HOST array of Mn floats (speaker_weights, model.py:816).
+ * Backward entries: dX / dbase are Mn host-array entries of device (L, B, H) buffers;
+ *   combine_bwd expects dbase and dE pre-zeroed (it writes only the rows that exist).
+ * ------------------------------------------------------------------------- */
+int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, float* S, int32_t* rank,
+                       int L, int B, int P, int H, void* stream);
+int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX,
+                           int L, int B, int P, int H, void* stream);
+int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const int32_t* rank,
+                        const int64_t* flat_idx, float* out, const float* weights,
+                        int L, int B, int P, int N, int H, void* stream);
+int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, const int64_t* flat_idx,
+                            float* const* dbase, float* dE, const float* weights,
+                            int L, int B, int P, int N, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,10 @@ SIGNATURES = {
     "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_gcnii_combine_bwd": [_P, _P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
+    "mmdfn_party_gather": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mmdfn_party_combine": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
 ABI_VERSION = 1
@@ -92,3 +96,7 @@ def ptr_array(tensors):
 
 def int_array(values):
     return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def float_array(values):
+    return (ctypes.c_float * len(values))(*[float(v) for v in values])

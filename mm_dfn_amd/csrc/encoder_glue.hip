@@ -1,0 +1,219 @@
+// K3 / K4: speaker-party gather / scatter and pad-strip of the encoders.
+//
+// Reference (model.py:1070-1090, 1101-1121, 1134-1154, 553-565): per modality, dialogue b and speaker p a
+// Python loop compacts speaker p's utterances to the front of a zero (L, H) buffer
+// (`U_parties_[p][b][:k] = U_[b][index_i]`), runs the party GRU, scatters the first k outputs back
+// (`U_p_[b][index_i] = E_parties_[p][b][:k]`), adds `w_m * U_p` to the base encoding and finally strips the
+// padding dialogue by dialogue.  B*P*2*3 slice-assigns (each with a CopySlices backward) become:
+//   party_gather       : one workgroup per (dialogue, speaker): ballot/popcount prefix scan over qmask gives
+//                        the compaction order, then a coalesced 16-byte copy of all modalities' rows;
+//   party_combine      : out[m][n] = base_m[t,b] + w_m * E[rank[t,b,p*], (m,b,p*)]  written directly in the
+//                        dialogue-major (M, N, H) order the graph kernels consume (p* = last flagged speaker,
+//                        the reference scatters speaker by speaker so the last one wins);
+//   and their backward counterparts (single writer per output element, no atomics).
+#include "mmdfn_internal.h"
+#include "../../include/mmdfn_hip.h"
+
+namespace {
+
+constexpr int MAXMOD = 4;
+constexpr int MAXL = 2048;
+
+struct ModPtrs {
+    const float* p[MAXMOD];
+};
+struct ModPtrsW {
+    float* p[MAXMOD];
+};
+
+// S: (L, Mn*B*P, H) with column ((m*B + b)*P + p);  rank: (L, B, P) int32, -1 = not this speaker
+__global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const float* __restrict__ qmask,
+                                                           float* __restrict__ S, int32_t* __restrict__ rank,
+                                                           int L, int B, int P, int Mn, int H) {
+    __shared__ int sel[MAXL];
+    __shared__ int cnt_s;
+    const int b = blockIdx.x / P;
+    const int p = blockIdx.x - b * P;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        int base = 0;
+        for (int t0 = 0; t0 < L; t0 += 64) {
+            const int t = t0 + tid;
+            const bool f = (t < L) && (qmask[((int64_t)t * B + b) * P + p] != 0.f);
+            const unsigned long long bal = __ballot(f);
+            const int pre = __popcll(bal & ((1ull << tid) - 1ull));
+            if (t < L) rank[((int64_t)t * B + b) * P + p] = f ? base + pre : -1;
+            if (f) sel[base + pre] = t;
+            base += __popcll(bal);
+        }
+        if (tid == 0) cnt_s = base;
+    }
+    __syncthreads();
+    const int cnt = cnt_s;
+    const int H4 = H / 4;
+    const int per_k = Mn * H4;
+    const int64_t cols = (int64_t)Mn * B * P;
+    for (int idx = tid; idx < L * per_k; idx += 256) {
+        const int k = idx / per_k;
+        const int rem = idx - k * per_k;
+        const int m = rem / H4;
+        const int c4 = rem - m * H4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < cnt) v = *reinterpret_cast<const float4*>(X.p[m] + ((int64_t)sel[k] * B + b) * H + 4 * c4);
+        *reinterpret_cast<float4*>(S + ((int64_t)k * cols + ((int64_t)m * B + b) * P + p) * H + 4 * c4) = v;
+    }
+}
+
+// dX_m[t,b,:] = sum_p [rank[t,b,p] >= 0] dS[rank, (m,b,p), :]
+__global__ void party_gather_bwd_kernel(const float* __restrict__ dS, const int32_t* __restrict__ rank, ModPtrsW dX,
+                                        int L, int B, int P, int Mn, int H) {
+    const int H4 = H / 4;
+    const int64_t total = (int64_t)Mn * L * B * H4;
+    const int64_t cols = (int64_t)Mn * B * P;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % H4);
+        int64_t r = idx / H4;
+        const int b = (int)(r % B);
+        r /= B;
+        const int t = (int)(r % L);
+        const int m = (int)(r / L);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < P; ++p) {
+            const int k = rank[((int64_t)t * B + b) * P + p];
+            if (k >= 0) {
+                const float4 v =
+                    *reinterpret_cast<const float4*>(dS + ((int64_t)k * cols + ((int64_t)m * B + b) * P + p) * H + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dX.p[m] + ((int64_t)t * B + b) * H + 4 * c4) = acc;
+    }
+}
+
+// out[m][n][:] = base_m[t,b,:] + w_m * E[rank[t,b,p*], (m,b,p*), :],  flat_idx[n] = t*B + b
+__global__ void party_combine_kernel(ModPtrs base, const float* __restrict__ E, const int32_t* __restrict__ rank,
+                                     const int64_t* __restrict__ flat_idx, float* __restrict__ out, float w0,
+                                     float w1, float w2, float w3, int L, int B, int P, int Mn, int N, int H) {
+    const int H4 = H / 4;
+    const int64_t total = (int64_t)Mn * N * H4;
+    const int64_t cols = (int64_t)Mn * B * P;
+    const float wv[MAXMOD] = {w0, w1, w2, w3};
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % H4);
+        int64_t r = idx / H4;
+        const int n = (int)(r % N);
+        const int m = (int)(r / N);
+        const int64_t tb = flat_idx[n];
+        const int b = (int)(tb % B);
+        float4 v = *reinterpret_cast<const float4*>(base.p[m] + tb * H + 4 * c4);
+        int ps = -1, ks = -1;
+        for (int p = 0; p < P; ++p) {
+            const int k = rank[tb * P + p];
+            if (k >= 0) { ps = p; ks = k; }
+        }
+        if (ps >= 0 && E != nullptr) {
+            const float4 e =
+                *reinterpret_cast<const float4*>(E + ((int64_t)ks * cols + ((int64_t)m * B + b) * P + ps) * H + 4 * c4);
+            const float w = wv[m];
+            v.x = fmaf(w, e.x, v.x); v.y = fmaf(w, e.y, v.y); v.z = fmaf(w, e.z, v.z); v.w = fmaf(w, e.w, v.w);
+        }
+        *reinterpret_cast<float4*>(out + ((int64_t)m * N + n) * H + 4 * c4) = v;
+    }
+}
+
+// dbase_m[t,b,:] = dout[m][n];  dE[rank, (m,b,p*), :] = w_m dout[m][n]   (dbase / dE are pre-zeroed by the caller)
+__global__ void party_combine_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ rank,
+                                         const int64_t* __restrict__ flat_idx, ModPtrsW dbase,
+                                         float* __restrict__ dE, float w0, float w1, float w2, float w3, int L,
+                                         int B, int P, int Mn, int N, int H) {
+    const int H4 = H / 4;
+    const int64_t total = (int64_t)Mn * N * H4;
+    const int64_t cols = (int64_t)Mn * B * P;
+    const float wv[MAXMOD] = {w0, w1, w2, w3};
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % H4);
+        int64_t r = idx / H4;
+        const int n = (int)(r % N);
+        const int m = (int)(r / N);
+        const int64_t tb = flat_idx[n];
+        const int b = (int)(tb % B);
+        const float4 g = *reinterpret_cast<const float4*>(dout + ((int64_t)m * N + n) * H + 4 * c4);
+        *reinterpret_cast<float4*>(dbase.p[m] + tb * H + 4 * c4) = g;
+        int ps = -1, ks = -1;
+        for (int p = 0; p < P; ++p) {
+            const int k = rank[tb * P + p];
+            if (k >= 0) { ps = p; ks = k; }
+        }
+        if (ps >= 0 && dE != nullptr) {
+            const float w = wv[m];
+            *reinterpret_cast<float4*>(dE + ((int64_t)ks * cols + ((int64_t)m * B + b) * P + ps) * H + 4 * c4) =
+                make_float4(w * g.x, w * g.y, w * g.z, w * g.w);
+        }
+    }
+}
+
+inline int grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, float* S, int32_t* rank, int L,
+                                  int B, int P, int H, void* stream) {
+    if (Mn <= 0 || Mn > MAXMOD || L <= 0 || L > MAXL || B <= 0 || P <= 0 || H <= 0 || (H & 3)) return -1;
+    ModPtrs x;
+    for (int m = 0; m < MAXMOD; ++m) x.p[m] = m < Mn ? X[m] : nullptr;
+    hipLaunchKernelGGL(party_gather_kernel, dim3(B * P), dim3(256), 0, (hipStream_t)stream, x, qmask, S, rank, L, B, P,
+                       Mn, H);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX, int L, int B,
+                                      int P, int H, void* stream) {
+    if (Mn <= 0 || Mn > MAXMOD || L <= 0 || B <= 0 || P <= 0 || H <= 0 || (H & 3)) return -1;
+    ModPtrsW x;
+    for (int m = 0; m < MAXMOD; ++m) x.p[m] = m < Mn ? dX[m] : nullptr;
+    hipLaunchKernelGGL(party_gather_bwd_kernel, dim3(grid_for((int64_t)Mn * L * B * (H / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dS, rank, x, L, B, P, Mn, H);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const int32_t* rank,
+                                   const int64_t* flat_idx, float* out, const float* weights, int L, int B, int P,
+                                   int N, int H, void* stream) {
+    if (Mn <= 0 || Mn > MAXMOD || L <= 0 || B <= 0 || P <= 0 || N <= 0 || H <= 0 || (H & 3)) return -1;
+    ModPtrs x;
+    float w[MAXMOD] = {0, 0, 0, 0};
+    for (int m = 0; m < MAXMOD; ++m) {
+        x.p[m] = m < Mn ? base[m] : nullptr;
+        if (m < Mn) w[m] = weights[m];
+    }
+    hipLaunchKernelGGL(party_combine_kernel, dim3(grid_for((int64_t)Mn * N * (H / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x, E, rank, flat_idx, out, w[0], w[1], w[2], w[3], L, B, P, Mn, N, H);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, const int64_t* flat_idx,
+                                       float* const* dbase, float* dE, const float* weights, int L, int B, int P,
+                                       int N, int H, void* stream) {
+    if (Mn <= 0 || Mn > MAXMOD || L <= 0 || B <= 0 || P <= 0 || N <= 0 || H <= 0 || (H & 3)) return -1;
+    ModPtrsW x;
+    float w[MAXMOD] = {0, 0, 0, 0};
+    for (int m = 0; m < MAXMOD; ++m) {
+        x.p[m] = m < Mn ? dbase[m] : nullptr;
+        if (m < Mn) w[m] = weights[m];
+    }
+    hipLaunchKernelGGL(party_combine_bwd_kernel, dim3(grid_for((int64_t)Mn * N * (H / 4))), dim3(256), 0,
+                       (hipStream_t)stream, dout, rank, flat_idx, x, dE, w[0], w[1], w[2], w[3], L, B, P, Mn, N, H);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}

@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import gru as fused_gru
+from . import ops
 from .mm_gcn import MM_GCN
 
 _FLAT_CACHE = {}
@@ -206,25 +207,20 @@ class DialogueGNNModel(nn.Module):
     def encode(self, U, qmask, seq_lengths, U_a, U_v):
         """Projection + context BiGRU (text) + speaker-party BiGRU (all modalities) ->
         (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209).
-        The context GRU and the batched party GRU are independent and share every recurrence launch."""
+        The context GRU and the batched party GRU are independent and share every recurrence launch;
+        the party gather / scatter / pad-strip are the fused K3/K4 kernels (csrc/encoder_glue.hip)."""
         Xa = self.linear_a(U_a)
         Xv = self.linear_v(U_v)
         Xl = self.linear_l(U)
-        if self.use_crn_speaker:
-            plan = self._party_plan(qmask)
-            S = self._party_gather([Xa, Xv, Xl], plan)
-            ctx, E = self._run_grus([Xl, S], [self.lstm_l, self.rnn_parties])
-            Pa, Pv, Pl = self._party_scatter(E, plan, 3)
-            w = self.speaker_weights
-            ea = Xa + w[0] * Pa
-            ev = Xv + w[1] * Pv
-            el = ctx + w[2] * Pl
-        else:
-            ea, ev = Xa, Xv
-            el = self._run_grus([Xl], [self.lstm_l])[0]
         L, B, H = Xa.shape
         idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
-        return torch.stack([ea, ev, el], 0).reshape(3, L * B, H).index_select(1, idx)
+        if self.use_crn_speaker:
+            S, rank = ops.party_gather([Xa, Xv, Xl], qmask)
+            ctx, E = self._run_grus([Xl, S], [self.lstm_l, self.rnn_parties])
+            return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
+        ctx = self._run_grus([Xl], [self.lstm_l])[0]
+        rank = torch.full((L, B, qmask.shape[2]), -1, dtype=torch.int32, device=Xa.device)
+        return ops.party_combine([Xa, Xv, ctx], None, rank, idx, [0.0, 0.0, 0.0])
 
     # ------------------------------------------------------------------ forward
     def forward(self, U, qmask, umask, seq_lengths, U_a=None, U_v=None, test_label=False):

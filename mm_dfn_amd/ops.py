@@ -250,3 +250,80 @@ class _GcniiCombine(torch.autograd.Function):
 
 def gcnii_combine(P, S2, q, mask, theta, alpha):
     return _GcniiCombine.apply(P, S2, q, mask, theta, alpha)
+
+
+class _PartyGather(torch.autograd.Function):
+    """(X_0..X_{Mn-1} each (L,B,H), qmask) -> S (L, Mn*B*P, H); also returns rank (L,B,P) int32 (no grad)."""
+
+    @staticmethod
+    def forward(ctx, qmask, *Xs):
+        _hip.require_cuda(qmask, *Xs)
+        Xs = [x.contiguous() for x in Xs]
+        qmask = qmask.contiguous()
+        L, B, P = qmask.shape
+        H = Xs[0].shape[-1]
+        Mn = len(Xs)
+        S = torch.empty(L, Mn * B * P, H, dtype=torch.float32, device=qmask.device)
+        rank = torch.empty(L, B, P, dtype=torch.int32, device=qmask.device)
+        rc = _hip.lib().mmdfn_party_gather(Mn, _hip.ptr_array(Xs), _hip.ptr(qmask), _hip.ptr(S), _hip.ptr(rank), L, B, P,
+                                           H, _hip.stream())
+        _hip.check(rc, "mmdfn_party_gather")
+        ctx.dims = (L, B, P, H, Mn)
+        ctx.save_for_backward(rank)
+        ctx.mark_non_differentiable(rank)
+        return S, rank
+
+    @staticmethod
+    def backward(ctx, dS, _drank):
+        (rank,) = ctx.saved_tensors
+        L, B, P, H, Mn = ctx.dims
+        dS = dS.contiguous()
+        dX = torch.empty(Mn, L, B, H, dtype=torch.float32, device=dS.device)
+        rc = _hip.lib().mmdfn_party_gather_bwd(Mn, _hip.ptr(dS), _hip.ptr(rank), _hip.ptr_array([dX[m] for m in range(Mn)]),
+                                               L, B, P, H, _hip.stream())
+        _hip.check(rc, "mmdfn_party_gather_bwd")
+        return (None,) + tuple(dX[m] for m in range(Mn))
+
+
+def party_gather(Xs, qmask):
+    return _PartyGather.apply(qmask, *Xs)
+
+
+class _PartyCombine(torch.autograd.Function):
+    """out (Mn, N, H) = strip_pad(base_m + w_m * scatter(E)); E may be None (no speaker encoder)."""
+
+    @staticmethod
+    def forward(ctx, E, rank, flat_idx, weights, *bases):
+        _hip.require_cuda(rank, *bases)
+        bases = [x.contiguous() for x in bases]
+        L, B, P = rank.shape
+        H = bases[0].shape[-1]
+        Mn = len(bases)
+        N = flat_idx.numel()
+        E_ = E.contiguous() if E is not None else None
+        out = torch.empty(Mn, N, H, dtype=torch.float32, device=rank.device)
+        rc = _hip.lib().mmdfn_party_combine(Mn, _hip.ptr_array(bases), _hip.ptr(E_), _hip.ptr(rank), _hip.ptr(flat_idx),
+                                            _hip.ptr(out), _hip.float_array(weights), L, B, P, N, H, _hip.stream())
+        _hip.check(rc, "mmdfn_party_combine")
+        ctx.dims = (L, B, P, H, Mn, N)
+        ctx.weights = list(weights)
+        ctx.has_E = E is not None
+        ctx.save_for_backward(rank, flat_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        rank, flat_idx = ctx.saved_tensors
+        L, B, P, H, Mn, N = ctx.dims
+        dout = dout.contiguous()
+        dbase = torch.zeros(Mn, L, B, H, dtype=torch.float32, device=dout.device)
+        dE = torch.zeros(L, Mn * B * P, H, dtype=torch.float32, device=dout.device) if ctx.has_E else None
+        rc = _hip.lib().mmdfn_party_combine_bwd(Mn, _hip.ptr(dout), _hip.ptr(rank), _hip.ptr(flat_idx),
+                                                _hip.ptr_array([dbase[m] for m in range(Mn)]), _hip.ptr(dE),
+                                                _hip.float_array(ctx.weights), L, B, P, N, H, _hip.stream())
+        _hip.check(rc, "mmdfn_party_combine_bwd")
+        return (dE, None, None, None) + tuple(dbase[m] for m in range(Mn))
+
+
+def party_combine(bases, E, rank, flat_idx, weights):
+    return _PartyCombine.apply(E, rank, flat_idx, list(weights), *bases)

@@ -53,3 +53,42 @@ def test_matches_torch_gru_module_eval():
         want = g(x)[0]
         got = fused.bigru2([x.to(DEV)], [g.to(DEV)], 0.0, False)[0]
     assert abs_err(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("P,lengths", [(2, [15, 9, 1, 6]), (9, [12, 12, 3]), (3, [1]), (2, [110, 64, 80])])
+def test_party_gather_combine_kernels_match_index_composition(P, lengths):
+    """K3/K4 kernels vs the torch index-op composition (itself checked against the oracle on CPU in
+    tests/test_host_logic.py), forward and backward, including a non-one-hot qmask row."""
+    from mm_dfn_amd import ops
+    from mm_dfn_amd.dialogue_model import _flat_index
+    cfg = dict(B=len(lengths), L=max(lengths), P=P, C=6, nlayers=2, D_t=100, D_a=32, D_v=64)
+    m = synthetic.build_model(**cfg)
+    b = synthetic.make_batch(4, lengths=lengths, **cfg)
+    q = b["qmask"].clone()
+    if max(lengths) > 2 and P > 1:
+        q[1, 0, :2] = 1.0   # two speakers flagged on one utterance: last one wins on scatter
+    q = q.to(DEV)
+    L, B = max(lengths), len(lengths)
+    rs = np.random.RandomState(5)
+    Xs = [torch.from_numpy(rs.randn(L, B, 200).astype(np.float32)).to(DEV) for _ in range(3)]
+    idx = _flat_index(lengths, L, B, DEV)
+    w = [3.0, 0.0, 1.0]
+    Wg = torch.from_numpy(rs.randn(3, sum(lengths), 200).astype(np.float32)).to(DEV)
+    # reference composition (torch index ops)
+    Xr = [x.clone().requires_grad_(True) for x in Xs]
+    plan = m._party_plan(q)
+    Sr = m._party_gather(Xr, plan)
+    Er = torch.tanh(Sr * 0.7 + 0.1)      # stand-in for the party GRU (any differentiable row-wise map)
+    Ur = m._party_scatter(Er, plan, 3)
+    outr = torch.stack([Xr[i] + w[i] * Ur[i] for i in range(3)], 0).reshape(3, L * B, 200).index_select(1, idx)
+    (outr * Wg).sum().backward()
+    # kernels
+    Xk = [x.clone().requires_grad_(True) for x in Xs]
+    Sk, rank = ops.party_gather(Xk, q)
+    Ek = torch.tanh(Sk * 0.7 + 0.1)
+    outk = ops.party_combine(Xk, Ek, rank, idx, w)
+    (outk * Wg).sum().backward()
+    assert abs_err(Sk, Sr) == 0.0
+    assert abs_err(outk, outr) < 1e-6
+    for i in range(3):
+        assert rel_err(Xk[i].grad, Xr[i].grad) < 1e-6
