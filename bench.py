@@ -127,7 +127,6 @@ def main():
     label = train.flatten_labels(batch["label"], lengths)
     loss_f = FocalLoss(gamma=0.5)
     dp = distributed.GradientBucket(model) if world > 1 else None
-    flat_bucket = dp if dp is not None else distributed.GradientBucket(model)   # one zero-fill per step
     total_utt = distributed.all_reduce_scalar(n_utt) if world > 1 else n_utt
 
     scale = (n_utt * world / total_utt) if dp is not None else 1.0
@@ -149,12 +148,12 @@ def main():
             return loss
     else:
         from mm_dfn_amd.graphs import CapturedStep
-        captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=flat_bucket)
+        captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
 
         def step():
             loss = captured.replay()
             if dp is not None:
-                dp.all_reduce_attached()
+                dp.reduce_flat()
             return loss
 
     for _ in range(a.warmup):

@@ -49,7 +49,12 @@ def shard_dialogues(lengths, world, rank):
 
 
 class GradientBucket:
-    """Flat fp32 gradient bucket over the parameters that receive gradients."""
+    """Flat fp32 gradient bucket over the parameters that receive gradients.
+
+    ``flatten()`` packs all live gradients into ONE contiguous buffer with a single multi-tensor copy
+    (torch.cat -> one or two launches instead of one add/copy per parameter) and re-points every ``.grad``
+    at its slice, so the all-reduce result is what the optimizer reads.  Backward passes therefore always
+    run with ``.grad = None`` (autograd hands over its buffers, no accumulation kernels)."""
 
     def __init__(self, model, average=True):
         self.model = model
@@ -57,49 +62,31 @@ class GradientBucket:
         self.flat = None
         self.params = None
 
-    def _materialise(self):
-        params = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
-        total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
-        off = 0
-        for p in params:
-            n = p.numel()
-            view = flat[off:off + n].view_as(p)
-            view.copy_(p.grad)
-            p.grad = view          # later backward passes accumulate straight into the bucket
-            off += n
-        self.flat = flat
-        self.params = params
-
-    def attach(self):
-        """Make every live parameter's .grad a view of the flat bucket (keeps current values)."""
+    def flatten(self):
+        if self.params is None:
+            self.params = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+        grads = [p.grad.reshape(-1) for p in self.params]
         if self.flat is None:
-            self._materialise()
+            self.flat = torch.cat(grads)
+        else:
+            torch.cat(grads, out=self.flat)
+        self.attach_views()
         return self.flat
 
-    def all_reduce_attached(self):
-        """All-reduce when the .grad views are known to be attached (captured-graph steps)."""
+    def attach_views(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def reduce_flat(self):
         dist.all_reduce(self.flat)
         if self.average:
             self.flat.div_(dist.get_world_size())
         return self.flat
 
     def all_reduce(self):
-        if self.flat is None:
-            self._materialise()
-        else:
-            # zero_grad(set_to_none=True) drops the views: re-attach (copy once per step only if detached)
-            off = 0
-            for p in self.params:
-                n = p.numel()
-                view = self.flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    view.zero_()
-                elif p.grad.data_ptr() != view.data_ptr():
-                    view.copy_(p.grad)
-                p.grad = view
-                off += n
-        dist.all_reduce(self.flat)
-        if self.average:
-            self.flat.div_(dist.get_world_size())
-        return self.flat
+        """Eager step: pack, all-reduce, leave .grad pointing into the reduced bucket."""
+        self.flatten()
+        return self.reduce_flat()

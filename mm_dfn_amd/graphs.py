@@ -11,28 +11,29 @@ import torch
 
 class CapturedStep:
     def __init__(self, model, step_fn, warmup=3, bucket=None):
-        """step_fn() must run forward + backward on STATIC input tensors and return the loss tensor."""
+        """step_fn() must run forward + backward on STATIC input tensors and return the loss tensor.
+        The step is captured with every ``.grad`` set to None, so autograd simply hands its gradient
+        buffers over (no zero-fill, no accumulate kernels); with a ``bucket`` the captured graph ends with
+        the single multi-tensor pack into the flat all-reduce buffer."""
         self.model = model
         self.bucket = bucket
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):
-                model.zero_grad(set_to_none=False)
+                model.zero_grad(set_to_none=True)
                 step_fn()
+                if bucket is not None:
+                    bucket.flatten()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.params = [p for p in model.parameters() if p.grad is not None]
-        if bucket is not None:
-            bucket.attach()
         self.graph = torch.cuda.CUDAGraph()
+        model.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            if bucket is not None:
-                bucket.flat.zero_()
-            else:
-                for p in self.params:
-                    p.grad.zero_()
             self.loss = step_fn()
+            if bucket is not None:
+                bucket.flatten()
+        self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
 
     def replay(self):
         self.graph.replay()

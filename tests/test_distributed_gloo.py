@@ -45,7 +45,7 @@ def worker(rank, world, port, out):
     n_global = distributed.all_reduce_scalar(n_local, device="cpu")
     bucket = distributed.GradientBucket(model)
     loss_f = FocalLoss(gamma=0.5)
-    for _ in range(2):   # second step exercises the re-attached views
+    for _ in range(2):   # second step exercises re-packing into the existing bucket
         model.zero_grad(set_to_none=True)
         loss = loss_f(model(x), y) * (n_local * world / n_global)
         loss.backward()
