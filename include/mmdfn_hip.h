@@ -173,6 +173,16 @@ int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, cons
                             float* const* dbase, float* dE, const float* weights,
                             int L, int B, int P, int N, int H, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K1  dense projection on exact-f32 MFMA (replaces nn.Linear / F.linear / torch.mm on the hot path:
+ * model.py:1065,1094,1129; the hoisted nn.GRU input contraction; model_GCN.py:454,466,186):
+ *   Y[r, n] = act( sum_k X[r, k] W[n, k] + bias[n] ) (+ Y[r, n] if accumulate)
+ *   X: R rows of K floats, row stride ldx; W: (N, K) contiguous (nn.Linear layout); bias: N or NULL;
+ *   Y: R rows of N floats, row stride ldy.  act: 0 = identity, 1 = ReLU.  K % 4 == 0, ldx % 4 == 0.
+ * ------------------------------------------------------------------------- */
+int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N,
+                 int ldx, int ldy, int act, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

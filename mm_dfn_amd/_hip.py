@@ -30,6 +30,7 @@ SIGNATURES = {
     "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_gcnii_combine_bwd": [_P, _P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
+    "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_party_gather": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_party_combine": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -100,3 +101,9 @@ def int_array(values):
 
 def float_array(values):
     return (ctypes.c_float * len(values))(*[float(v) for v in values])
+
+
+def require_f32(*tensors):
+    for t in tensors:
+        if t is not None and t.dtype != torch.float32:
+            raise HipLibraryError("the MM-DFN HIP kernels are fp32 (got %s)" % t.dtype)

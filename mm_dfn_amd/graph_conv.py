@@ -93,7 +93,7 @@ class GCNII_lyc(nn.Module):
         """MI355X path: per layer = gate GEMM(s) + fused LSTM-cell kernel + propagate (writes [A.x | h0] in
         place) + support GEMM + fused GCNII update kernel."""
         x = F.dropout(x, self.dropout, training=self.training)
-        h0 = self.act_fn(self.fcs[0](x))
+        h0 = ops.linear(x, self.fcs[0].weight, self.fcs[0].bias, act=1)      # Linear + ReLU fused
         cur = F.dropout(h0, self.dropout, training=self.training)
         h = c = None
         if self.reason_flag:
@@ -102,7 +102,7 @@ class GCNII_lyc(nn.Module):
         for i, con in enumerate(self.convs):
             q = cur
             if self.reason_flag:
-                G = F.linear(q, w_ih, bias)
+                G = ops.linear(q, w_ih, bias)
                 if h is not None:
                     G = torch.addmm(G, h, w_hh.t())
                 h, c = ops.lstm_pointwise(G, c)

@@ -9,7 +9,7 @@ state_dict keys stay the reference's); their own forward (MIOpen) is never calle
 import torch
 import torch.nn.functional as F
 
-from . import _hip
+from . import _hip, ops
 
 H = 100
 
@@ -82,7 +82,7 @@ def bigru2(xs, grus, dropout=0.0, training=False):
         args = []
         for x, gru in zip(cur, grus):
             w_ih, b_ih, w_hh, b_hh = _layer_params(gru, layer)
-            args += [F.linear(x, w_ih, b_ih), w_hh, b_hh]      # hoisted input contraction (all t, both directions)
+            args += [ops.linear(x, w_ih, b_ih), w_hh, b_hh]    # hoisted input contraction (all t, both directions)
         cur = list(_GruRecurrence.apply(*args))
         if layer == 0 and training and dropout > 0:
             cur = [F.dropout(y, dropout, True) for y in cur]

@@ -327,3 +327,75 @@ class _PartyCombine(torch.autograd.Function):
 
 def party_combine(bases, E, rank, flat_idx, weights):
     return _PartyCombine.apply(E, rank, flat_idx, list(weights), *bases)
+
+
+def linear_raw(x2d, weight, bias=None, act=0, out=None, accumulate=False):
+    """Y = act(x2d @ weight.T + bias) (+ out) on the MFMA kernel; x2d (R, K) row-strided ok, weight (N, K)."""
+    _hip.require_cuda(x2d, weight)
+    _hip.require_f32(x2d, weight, bias, out)
+    R, K = x2d.shape
+    N = weight.shape[0]
+    if x2d.stride(1) != 1 or x2d.stride(0) % 4 or x2d.data_ptr() % 16:
+        x2d = x2d.contiguous()
+    weight = weight.contiguous()
+    if out is None:
+        out = torch.empty(R, N, dtype=torch.float32, device=x2d.device)
+    rc = _hip.lib().mmdfn_linear(_hip.ptr(x2d), _hip.ptr(weight), _hip.ptr(bias), _hip.ptr(out), R, K, N,
+                                 x2d.stride(0), out.stride(0), int(act), 1 if accumulate else 0, _hip.stream())
+    _hip.check(rc, "mmdfn_linear")
+    return out
+
+
+def linear_supported(x, weight):
+    return x.is_cuda and x.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 4
+
+
+def linear_preferred(rows, K, N):
+    """Shapes where the MFMA kernel beats the library GEMM on MI355X (tools/bench_linear.py, round 1):
+    many rows and a short contraction (the batched party-GRU input projection, the GCN input layer, the
+    LSTM gate pre-activations).  Small-row / long-K projections stay on hipBLASLt (a plain library GEMM)."""
+    return rows >= 4096 and K <= 256
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b); forward and dX on the MFMA kernel, dW / db as library reductions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y = linear_raw(x2, weight, bias, act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, weight, y if act else None)
+        return y.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        dy2 = dy.reshape(-1, weight.shape[0])
+        if ctx.act:
+            dy2 = dy2 * (y > 0).to(dy2.dtype)
+        dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            N = weight.shape[0]
+            if N % 4 == 0 and linear_preferred(dy2.shape[0], N, weight.shape[1]):
+                dx = linear_raw(dy2, weight.t().contiguous(), None, 0)
+            else:
+                dx = dy2 @ weight
+            dx = dx.view(*dy.shape[:-1], weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = dy2.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=0):
+    """Drop-in for F.linear (optionally fused ReLU): MFMA kernel where it is the faster engine, library GEMM
+    (hipBLASLt through torch, also on the GPU) otherwise or when K % 4 != 0."""
+    if not linear_supported(x, weight) or not linear_preferred(x.numel() // x.shape[-1], weight.shape[1], weight.shape[0]):
+        y = torch.nn.functional.linear(x, weight, bias)
+        return torch.relu(y) if act else y
+    return _Linear.apply(x, weight, bias, act)

@@ -198,3 +198,27 @@ def test_lstm_pointwise_and_gcnii_combine_against_oracle():
         assert rel_err(Pg.grad, Po.grad) < 1e-6 and rel_err(Sg.grad, So.grad) < 1e-6
         if use_q:
             assert rel_err(qg.grad, qo.grad) < 1e-6
+
+
+@pytest.mark.parametrize("R,K,N", [(5280, 200, 100), (4100, 100, 400), (10560, 200, 600), (37, 12, 5), (1000, 900, 6),
+                                   (4097, 256, 67)])
+def test_mfma_linear_forward_backward(R, K, N):
+    rs = np.random.RandomState(R + K + N)
+    x = torch.from_numpy(rs.randn(R, K).astype(np.float32))
+    w = torch.from_numpy((rs.randn(N, K) / np.sqrt(K)).astype(np.float32))
+    b = torch.from_numpy(rs.randn(N).astype(np.float32))
+    g = torch.from_numpy(rs.randn(R, N).astype(np.float32))
+    for act in (0, 1):
+        xo, wo, bo = (t.clone().double().requires_grad_(True) for t in (x, w, b))
+        yo = torch.nn.functional.linear(xo, wo, bo)
+        if act:
+            yo = torch.relu(yo)
+        (yo * g.double()).sum().backward()
+        xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        y = ops._Linear.apply(xg, wg, bg, act)          # force the MFMA path regardless of the shape heuristic
+        (y * g.to(DEV)).sum().backward()
+        assert rel_err(y, yo) < 2e-6
+        assert rel_err(xg.grad, xo.grad) < 2e-5 and rel_err(wg.grad, wo.grad) < 2e-5 and rel_err(bg.grad, bo.grad) < 2e-5
+    raw = ops.linear_raw(x.to(DEV), w.to(DEV), None, 0)
+    acc = ops.linear_raw(x.to(DEV), w.to(DEV), b.to(DEV), 0, out=raw.clone(), accumulate=True)
+    assert rel_err(acc, 2 * (x.double() @ w.double().t()) + b.double()) < 2e-6

@@ -1,0 +1,33 @@
+"""MFMA linear kernel vs torch F.linear (hipBLASLt) on the hot-path shapes; graph-captured timing."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mm_dfn_amd import ops
+
+def gtime(fn, iters=50):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters): fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); g.replay(); e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+shapes = [("party gi", 10560, 200, 600), ("text gi", 1760, 200, 600), ("party dX", 10560, 600, 200), ("linear_v", 1760, 512, 200),
+          ("linear_l", 1760, 100, 200), ("fcs0", 5280, 200, 100), ("lstm gate", 5280, 100, 400), ("S2.W", 5280, 200, 100),
+          ("cfg4 party gi", 21120, 200, 600)]
+cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1]
+for name, R, K, N in shapes:
+    x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
+    ref = torch.nn.functional.linear(x, w, b)
+    t0 = gtime(lambda: torch.nn.functional.linear(x, w, b))
+    line = "%-14s R=%6d K=%4d N=%4d  torch %7.1f us (%5.1f TF)" % (name, R, K, N, t0, 2.0 * R * K * N / t0 / 1e6)
+    for c in cfgs:
+        if c >= 0: os.environ["MMDFN_LIN_CFG"] = str(c)
+        y = ops.linear_raw(x, w, b)
+        err = float((y - ref).abs().max() / ref.abs().max())
+        t1 = gtime(lambda: ops.linear_raw(x, w, b))
+        line += " | cfg%2d %7.1f us (%5.1f TF) err %.1e" % (c, t1, 2.0 * R * K * N / t1 / 1e6, err)
+    print(line, flush=True)
