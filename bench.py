@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use GPU 0")
     return ap.parse_args()
 
 
@@ -110,12 +112,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from mm_dfn_amd import FocalLoss, synthetic, train, ops, distributed
 
     if world > 1:
-        distributed.init(backend="nccl")
+        distributed.init(backend=a.backend)
 
     cfg = dict(synthetic.CONFIGS[a.config])
     model = synthetic.build_model(dropout=a.dropout, **cfg)

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
         __syncthreads();                                                                                  \
         if ((C) + 2 < nchunks) MMDFN_ISSUE(SET, ((C) + 2) * BKT);                                         \
         if (wave_active && !(abl & 2)) {                                                                  \
+            __builtin_amdgcn_s_setprio(3); /* MFMA phase outranks other waves' load/store phases */       \
             const float* hbase = &Hs[16 * wc * NCTW + frow];                                              \
             float bq[2][NCTW];                                                                            \
             _Pragma("unroll") for (int ct = 0; ct < NCTW; ++ct) bq[0][ct] = hbase[(4 * g) * LDH + 16 * ct]; \
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
                 __builtin_amdgcn_sched_barrier(0);                                                        \
             }                                                                                             \
         }                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                \
     } while (0)
 

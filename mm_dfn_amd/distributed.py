@@ -30,7 +30,7 @@ def init(backend=None):
 
 def all_reduce_scalar(value, device=None):
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t)
     return float(t.item())
