@@ -183,6 +183,17 @@ int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, cons
 int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N,
                  int ldx, int ldy, int act, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Weight-gradient contraction (autograd of the dense layers on the path: dW = dY^T X, db = sum_r dY):
+ *   C[m, n] = sum_r A[r, m] B[r, n]      A: R rows of M floats (stride lda), B: R rows of N floats (ldb)
+ *   colsum[m] = sum_r A[r, m]            (optional, NULL to skip)
+ * Split over r across workgroups; `workspace` must hold splits*(M*N + M) floats
+ * (splits from mmdfn_gemm_tn_splits).  M, N, lda, ldb multiples of 4.  C: M rows, stride ldc.
+ * ------------------------------------------------------------------------- */
+int mmdfn_gemm_tn_splits(int R, int M, int N);
+int mmdfn_gemm_tn(const float* A, const float* B, float* C, float* colsum, float* workspace,
+                  int R, int M, int N, int lda, int ldb, int ldc, int splits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

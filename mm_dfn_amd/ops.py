@@ -357,6 +357,37 @@ def linear_preferred(rows, K, N):
     return rows >= 4096 and K <= 256
 
 
+def _strided_rows(t):
+    """2-D fp32 view usable by the strided kernels (unit inner stride, 16-byte aligned rows) or a copy."""
+    if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def gemm_tn_supported(M, N):
+    return M % 4 == 0 and N % 4 == 0
+
+
+def gemm_tn(A, B, want_colsum=False):
+    """C = A^T @ B for A (R, M), B (R, N) (row-strided views accepted) and optionally colsum = A.sum(0);
+    the reduction over the R rows is split across workgroups (csrc/gemm_tn.hip)."""
+    _hip.require_cuda(A, B)
+    _hip.require_f32(A, B)
+    A = _strided_rows(A)
+    B = _strided_rows(B)
+    R, M = A.shape
+    N = B.shape[1]
+    lib = _hip.lib()
+    splits = lib.mmdfn_gemm_tn_splits(R, M, N)
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    colsum = torch.empty(M, dtype=torch.float32, device=A.device) if want_colsum else None
+    ws = torch.empty(splits * (M * N + M), dtype=torch.float32, device=A.device)
+    rc = lib.mmdfn_gemm_tn(_hip.ptr(A), _hip.ptr(B), _hip.ptr(C), _hip.ptr(colsum), _hip.ptr(ws), R, M, N,
+                           A.stride(0), B.stride(0), N, splits, _hip.stream())
+    _hip.check(rc, "mmdfn_gemm_tn")
+    return C, colsum
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b); forward and dX on the MFMA kernel, dW / db as library reductions."""
 
@@ -386,8 +417,11 @@ class _Linear(torch.autograd.Function):
                 dx = dy2 @ weight
             dx = dx.view(*dy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = dy2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if gemm_tn_supported(weight.shape[0], weight.shape[1]):
+                dw, db = gemm_tn(dy2, x2, want_colsum=ctx.has_bias)      # dW and db in one pass over dY
+            else:
+                dw = dy2.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = dy2.sum(0)
         return dx, dw, db, None
 

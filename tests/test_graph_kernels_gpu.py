@@ -222,3 +222,19 @@ def test_mfma_linear_forward_backward(R, K, N):
     raw = ops.linear_raw(x.to(DEV), w.to(DEV), None, 0)
     acc = ops.linear_raw(x.to(DEV), w.to(DEV), b.to(DEV), 0, out=raw.clone(), accumulate=True)
     assert rel_err(acc, 2 * (x.double() @ w.double().t()) + b.double()) < 2e-6
+
+
+@pytest.mark.parametrize("R,M,N", [(10560, 600, 200), (5280, 100, 200), (333, 300, 100), (7, 4, 8), (40000, 64, 64)])
+def test_gemm_tn_weight_gradient_kernel(R, M, N):
+    rs = np.random.RandomState(R + M)
+    A = torch.from_numpy(rs.randn(R, M).astype(np.float32))
+    B = torch.from_numpy(rs.randn(R, N).astype(np.float32))
+    C, cs = ops.gemm_tn(A.to(DEV), B.to(DEV), want_colsum=True)
+    want = A.double().t() @ B.double()
+    assert rel_err(C, want) < 5e-6
+    assert rel_err(cs, A.double().sum(0)) < 5e-6
+    # strided views (column slices of wider buffers, shifted rows) are read in place
+    wideA = torch.from_numpy(rs.randn(R + 3, M + 8).astype(np.float32)).to(DEV)
+    wideB = torch.from_numpy(rs.randn(R + 3, 2 * N).astype(np.float32)).to(DEV)
+    C2, _ = ops.gemm_tn(wideA[3:, 4:4 + M], wideB[:-3, N:])
+    assert rel_err(C2, wideA[3:, 4:4 + M].double().cpu().t() @ wideB[:-3, N:].double().cpu()) < 5e-6
