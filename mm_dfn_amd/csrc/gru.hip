@@ -9,10 +9,10 @@
 //   * this kernel is the serial part: one PERSISTENT workgroup owns R batch rows of one direction
 //     for the whole sequence, so there is no inter-workgroup synchronisation and no launch per step.
 //     W_hh (3H x H fp32 = 120 KB per direction) lives in REGISTERS, sliced over the workgroup:
-//     thread (u, s) keeps the r/z/n rows of hidden unit u restricted to the k-slice s
-//     (3 x 20 floats); h_{t-1} is broadcast from LDS; the KS partial sums meet in LDS and the
-//     R*H "gate threads" apply the sigmoid/tanh gate math, write y_t, the saved gates and h_t.
-//     GI for step t+1 is prefetched into registers while step t computes.
+//     the lane pair (2u, 2u+1) keeps the r/z/n rows of hidden unit u, each lane one half of the
+//     contraction index (3 x 52 floats); h_{t-1} is broadcast from LDS; the two partial sums meet
+//     with one __shfl_xor and the owning lane applies the sigmoid/tanh gate math, writes y_t, the
+//     saved gates and h_t: ONE barrier per timestep.  GI for step t+1 is prefetched meanwhile.
 //   * several independent GRUs (text context + party batch) share ONE launch ("groups").
 //
 // Gate order r, z, n;  n = tanh(gi_n + r * (W_hn h + b_hn));  h = (1-z) n + z h_prev.
@@ -22,10 +22,7 @@
 namespace {
 
 constexpr int GH = 100;          // hidden size (the reference hard-codes D_e = 100, model.py:847-849)
-constexpr int KS = 5;            // k-slices
-constexpr int KL = GH / KS;      // 20 hidden inputs per slice
-constexpr int JL = 3 * GH / KS;  // 60 gate rows per slice (backward)
-constexpr int NT = 512;
+constexpr int NT = 256;
 constexpr int MAXG = 4;
 
 struct FwdGroups {
@@ -53,12 +50,46 @@ struct BwdGroups {
     int slice0[MAXG + 1];
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the
+// accurate libm expf/tanhf are ~600 cycles of dependent scalar code per timestep on the serial critical
+// path of the recurrence (tools/ubench/step_latency.hip).  Absolute error < 3e-7, far inside the 1e-5 parity
+// budget of the encoders (logits 1e-4).
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// exchange with the other lane of the pair (lane ^ 1): one DPP quad_perm [1,0,3,2] move instead of a
+// ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ float pair_swap(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+// Thread mapping of both kernels: 256 threads, lane pair (2u, 2u+1) owns hidden unit u (u < 100; the
+// last 56 lanes idle).  The pair splits the contraction index in two 16-byte aligned halves
+// [0, 52) and [52, 100); each lane keeps its 3 x 52 weights in registers, the two partial sums meet with
+// ONE cross-lane exchange (__shfl_xor 1), and the lane that owns (row, unit) applies the gate math itself,
+// so a timestep needs a single workgroup barrier (h is double-buffered in LDS).
+constexpr int KH0 = 52;                 // split point of the contraction index
+constexpr int KW = 52;                  // weights held per gate per lane (second half: 48 used)
+
+// Global memory traffic of the time loop is BLOCKED: gfx950 retires vector memory operations in order and
+// vmcnt counts stores as well as loads, so a per-step "wait for the next step's operands" would also wait
+// for the previous step's result stores (a full store round trip on the serial critical path).  Instead the
+// operands of TB = 8/R consecutive timesteps are copied global -> registers one block ahead (coalesced
+// 16-byte loads by all 256 threads), dropped into LDS at the block boundary, and the results of a block are
+// collected in LDS and written out with coalesced 16-byte stores that nobody waits for.  Inside a block the
+// recurrence touches LDS only.
 
 template <int R>
 __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
-    __shared__ float hs[R][GH];
-    __shared__ float part[KS][3][R][GH];
+    constexpr int TB = 8 / R;
+    constexpr int IN4 = 3 * GH / 4;                 // float4 per (step, row) of staged input  (gi: r, z, n)
+    constexpr int OUT4 = 5 * GH / 4;                // float4 per (step, row) of staged output (y, r, z, n, ghn)
+    constexpr int NIN = (TB * R * IN4 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float hs[2][R][GH + 4];
+    __shared__ __attribute__((aligned(16))) float in_s[2][TB][R][3 * GH];
+    __shared__ __attribute__((aligned(16))) float out_s[TB][R][5 * GH];
 
     int gidx = 0;
     while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
@@ -73,93 +104,152 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     float* __restrict__ gates = G.gates[gidx];
 
     const int tid = threadIdx.x;
-    const int u = tid % GH;
-    const int s = tid / GH;
-    const bool mv = tid < KS * GH;
+    const int u = tid >> 1;
+    const int half = tid & 1;
+    const bool active = u < GH;
+    const int uu = active ? u : GH - 1;
+    const int kbase = half ? KH0 : 0;
+    const int klen = half ? GH - KH0 : KH0;
 
-    float wr[KL], wz[KL], wn[KL];
-    if (mv) {
+    // weights as packed pairs: v_pk_fma_f32 retires two FMAs per issue slot (a single wave per SIMD issues
+    // one VALU instruction every ~4 cycles, so halving the instruction count halves the matvec time)
+    f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
 #pragma unroll
-        for (int k = 0; k < KL; ++k) {
-            wr[k] = w_hh[(int64_t)(0 * GH + u) * GH + s * KL + k];
-            wz[k] = w_hh[(int64_t)(1 * GH + u) * GH + s * KL + k];
-            wn[k] = w_hh[(int64_t)(2 * GH + u) * GH + s * KL + k];
-        }
+    for (int k = 0; k < KW; ++k) {
+        const bool ok = k < klen;
+        const int kk = kbase + (ok ? k : 0);
+        wr[k >> 1][k & 1] = ok ? w_hh[(int64_t)(0 * GH + uu) * GH + kk] : 0.f;
+        wz[k >> 1][k & 1] = ok ? w_hh[(int64_t)(1 * GH + uu) * GH + kk] : 0.f;
+        wn[k >> 1][k & 1] = ok ? w_hh[(int64_t)(2 * GH + uu) * GH + kk] : 0.f;
     }
-    // gate-thread role: (r, u) for tid < R*GH
-    const int gr = tid / GH;
-    const bool gate = (tid < R * GH) && (row0 + gr < rows);
-    const int row = row0 + gr;
-    float bhr = 0.f, bhz = 0.f, bhn = 0.f, hprev = 0.f;
-    if (gate) {
-        bhr = b_hh[u];
-        bhz = b_hh[GH + u];
-        bhn = b_hh[2 * GH + u];
-    }
-    for (int i = tid; i < R * GH; i += NT) (&hs[0][0])[i] = 0.f;
+    const float bhr = b_hh[uu], bhz = b_hh[GH + uu], bhn = b_hh[2 * GH + uu];
 
-    float gir = 0.f, giz = 0.f, gin = 0.f;
-    auto load_gi = [&](int t) {
-        const float* p = gi + ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH + u;
-        gir = p[0];
-        giz = p[GH];
-        gin = p[2 * GH];
+    float hprev[R];
+    bool mine[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mine[r] = active && ((r & 1) == half) && (row0 + r < rows);
+        hprev[r] = 0.f;
+    }
+
+    const int nblocks = (T + TB - 1) / TB;
+    float4 stage[NIN];
+    auto load_block = [&](int b) {            // global -> registers (raw; out-of-range slots are never consumed)
+#pragma unroll
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NT;
+            const int sl = idx / (R * IN4);
+            const int rem = idx - sl * (R * IN4);
+            const int r = rem / IN4;
+            const int c4 = rem - r * IN4;
+            const int sidx = b * TB + sl;
+            stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sl < TB && sidx < T && row0 + r < rows) {
+                const int t = dir ? T - 1 - sidx : sidx;
+                stage[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + row0 + r) * (6 * GH) + dir * 3 * GH + 4 * c4);
+            }
+        }
     };
-    if (gate && T > 0) load_gi(dir ? T - 1 : 0);
+    auto stash_block = [&](int buf) {          // registers -> LDS
+#pragma unroll
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NT;
+            if (idx < TB * R * IN4) *reinterpret_cast<float4*>(&in_s[buf][0][0][0] + 4 * idx) = stage[e];
+        }
+    };
+    auto flush_block = [&](int b) {            // LDS -> global, nobody waits for these stores
+        for (int idx = tid; idx < TB * R * OUT4; idx += NT) {
+            const int sl = idx / (R * OUT4);
+            const int rem = idx - sl * (R * OUT4);
+            const int r = rem / OUT4;
+            const int c4 = rem - r * OUT4;
+            const int sidx = b * TB + sl;
+            if (sidx >= T || row0 + r >= rows) continue;
+            const int t = dir ? T - 1 - sidx : sidx;
+            const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][r][4 * c4]);
+            const int64_t o = ((int64_t)t * rows + row0 + r);
+            if (c4 < GH / 4)
+                *reinterpret_cast<float4*>(y + o * (2 * GH) + dir * GH + 4 * c4) = v;
+            else
+                *reinterpret_cast<float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4)) = v;
+        }
+    };
+
+    for (int i = tid; i < 2 * R * (GH + 4); i += NT) (&hs[0][0][0])[i] = 0.f;
+    load_block(0);
+    stash_block(0);
+    if (nblocks > 1) load_block(1);
     __syncthreads();
 
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? T - 1 - step : step;
-        if (mv) {
+    int step = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int buf = b & 1;
+        for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
+            const int cur = step & 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float ar = 0.f, az = 0.f, an = 0.f;
-                const float4* hv = reinterpret_cast<const float4*>(&hs[r][s * KL]);
+                f32x2 ar0 = {0.f, 0.f}, az0 = {0.f, 0.f}, an0 = {0.f, 0.f}, ar1 = {0.f, 0.f}, az1 = {0.f, 0.f}, an1 = {0.f, 0.f};
+                const float4* hv = reinterpret_cast<const float4*>(&hs[cur][r][kbase]);
 #pragma unroll
-                for (int k4 = 0; k4 < KL / 4; ++k4) {
+                for (int k4 = 0; k4 < KW / 4; ++k4) {
+                    // the second half has 12 real float4 (48 floats); its 13th reads the 4 zero pad floats
                     const float4 h4 = hv[k4];
-                    ar = fmaf(wr[4 * k4 + 0], h4.x, ar); az = fmaf(wz[4 * k4 + 0], h4.x, az); an = fmaf(wn[4 * k4 + 0], h4.x, an);
-                    ar = fmaf(wr[4 * k4 + 1], h4.y, ar); az = fmaf(wz[4 * k4 + 1], h4.y, az); an = fmaf(wn[4 * k4 + 1], h4.y, an);
-                    ar = fmaf(wr[4 * k4 + 2], h4.z, ar); az = fmaf(wz[4 * k4 + 2], h4.z, az); an = fmaf(wn[4 * k4 + 2], h4.z, an);
-                    ar = fmaf(wr[4 * k4 + 3], h4.w, ar); az = fmaf(wz[4 * k4 + 3], h4.w, az); an = fmaf(wn[4 * k4 + 3], h4.w, an);
+                    const f32x2 ha = {h4.x, h4.y}, hb = {h4.z, h4.w};
+                    ar0 = __builtin_elementwise_fma(wr[2 * k4], ha, ar0);
+                    az0 = __builtin_elementwise_fma(wz[2 * k4], ha, az0);
+                    an0 = __builtin_elementwise_fma(wn[2 * k4], ha, an0);
+                    ar1 = __builtin_elementwise_fma(wr[2 * k4 + 1], hb, ar1);
+                    az1 = __builtin_elementwise_fma(wz[2 * k4 + 1], hb, az1);
+                    an1 = __builtin_elementwise_fma(wn[2 * k4 + 1], hb, an1);
                 }
-                part[s][0][r][u] = ar;
-                part[s][1][r][u] = az;
-                part[s][2][r][u] = an;
+                float ar = (ar0.x + ar0.y) + (ar1.x + ar1.y);
+                float az = (az0.x + az0.y) + (az1.x + az1.y);
+                float an = (an0.x + an0.y) + (an1.x + an1.y);
+                ar += pair_swap(ar);
+                az += pair_swap(az);
+                an += pair_swap(an);
+                if (mine[r]) {
+                    const float* gp = &in_s[buf][sl][r][u];
+                    const float ghn = an + bhn;
+                    const float rr = sigmoidf_(gp[0] + ar + bhr);
+                    const float zz = sigmoidf_(gp[GH] + az + bhz);
+                    const float nn = tanhf_(gp[2 * GH] + rr * ghn);
+                    const float hnew = (1.0f - zz) * nn + zz * hprev[r];
+                    float* op = &out_s[sl][r][u];
+                    op[0] = hnew;
+                    op[GH] = rr;
+                    op[2 * GH] = zz;
+                    op[3 * GH] = nn;
+                    op[4 * GH] = ghn;
+                    hs[cur ^ 1][r][u] = hnew;
+                    hprev[r] = hnew;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (gate) {
-            float ghr = bhr, ghz = bhz, ghn = bhn;
-#pragma unroll
-            for (int q = 0; q < KS; ++q) {
-                ghr += part[q][0][gr][u];
-                ghz += part[q][1][gr][u];
-                ghn += part[q][2][gr][u];
-            }
-            const float rr = sigmoidf_(gir + ghr);
-            const float zz = sigmoidf_(giz + ghz);
-            const float nn = tanhf(gin + rr * ghn);
-            const float hnew = (1.0f - zz) * nn + zz * hprev;
-            const int64_t o = ((int64_t)t * rows + row);
-            y[o * (2 * GH) + dir * GH + u] = hnew;
-            float* gp = gates + (o * 2 + dir) * (4 * GH) + u;
-            gp[0] = rr;
-            gp[GH] = zz;
-            gp[2 * GH] = nn;
-            gp[3 * GH] = ghn;
-            hs[gr][u] = hnew;
-            hprev = hnew;
-            if (step + 1 < T) load_gi(dir ? t - 1 : t + 1);
-        }
+        // block boundary: next block's operands (loaded a block ago) drop into LDS, this block's results
+        // leave, and the loads of block b+2 are issued
+        if (b + 1 < nblocks) stash_block(buf ^ 1);
+        flush_block(b);
+        if (b + 2 < nblocks) load_block(b + 2);
         __syncthreads();
     }
 }
 
+// Backward through time.  dh_prev[u] = sum_j dgh[j] W_hh[j][u] + dh z: lane (u, half) keeps W_hh[j][u] for
+// j in its half of the 3H gate rows ([0,152) / [152,300)), dgh of the current step is broadcast from LDS.
+constexpr int JH0 = 152;
+constexpr int JW = 152;
+
 template <int R>
 __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
-    __shared__ float dghs[R][3 * GH];
-    __shared__ float part[KS][R][GH];
+    constexpr int TB = 8 / R;
+    constexpr int IN4 = 6 * GH / 4;     // staged per (step,row): dy (GH) | r z n ghn (4 GH) | h_prev (GH)
+    constexpr int OUT4 = 6 * GH / 4;    // dgi (3 GH) | dgh (3 GH)
+    constexpr int NIN = (TB * R * IN4 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float dghs[2][R][3 * GH + 4];
+    __shared__ __attribute__((aligned(16))) float in_s[2][TB][R][6 * GH];
+    __shared__ __attribute__((aligned(16))) float out_s[TB][R][6 * GH];
 
     int gidx = 0;
     while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
@@ -175,79 +265,133 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     float* __restrict__ dgh = G.dgh[gidx];
 
     const int tid = threadIdx.x;
-    const int u = tid % GH;
-    const int s = tid / GH;
-    const bool mv = tid < KS * GH;
-    // dh_prev[u] = sum_j dgh[j] W_hh[j][u]; this thread covers j in [s*JL, s*JL+JL)
-    float w[JL];
-    if (mv) {
+    const int u = tid >> 1;
+    const int half = tid & 1;
+    const bool active = u < GH;
+    const int uu = active ? u : GH - 1;
+    const int jbase = half ? JH0 : 0;
+    const int jlen = half ? 3 * GH - JH0 : JH0;
+    f32x2 w[JW / 2];
 #pragma unroll
-        for (int j = 0; j < JL; ++j) w[j] = w_hh[(int64_t)(s * JL + j) * GH + u];
+    for (int j = 0; j < JW; ++j) w[j >> 1][j & 1] = (j < jlen) ? w_hh[(int64_t)(jbase + (j < jlen ? j : 0)) * GH + uu] : 0.f;
+
+    bool mine[R];
+    float carry[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mine[r] = active && ((r & 1) == half) && (row0 + r < rows);
+        carry[r] = 0.f;
     }
-    const int gr = tid / GH;
-    const bool gate = (tid < R * GH) && (row0 + gr < rows);
-    const int row = row0 + gr;
-    float carry = 0.f;  // dh * z carried to the previous timestep
 
-    float p_dy = 0.f, p_r = 0.f, p_z = 0.f, p_n = 0.f, p_ghn = 0.f, p_hprev = 0.f;
-    auto prefetch = [&](int t) {
-        const int64_t o = ((int64_t)t * rows + row);
-        p_dy = dy[o * (2 * GH) + dir * GH + u];
-        const float* gp = gates + (o * 2 + dir) * (4 * GH) + u;
-        p_r = gp[0];
-        p_z = gp[GH];
-        p_n = gp[2 * GH];
-        p_ghn = gp[3 * GH];
-        const int tp = dir ? t + 1 : t - 1;  // the step that produced h_prev in the forward pass
-        p_hprev = (tp >= 0 && tp < T) ? y[((int64_t)tp * rows + row) * (2 * GH) + dir * GH + u] : 0.f;
-    };
-    if (gate && T > 0) prefetch(dir ? 0 : T - 1);
-
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? step : T - 1 - step;  // reverse of the forward order
-        if (gate) {
-            float dh = p_dy + carry;
-            if (step > 0) {
+    // step index s runs in the REVERSE of the forward order: t(s) = dir ? s : T-1-s
+    const int nblocks = (T + TB - 1) / TB;
+    float4 stage[NIN];
+    auto load_block = [&](int b) {
 #pragma unroll
-                for (int q = 0; q < KS; ++q) dh += part[q][gr][u];
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NT;
+            const int sl = idx / (R * IN4);
+            const int rem = idx - sl * (R * IN4);
+            const int r = rem / IN4;
+            const int c4 = rem - r * IN4;
+            const int sidx = b * TB + sl;
+            stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sl < TB && sidx < T && row0 + r < rows) {
+                const int t = dir ? sidx : T - 1 - sidx;
+                const int64_t o = ((int64_t)t * rows + row0 + r);
+                if (c4 < GH / 4) {
+                    stage[e] = *reinterpret_cast<const float4*>(dy + o * (2 * GH) + dir * GH + 4 * c4);
+                } else if (c4 < 5 * GH / 4) {
+                    stage[e] = *reinterpret_cast<const float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4));
+                } else {
+                    const int tp = dir ? t + 1 : t - 1;   // the step that produced h_prev in the forward pass
+                    if (tp >= 0 && tp < T)
+                        stage[e] = *reinterpret_cast<const float4*>(y + ((int64_t)tp * rows + row0 + r) * (2 * GH) + dir * GH +
+                                                                    4 * (c4 - 5 * GH / 4));
+                }
             }
-            const float rr = p_r, zz = p_z, nn = p_n, ghn = p_ghn, hprev = p_hprev;
-            const float dn = dh * (1.0f - zz);
-            const float dz = dh * (hprev - nn);
-            carry = dh * zz;
-            const float dnpre = dn * (1.0f - nn * nn);
-            const float drpre = dnpre * ghn * rr * (1.0f - rr);
-            const float dzpre = dz * zz * (1.0f - zz);
-            const float dghn = dnpre * rr;
-            const int64_t o = ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH + u;
-            dgi[o] = drpre;
-            dgi[o + GH] = dzpre;
-            dgi[o + 2 * GH] = dnpre;
-            dgh[o] = drpre;
-            dgh[o + GH] = dzpre;
-            dgh[o + 2 * GH] = dghn;
-            dghs[gr][u] = drpre;
-            dghs[gr][GH + u] = dzpre;
-            dghs[gr][2 * GH + u] = dghn;
-            if (step + 1 < T) prefetch(dir ? t + 1 : t - 1);
         }
-        __syncthreads();
-        if (mv) {
+    };
+    auto stash_block = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NT;
+            if (idx < TB * R * IN4) *reinterpret_cast<float4*>(&in_s[buf][0][0][0] + 4 * idx) = stage[e];
+        }
+    };
+    auto flush_block = [&](int b) {
+        for (int idx = tid; idx < TB * R * OUT4; idx += NT) {
+            const int sl = idx / (R * OUT4);
+            const int rem = idx - sl * (R * OUT4);
+            const int r = rem / OUT4;
+            const int c4 = rem - r * OUT4;
+            const int sidx = b * TB + sl;
+            if (sidx >= T || row0 + r >= rows) continue;
+            const int t = dir ? sidx : T - 1 - sidx;
+            const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][r][4 * c4]);
+            const int64_t o = ((int64_t)t * rows + row0 + r) * (6 * GH) + dir * 3 * GH;
+            if (c4 < 3 * GH / 4)
+                *reinterpret_cast<float4*>(dgi + o + 4 * c4) = v;
+            else
+                *reinterpret_cast<float4*>(dgh + o + 4 * (c4 - 3 * GH / 4)) = v;
+        }
+    };
+
+    for (int i = tid; i < 2 * R * (3 * GH + 4); i += NT) (&dghs[0][0][0])[i] = 0.f;
+    load_block(0);
+    stash_block(0);
+    if (nblocks > 1) load_block(1);
+    __syncthreads();
+
+    int step = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int buf = b & 1;
+        for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
+            const int cur = step & 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float a = 0.f;
-                const float4* dv = reinterpret_cast<const float4*>(&dghs[r][s * JL]);
+                // recurrent contribution from the step processed just before (its dgh sits in dghs[cur^1])
+                f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+                const float4* dv = reinterpret_cast<const float4*>(&dghs[cur ^ 1][r][jbase]);
 #pragma unroll
-                for (int j4 = 0; j4 < JL / 4; ++j4) {
-                    const float4 d4 = dv[j4];
-                    a = fmaf(w[4 * j4 + 0], d4.x, a);
-                    a = fmaf(w[4 * j4 + 1], d4.y, a);
-                    a = fmaf(w[4 * j4 + 2], d4.z, a);
-                    a = fmaf(w[4 * j4 + 3], d4.w, a);
+                for (int j8 = 0; j8 < JW / 8; ++j8) {
+                    const float4 d4 = dv[2 * j8], e4 = dv[2 * j8 + 1];   // second half: 148 real values + 4 zero pad floats
+                    const f32x2 da = {d4.x, d4.y}, db = {d4.z, d4.w}, dc = {e4.x, e4.y}, dd = {e4.z, e4.w};
+                    a0 = __builtin_elementwise_fma(w[4 * j8 + 0], da, a0);
+                    a1 = __builtin_elementwise_fma(w[4 * j8 + 1], db, a1);
+                    a2 = __builtin_elementwise_fma(w[4 * j8 + 2], dc, a2);
+                    a3 = __builtin_elementwise_fma(w[4 * j8 + 3], dd, a3);
                 }
-                part[s][r][u] = a;
+                float rec = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+                rec += pair_swap(rec);
+                if (mine[r]) {
+                    const float* ip = &in_s[buf][sl][r][u];
+                    const float dh = ip[0] + carry[r] + rec;
+                    const float rr = ip[GH], zz = ip[2 * GH], nn = ip[3 * GH], ghn = ip[4 * GH], hprev = ip[5 * GH];
+                    const float dn = dh * (1.0f - zz);
+                    const float dz = dh * (hprev - nn);
+                    carry[r] = dh * zz;
+                    const float dnpre = dn * (1.0f - nn * nn);
+                    const float drpre = dnpre * ghn * rr * (1.0f - rr);
+                    const float dzpre = dz * zz * (1.0f - zz);
+                    const float dghn = dnpre * rr;
+                    float* op = &out_s[sl][r][u];
+                    op[0] = drpre;
+                    op[GH] = dzpre;
+                    op[2 * GH] = dnpre;
+                    op[3 * GH] = drpre;
+                    op[4 * GH] = dzpre;
+                    op[5 * GH] = dghn;
+                    dghs[cur][r][u] = drpre;
+                    dghs[cur][r][GH + u] = dzpre;
+                    dghs[cur][r][2 * GH + u] = dghn;
+                }
             }
+            __syncthreads();
         }
+        if (b + 1 < nblocks) stash_block(buf ^ 1);
+        flush_block(b);
+        if (b + 2 < nblocks) load_block(b + 2);
         __syncthreads();
     }
 }
