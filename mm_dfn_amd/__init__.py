@@ -10,3 +10,4 @@ from .graph_conv import GraphConvolution, GCNII_lyc  # noqa: F401
 from .mm_gcn import MM_GCN  # noqa: F401
 from .dialogue_model import DialogueGNNModel  # noqa: F401
 from .loss import FocalLoss  # noqa: F401
+from .fusion import MFN, MMGatedAttention  # noqa: F401

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from . import gru as fused_gru
 from . import ops
+from .fusion import MFN, MMGatedAttention
 from .mm_gcn import MM_GCN
 
 _FLAT_CACHE = {}
@@ -73,20 +74,6 @@ class _EdgeAttentionParams(nn.Module):
         self.att = _MlpAttention(dim)
 
 
-class _GatedAttentionParams(nn.Module):
-    """Parameters of the reference's MMGatedAttention('general') (model.py:718-740);
-    unreachable under graph_type='GDF' (SURVEY.md §2)."""
-
-    def __init__(self, mem_dim, cand_dim):
-        super().__init__()
-        self.transform_l = nn.Linear(mem_dim, cand_dim)
-        self.transform_v = nn.Linear(mem_dim, cand_dim)
-        self.transform_a = nn.Linear(mem_dim, cand_dim)
-        self.transform_av = nn.Linear(mem_dim * 3, 1)
-        self.transform_al = nn.Linear(mem_dim * 3, 1)
-        self.transform_vl = nn.Linear(mem_dim * 3, 1)
-
-
 class DialogueGNNModel(nn.Module):
 
     def __init__(self, base_model, D_m, D_g, D_p, D_e, D_h, D_a, graph_hidden_size, n_speakers, max_seq_len,
@@ -102,8 +89,8 @@ class DialogueGNNModel(nn.Module):
             raise NotImplementedError("mm_dfn_amd implements the MM-DFN hot path only: base_model='LSTM', "
                                       "multi_modal=True, graph_type='GDF' (got %r, %r, %r)"
                                       % (base_model, multi_modal, graph_type))
-        if att_type != 'concat_subsequently':
-            raise NotImplementedError("only att_type='concat_subsequently' (--mm_fusion_mthd of the MM-DFN scripts)")
+        if att_type not in ('concat_subsequently', 'mfn'):
+            raise NotImplementedError("att_type must be 'concat_subsequently' (the MM-DFN scripts) or 'mfn'")
         if av_using_lstm:
             raise NotImplementedError("av_using_lstm=True is not part of the MM-DFN configuration")
         if sorted(modals) != ['a', 'l', 'v']:
@@ -146,10 +133,14 @@ class DialogueGNNModel(nn.Module):
                                   alpha=alpha, variant=True, return_feature=True, use_residue=use_residue,
                                   n_speakers=n_speakers, modals=self.modals, use_speaker=use_speaker,
                                   use_modal=use_modal, reason_flag=reason_flag, modal_weight=modal_weight)
-        self.gatedatt = _GatedAttentionParams(hidden + graph_hidden_size, graph_hidden_size)
+        self.gatedatt = MMGatedAttention(hidden + graph_hidden_size, graph_hidden_size, att_type='general')
         self.dropout_ = nn.Dropout(dropout)
-        width = (hidden + graph_hidden_size) if use_residue else graph_hidden_size
-        self.smax_fc = nn.Linear(width * len(self.modals), n_classes)
+        if att_type == 'mfn':
+            self.mfn = MFN()                                      # model.py:991-994
+            self.smax_fc = nn.Linear(400, n_classes)
+        else:
+            width = (hidden + graph_hidden_size) if use_residue else graph_hidden_size
+            self.smax_fc = nn.Linear(width * len(self.modals), n_classes)
 
     # ------------------------------------------------------------------ encoders
     @staticmethod
@@ -228,6 +219,12 @@ class DialogueGNNModel(nn.Module):
             raise ValueError("the trimodal GDF path needs U_a and U_v")
         feats = self.encode(U, qmask, seq_lengths, U_a, U_v)
         fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label)
+        if self.att_type == 'mfn':
+            # re-pad (N, 900) -> (L, B, 900), memory fusion over time, strip again (model.py:1303-1326)
+            L, B = U.shape[0], U.shape[1]
+            idx = _flat_index([int(x) for x in seq_lengths], L, B, fused.device)
+            padded = fused.new_zeros(L * B, fused.shape[1]).index_copy(0, idx, fused).view(L, B, -1)
+            fused = self.mfn(padded).reshape(L * B, -1).index_select(0, idx)
         z = F.relu(self.dropout_(fused))
         log_prob = F.log_softmax(self.smax_fc(z), 1)
         return log_prob, None, None, None, None

@@ -169,6 +169,46 @@ def export_train_trace():
     print("train trace", losses)
 
 
+def export_fusion_modules():
+    """G8: MFN (model_fusion.py:10-120) and MMGatedAttention('general') (model.py:718-781) at module level, and the
+    GDF model with --mm_fusion_mthd mfn end to end (needs torch.cuda.is_available faked True: model.py:1307,1325)."""
+    ref_shim.install()
+    import model_fusion
+    import model as ref_model_mod
+    out = {}
+    rs = np.random.RandomState(700)
+    mfn = model_fusion.MFN()
+    mfn.load_state_dict(synthetic.seeded_state_dict(mfn.state_dict(), 700))
+    mfn.eval()
+    x = torch.from_numpy(rs.randn(9, 2, 900).astype(np.float32)).requires_grad_(True)
+    R = torch.from_numpy(rs.randn(9, 2, 400).astype(np.float32))
+    y = mfn(x)
+    (y * R).sum().backward()
+    out["mfn_y"] = y.detach().numpy()
+    out["mfn_dx"] = x.grad.numpy()
+    out["mfn_dW"] = mfn.gamma1_fc1.weight.grad.numpy()
+    g = ref_model_mod.MMGatedAttention(300, 100, att_type='general')
+    g.load_state_dict(synthetic.seeded_state_dict(g.state_dict(), 701))
+    g.eval()
+    a, v, l = (torch.from_numpy(rs.randn(11, 300).astype(np.float32)) for _ in range(3))
+    out["gated_avl"] = g(a, v, l, ['a', 'v', 'l']).detach().numpy()
+    out["gated_al"] = g(a, [], l, ['a', 'l']).detach().numpy()
+    real = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    try:
+        cfg = dict(B=3, L=12, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+        m = ref_shim.build_reference_model(100, 100, 512, 2, 6, 2, att_type='mfn')
+        m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 702))
+        m.eval()
+        b = synthetic.make_batch(703, lengths=[12, 5, 9], **cfg)
+        with torch.no_grad():
+            out["e2e_mfn_log_prob"] = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0].numpy()
+    finally:
+        torch.cuda.is_available = real
+    np.savez_compressed(os.path.join(HERE, "fusion_modules.npz"), **out)
+    print("fusion modules ok")
+
+
 def export_state_keys():
     m = ref_shim.build_reference_model(100, 1582, 342, 2, 6, 2)
     keys = ["%s %s" % (k, "x".join(map(str, v.shape))) for k, v in m.state_dict().items()]
@@ -180,6 +220,7 @@ def export_state_keys():
 if __name__ == "__main__":
     torch.manual_seed(0)
     export_state_keys()
+    export_fusion_modules()
     export_focal()
     export_adjacency()
     export_gcnii()

@@ -168,3 +168,19 @@ def test_size_independent_properties_at_full_size():
     inv_r = torch.sqrt(spp / r2).reshape(3 * N, 1).repeat(1, 4)
     out = ops.propagate(adj, inv_r.contiguous())
     assert rel_err(out, inv_r) < 1e-4
+
+
+def test_mfn_fusion_variant_against_reference_golden():
+    """--mm_fusion_mthd mfn after the GDF graph (model.py:1303-1326), eval logits vs the reference."""
+    g = np.load(os.path.join(GOLD, "fusion_modules.npz"))
+    cfg = dict(B=3, L=12, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+    m = synthetic.build_model(att_type='mfn', **cfg)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 702))
+    m = m.to(DEV).eval()
+    b = synthetic.make_batch(703, lengths=[12, 5, 9], **cfg)
+    with torch.no_grad():
+        logp = run(m, b)
+    assert np.abs(logp.cpu().numpy() - g["e2e_mfn_log_prob"]).max() < 1e-4
+    m.train()
+    run(m, b).sum().backward()
+    assert m.mfn.gamma1_fc1.weight.grad is not None and torch.isfinite(m.mfn.gamma1_fc1.weight.grad).all()
