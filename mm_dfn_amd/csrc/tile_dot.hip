@@ -14,6 +14,7 @@
 // sweep over q; no LDS is needed.
 #include "mmdfn_internal.h"
 #include "../../include/mmdfn_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -104,6 +105,163 @@ __global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 (K <= 208): each wave sweeps q in groups of four 16-column tiles.
+//   * B fragments of the next tile are prefetched into a second register set while the current tile's
+//     MFMAs run;
+//   * the 16 x 64 result block goes through a wave-private LDS patch so that it leaves as 16-byte,
+//     row-contiguous stores (256 B per row instead of 64-byte column fragments) and the Gram epilogue
+//     (similarity, saved cosine, row degree) works on whole float4 rows;
+//   * blockIdx % 8 == dialogue % 8 (all tiles of a dialogue share one XCD's L2, like the propagate kernel).
+template <int KC, int EPI>
+__global__ __launch_bounds__(256) void tile_dot_v2_kernel(
+    const float* __restrict__ X, const float* __restrict__ Y, float* __restrict__ out_tiles,
+    float* __restrict__ out_aux, float* __restrict__ deg, const int32_t* __restrict__ dia_len,
+    const int32_t* __restrict__ row_start, const int64_t* __restrict__ tile_base, int B, int M, int N, int K,
+    int ldx, int ldy, int max_rb, int accumulate) {
+    constexpr int BM = 64;
+    constexpr int LDP = 68;                       // patch row stride (floats), 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) float patch[4][16 * LDP];
+
+    const int Rd = M * max_rb;
+    const int bid = blockIdx.x;
+    const int yq = bid >> 3;
+    const int i = (yq / Rd) * 8 + (bid & 7);
+    if (i >= B) return;
+    const int rho = yq % Rd;
+    const int m = rho / max_rb;
+    const int rb = rho - m * max_rb;
+    const int L = dia_len[i];
+    const int r0 = rb * BM;
+    if (r0 >= L) return;
+    const int ld = (L + 3) & ~3;
+    const int rs = row_start[i];
+    const int64_t toff = tile_base[i] + (int64_t)m * L * ld;
+    const float* Xm = X + ((int64_t)m * N + rs) * ldx;
+    const float* Ym = Y + ((int64_t)m * N + rs) * ldy;
+
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int fi = lane & 15;
+    const int g = lane >> 4;
+    const int p0 = r0 + 16 * w;
+    if (p0 >= L) return;                          // whole wave out of range (no workgroup barriers below)
+    float* pw = patch[w];
+
+    float4 a[KC];
+    {
+        const int prow = p0 + fi;
+        const float* xp = Xm + (int64_t)(prow < L ? prow : L - 1) * ldx;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int k = 16 * kc + 4 * g;
+            const float4 v = *reinterpret_cast<const float4*>(xp + (k < K ? k : K - 4));
+            const bool ok = (prow < L) && (k < K);
+            a[kc] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    }
+    float4 bset[2][KC];
+    auto load_b = [&](int set, int qt) {
+        const int qrow = 16 * qt + fi;
+        const float* yp = Ym + (int64_t)(qrow < L ? qrow : L - 1) * ldy;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int k = 16 * kc + 4 * g;
+            bset[set][kc] = *reinterpret_cast<const float4*>(yp + (k < K ? k : K - 4));
+        }
+    };
+    const int nqt = (ld + 15) / 16;
+    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+#define TD_TILE(SET, QT, SLOT)                                                                         \
+    do {                                                                                               \
+        if ((QT) + 1 < nqt) load_b(1 - (SET), (QT) + 1);                                               \
+        const bool qok = (16 * (QT) + fi) < L;                                                         \
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        _Pragma("unroll") for (int kc = 0; kc < KC; ++kc) {                                            \
+            const bool ok = qok && (16 * kc + 4 * g < K);                                              \
+            const float4 b = bset[SET][kc];                                                            \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].x, ok ? b.x : 0.f, acc, 0, 0, 0);          \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].y, ok ? b.y : 0.f, acc, 0, 0, 0);          \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].z, ok ? b.z : 0.f, acc, 0, 0, 0);          \
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kc].w, ok ? b.w : 0.f, acc, 0, 0, 0);          \
+        }                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) pw[(4 * g + r) * LDP + 16 * (SLOT) + fi] = acc[r]; \
+    } while (0)
+
+    load_b(0, 0);
+    for (int q0t = 0; q0t < nqt; q0t += 4) {
+        TD_TILE(0, q0t, 0);
+        if (q0t + 1 < nqt) TD_TILE(1, q0t + 1, 1);
+        if (q0t + 2 < nqt) TD_TILE(0, q0t + 2, 2);
+        if (q0t + 3 < nqt) TD_TILE(1, q0t + 3, 3);
+        __builtin_amdgcn_wave_barrier();
+        // 16 rows x 64 columns -> 256 float4: lane handles (row = g + 4e, c4 = fi)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = g + 4 * e;
+            const int p = p0 + row;
+            const int q = 16 * q0t + 4 * fi;
+            const bool ok = (p < L) && (q < ld) && (4 * fi < 16 * (nqt - q0t));
+            const float4 v = *reinterpret_cast<const float4*>(&pw[row * LDP + 4 * fi]);
+            const int64_t off = toff + (int64_t)p * ld + q;
+            float s4 = 0.f;
+            if (EPI == 0) {
+                if (ok) {
+                    float4 o = v;
+                    if (accumulate) {
+                        const float4 old = *reinterpret_cast<const float4*>(out_tiles + off);
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                    *reinterpret_cast<float4*>(out_tiles + off) = o;
+                }
+            } else {
+                if (ok) {
+                    float4 c, sv;
+                    c.x = (q + 0 < L) ? v.x : 0.f; c.y = (q + 1 < L) ? v.y : 0.f;
+                    c.z = (q + 2 < L) ? v.z : 0.f; c.w = (q + 3 < L) ? v.w : 0.f;
+                    sv.x = (q + 0 < L) ? mmdfn_sim(c.x) : 0.f; sv.y = (q + 1 < L) ? mmdfn_sim(c.y) : 0.f;
+                    sv.z = (q + 2 < L) ? mmdfn_sim(c.z) : 0.f; sv.w = (q + 3 < L) ? mmdfn_sim(c.w) : 0.f;
+                    *reinterpret_cast<float4*>(out_aux + off) = c;      // raw cosine (saved for backward)
+                    *reinterpret_cast<float4*>(out_tiles + off) = sv;   // raw similarity; normalised later
+                    s4 = (sv.x + sv.y) + (sv.z + sv.w);
+                }
+                s4 += __shfl_xor(s4, 1, 64);
+                s4 += __shfl_xor(s4, 2, 64);
+                s4 += __shfl_xor(s4, 4, 64);
+                s4 += __shfl_xor(s4, 8, 64);
+                rowsum[e] += s4;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef TD_TILE
+    if (EPI == 1 && fi == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int p = p0 + g + 4 * e;
+            if (p < L) deg[(int64_t)m * N + rs + p] += rowsum[e];  // single writer per row
+        }
+    }
+}
+
+template <int KC>
+int launch_v2(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg, const int32_t* dia_len,
+              const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx, int ldy,
+              int max_len, int epi, int accumulate, hipStream_t s) {
+    const int max_rb = (max_len + 63) / 64;
+    dim3 grid(((B + 7) / 8) * 8 * M * max_rb);
+    if (epi == 0)
+        hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 0>), grid, dim3(256), 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
+                           row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate);
+    else
+        hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 1>), grid, dim3(256), 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
+                           row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int NW, int KC>
 int launch(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg, const int32_t* dia_len,
            const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx, int ldy,
@@ -153,6 +311,11 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
                           hipStream_t s) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 3) || max_len <= 0) return -1;
     if (ldx < K || ldy < K || (ldx & 3) || (ldy & 3)) return -1;
+    const char* e = getenv("MMDFN_TILEDOT_V1");   // A/B aid: the first-generation kernel
+    if (e == nullptr || e[0] == '0') {
+        if (K <= 112) return launch_v2<7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
+        if (K <= 208) return launch_v2<13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
+    }
     if (K <= 112) return launch<4, 7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
     if (K <= 208) return launch<4, 13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
     if (K <= 512) return launch<4, 32>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
