@@ -143,22 +143,30 @@ def main():
         loss.backward()
         return loss
 
-    if a.no_graph:
-        def step():
-            model.zero_grad(set_to_none=True)
-            loss = fwd_bwd()
-            if dp is not None:
-                dp.all_reduce()
-            return loss
-    else:
-        from mm_dfn_amd.graphs import CapturedStep
-        captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
+    def eager_step():
+        model.zero_grad(set_to_none=True)
+        loss = fwd_bwd()
+        if dp is not None:
+            dp.all_reduce()
+        return loss
 
-        def step():
-            loss = captured.replay()
-            if dp is not None:
-                dp.reduce_flat()
-            return loss
+    step = eager_step
+    launch_mode = "eager"
+    if not a.no_graph:
+        from mm_dfn_amd.graphs import CapturedStep
+        try:
+            captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
+
+            def step():
+                loss = captured.replay()
+                if dp is not None:
+                    dp.reduce_flat()
+                return loss
+            launch_mode = "hipGraph replay of the whole step"
+        except Exception as exc:  # capture is an optimisation; never lose the measurement over it
+            print("[bench] hipGraph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
+            torch.cuda.synchronize()
+            step = eager_step
 
     for _ in range(a.warmup):
         step()
@@ -194,7 +202,7 @@ def main():
             "metric": "utterances/sec (fwd+bwd), IEMOCAP-shaped batch", "value": total_utt * a.steps / dt,
             "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "launch": "eager" if a.no_graph else "hipGraph replay of the whole step",
+            "dtype": "f32", "data": "synthetic", "launch": launch_mode,
             "config": {"workload": "%s: B=%d dialogues/GPU, L=%s, dims %d/%d/%d, %d GCN layers, P=%d, dropout %.2f"
                                    % (a.config, cfg["B"], "ragged<=%d" % cfg["L"] if a.ragged else cfg["L"], cfg["D_t"],
                                       cfg["D_a"], cfg["D_v"], cfg["nlayers"], cfg["P"], a.dropout),
@@ -203,6 +211,27 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3, "traffic": None},
         }
+        # the same kernel on BASELINE config 5 (L=512, M=6, d=100, 32 dialogues), where one launch moves 282 MB and
+        # the launch-latency floor no longer hides the kernel (the >=40 % HBM target is a cfg5 property)
+        try:
+            l5 = [512] * 32
+            f5 = torch.randn(6, sum(l5), 200, device=dev)
+
+            def mk5():
+                adj = ops.build_adjacency(f5, l5)
+                return adj, torch.randn(6 * sum(l5), d, device=dev)
+
+            ms5 = time_propagate(mk5, d, iters=20)
+            lay5 = ops.DialogueLayout.get(l5, 6, dev)
+            b5 = lay5.propagate_bytes(d)
+            out["roofline_cfg5"] = {"workload": "cfg5: B=32, L=512, M=6, d=100", "bound": "hbm (MFMA-bound at 47 %)",
+                                    "achieved": b5 / (ms5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b5,
+                                    "avg_launch_us": ms5 * 1e3,
+                                    "f32_mfma_tflops": lay5.propagate_flops(d) / (ms5 * 1e-3) / 1e12}
+            del f5
+        except Exception as exc:
+            print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads)
         print(json.dumps(out), flush=True)

@@ -29,7 +29,8 @@ class CapturedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # thread_local: a communication-library watchdog thread polling its own events must not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = step_fn()
             if bucket is not None:
                 bucket.flatten()
