@@ -200,9 +200,9 @@ class DialogueGNNModel(nn.Module):
         (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209).
         The context GRU and the batched party GRU are independent and share every recurrence launch;
         the party gather / scatter / pad-strip are the fused K3/K4 kernels (csrc/encoder_glue.hip)."""
-        Xa = self.linear_a(U_a)
-        Xv = self.linear_v(U_v)
-        Xl = self.linear_l(U)
+        Xa = ops.linear(U_a, self.linear_a.weight, self.linear_a.bias)
+        Xv = ops.linear(U_v, self.linear_v.weight, self.linear_v.bias)
+        Xl = ops.linear(U, self.linear_l.weight, self.linear_l.bias)
         L, B, H = Xa.shape
         idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
         if self.use_crn_speaker:
@@ -226,5 +226,5 @@ class DialogueGNNModel(nn.Module):
             padded = fused.new_zeros(L * B, fused.shape[1]).index_copy(0, idx, fused).view(L, B, -1)
             fused = self.mfn(padded).reshape(L * B, -1).index_select(0, idx)
         z = F.relu(self.dropout_(fused))
-        log_prob = F.log_softmax(self.smax_fc(z), 1)
+        log_prob = F.log_softmax(ops.linear(z, self.smax_fc.weight, self.smax_fc.bias), 1)
         return log_prob, None, None, None, None

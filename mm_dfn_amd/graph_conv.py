@@ -104,12 +104,12 @@ class GCNII_lyc(nn.Module):
             if self.reason_flag:
                 G = ops.linear(q, w_ih, bias)
                 if h is not None:
-                    G = torch.addmm(G, h, w_hh.t())
+                    G = ops.linear(h, w_hh, None, base=G)
                 h, c = ops.lstm_pointwise(G, c)
                 cur = h
             theta = math.log(self.lamda / (i + 1) + 1)
             S2 = ops.propagate_concat(adj, cur, h0)
-            P = torch.mm(S2, con.weight)
+            P = ops.matmul_kn(S2, con.weight)
             cur = ops.gcnii_combine(P, S2, q if self.reason_flag else None, self._dropout_mask(P), theta, self.alpha)
         if self.use_residue:
             cur = torch.cat([x, cur], dim=-1)

@@ -8,6 +8,8 @@ all-reduce / optimizer step can follow each replay.
 """
 import torch
 
+from . import ops
+
 
 class CapturedStep:
     def __init__(self, model, step_fn, warmup=3, bucket=None):
@@ -23,6 +25,7 @@ class CapturedStep:
             for _ in range(max(warmup, 1)):
                 model.zero_grad(set_to_none=True)
                 step_fn()
+                ops.join_weight_grads()
                 if bucket is not None:
                     bucket.flatten()
         torch.cuda.current_stream().wait_stream(side)
@@ -32,6 +35,7 @@ class CapturedStep:
         # thread_local: a communication-library watchdog thread polling its own events must not invalidate the capture
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = step_fn()
+            ops.join_weight_grads()          # side-stream branches rejoin the captured graph here
             if bucket is not None:
                 bucket.flatten()
         self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}

@@ -60,13 +60,16 @@ class _GruRecurrence(torch.autograd.Function):
             # dW_hh = sum_t dgh_t (x) h_{t-1}: forward direction h_{t-1} = y[t-1], reverse h_{t-1} = y[t+1];
             # the time-shifted column slices are read in place (row-strided views) by the split-K kernel
             d2, y2 = d.view(T * R, 6 * H), y.view(T * R, 2 * H)
-            if T > 1:
-                dwf = ops.gemm_tn(d2[R:, :3 * H], y2[:-R, :H])[0]
-                dwr = ops.gemm_tn(d2[:-R, 3 * H:], y2[R:, H:])[0]
-            else:
-                dwf = torch.zeros(3 * H, H, dtype=torch.float32, device=y.device)
-                dwr = torch.zeros_like(dwf)
-            out += [dgi[g], torch.stack([dwf, dwr], 0), d2.sum(0).view(2, 3 * H)]
+            with ops._wgrad_scope(d, y):              # recurrent-weight gradients: off the critical path
+                if T > 1:
+                    dwf = ops.gemm_tn(d2[R:, :3 * H], y2[:-R, :H])[0]
+                    dwr = ops.gemm_tn(d2[:-R, 3 * H:], y2[R:, H:])[0]
+                else:
+                    dwf = torch.zeros(3 * H, H, dtype=torch.float32, device=y.device)
+                    dwr = torch.zeros_like(dwf)
+                dw = torch.stack([dwf, dwr], 0)
+                db = d2.sum(0).view(2, 3 * H)
+            out += [dgi[g], dw, db]
         return tuple(out)
 
 

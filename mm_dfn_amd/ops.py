@@ -388,48 +388,150 @@ def gemm_tn(A, B, want_colsum=False):
     return C, colsum
 
 
+# ---------------------------------------------------------------------------------------------------
+# Weight-gradient side stream.  dW / db of the dense layers feed nothing else in the backward pass, so when
+# enabled they are enqueued on a second HIP stream (forked from / joined to the main stream with events; under
+# hipGraph capture these become parallel graph branches) and overlap the serial dX chain.  Whoever consumes
+# .grad (optimizer step, gradient all-reduce) must call join_weight_grads() first; mm_dfn_amd.train and
+# mm_dfn_amd.graphs.CapturedStep do.  Off by default: on MI355X at IEMOCAP sizes the fork/join cost outweighs
+# the overlap (cfg2 step 2.16 ms with the side stream vs 1.99 ms without, bench.py --async-wgrad).
+# ---------------------------------------------------------------------------------------------------
+_WG = {"enabled": False, "stream": None, "dirty": False}
+
+
+def set_async_weight_grads(flag):
+    _WG["enabled"] = bool(flag)
+
+
+def async_weight_grads_enabled():
+    return _WG["enabled"]
+
+
+def _wgrad_stream():
+    if _WG["stream"] is None:
+        _WG["stream"] = torch.cuda.Stream()
+    return _WG["stream"]
+
+
+def join_weight_grads():
+    """Make the current stream wait for every weight-gradient kernel launched on the side stream."""
+    if _WG["dirty"]:
+        torch.cuda.current_stream().wait_stream(_WG["stream"])
+        _WG["dirty"] = False
+
+
+class _wgrad_scope:
+    """``with _wgrad_scope(t1, t2, ...):`` runs the block on the side stream (if enabled) behind the main
+    stream's work so far; the listed tensors (main-stream allocations read by the block) are protected from
+    premature reuse by the caching allocator."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if _WG["enabled"]:
+            side = _wgrad_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(side)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+            _WG["dirty"] = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class _Linear(torch.autograd.Function):
-    """y = act(x W^T + b); forward and dX on the MFMA kernel, dW / db as library reductions."""
+    """y = act(x W^T + b) (+ base).  Engine per shape: the hand-written MFMA kernels where they win
+    (linear_preferred), the library GEMM otherwise; dW / db always off the critical path (side stream)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, base):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        y = linear_raw(x2, weight, bias, act)
+        N, K = weight.shape
+        mfma = linear_supported(x2, weight) and linear_preferred(x2.shape[0], K, N)
+        if mfma:
+            if base is not None:
+                y = linear_raw(x2, weight, bias, 0, out=base.reshape(-1, N).clone(), accumulate=True)
+                if act:
+                    y = torch.relu_(y)
+            else:
+                y = linear_raw(x2, weight, bias, act)
+        else:
+            if base is not None:
+                y = torch.addmm(base.reshape(-1, N), x2, weight.t())
+                if bias is not None:
+                    y = y + bias
+            else:
+                y = torch.nn.functional.linear(x2, weight, bias)
+            if act:
+                y = torch.relu_(y)
         ctx.act = act
         ctx.has_bias = bias is not None
+        ctx.has_base = base is not None
         ctx.save_for_backward(x2, weight, y if act else None)
-        return y.view(*shp[:-1], weight.shape[0])
+        return y.view(*shp[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, weight, y = ctx.saved_tensors
-        dy2 = dy.reshape(-1, weight.shape[0])
+        N, K = weight.shape
+        dy2 = dy.reshape(-1, N)
         if ctx.act:
             dy2 = dy2 * (y > 0).to(dy2.dtype)
         dy2 = dy2.contiguous()
         dx = dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            with _wgrad_scope(dy2, x2):
+                if gemm_tn_supported(N, K):
+                    dw, db = gemm_tn(dy2, x2, want_colsum=ctx.has_bias)      # dW and db in one pass over dY
+                else:
+                    dw = dy2.t() @ x2
+                    db = dy2.sum(0) if ctx.has_bias else None
         if ctx.needs_input_grad[0]:
-            N = weight.shape[0]
-            if N % 4 == 0 and linear_preferred(dy2.shape[0], N, weight.shape[1]):
+            if N % 4 == 0 and linear_preferred(dy2.shape[0], N, K):
                 dx = linear_raw(dy2, weight.t().contiguous(), None, 0)
             else:
                 dx = dy2 @ weight
-            dx = dx.view(*dy.shape[:-1], weight.shape[1])
+            dx = dx.view(*dy.shape[:-1], K)
+        dbase = dy2.view(dy.shape) if ctx.has_base and ctx.needs_input_grad[4] else None
+        return dx, dw, db, None, dbase
+
+
+class _MatmulKN(torch.autograd.Function):
+    """y = x @ W with W stored (K, N) (GraphConvolution.weight, model_GCN.py:169,186); dW on the side stream."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.mm(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
         if ctx.needs_input_grad[1]:
-            if gemm_tn_supported(weight.shape[0], weight.shape[1]):
-                dw, db = gemm_tn(dy2, x2, want_colsum=ctx.has_bias)      # dW and db in one pass over dY
-            else:
-                dw = dy2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
-            db = dy2.sum(0)
-        return dx, dw, db, None
+            with _wgrad_scope(dy, x):
+                dw = gemm_tn(x, dy)[0] if gemm_tn_supported(w.shape[0], w.shape[1]) else x.t() @ dy
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w.t()
+        return dx, dw
 
 
-def linear(x, weight, bias=None, act=0):
-    """Drop-in for F.linear (optionally fused ReLU): MFMA kernel where it is the faster engine, library GEMM
-    (hipBLASLt through torch, also on the GPU) otherwise or when K % 4 != 0."""
-    if not linear_supported(x, weight) or not linear_preferred(x.numel() // x.shape[-1], weight.shape[1], weight.shape[0]):
-        y = torch.nn.functional.linear(x, weight, bias)
-        return torch.relu(y) if act else y
-    return _Linear.apply(x, weight, bias, act)
+def matmul_kn(x, w):
+    _hip.require_cuda(x)
+    return _MatmulKN.apply(x, w)
+
+
+def linear(x, weight, bias=None, act=0, base=None):
+    """Drop-in for F.linear with optional fused ReLU and an optional addend (y = base + x W^T + b)."""
+    _hip.require_cuda(x)
+    return _Linear.apply(x, weight, bias, act, base)

@@ -13,6 +13,8 @@ import random
 import numpy as np
 import torch
 
+from . import ops
+
 
 def seed_everything(seed=2021):
     """run_train_erc.py:19-26."""
@@ -58,6 +60,7 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
         losses.append(loss.detach())
         if train_flag:
             loss.backward()
+            ops.join_weight_grads()       # weight gradients may have been computed on the side stream
             if step_hook is not None:
                 step_hook(model)          # e.g. data-parallel gradient all-reduce
             optimizer.step()

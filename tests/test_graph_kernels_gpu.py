@@ -215,10 +215,18 @@ def test_mfma_linear_forward_backward(R, K, N):
             yo = torch.relu(yo)
         (yo * g.double()).sum().backward()
         xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
-        y = ops._Linear.apply(xg, wg, bg, act)          # force the MFMA path regardless of the shape heuristic
+        y = ops.linear(xg, wg, bg, act)      # MFMA kernels for the big-row shapes, library GEMM for the rest;
+        # dW / db always through the split-K kernel when the shape allows
         (y * g.to(DEV)).sum().backward()
         assert rel_err(y, yo) < 2e-6
         assert rel_err(xg.grad, xo.grad) < 2e-5 and rel_err(wg.grad, wo.grad) < 2e-5 and rel_err(bg.grad, bo.grad) < 2e-5
+    # base + x W^T + b through the autograd wrapper (LSTM gate pre-activations: G + h W_hh^T)
+    base = torch.from_numpy(rs.randn(R, N).astype(np.float32))
+    xg, wg, baseg = (t.to(DEV).requires_grad_(True) for t in (x, w, base))
+    y = ops.linear(xg, wg, None, 0, base=baseg)
+    (y * g.to(DEV)).sum().backward()
+    assert rel_err(y, base.double() + x.double() @ w.double().t()) < 2e-6
+    assert rel_err(baseg.grad, g) < 1e-7 and rel_err(xg.grad, g.double() @ w.double()) < 2e-5
     raw = ops.linear_raw(x.to(DEV), w.to(DEV), None, 0)
     acc = ops.linear_raw(x.to(DEV), w.to(DEV), b.to(DEV), 0, out=raw.clone(), accumulate=True)
     assert rel_err(acc, 2 * (x.double() @ w.double().t()) + b.double()) < 2e-6
