@@ -194,6 +194,14 @@ int mmdfn_gemm_tn_splits(int R, int M, int N);
 int mmdfn_gemm_tn(const float* A, const float* B, float* C, float* colsum, float* workspace,
                   int R, int M, int N, int lda, int ldb, int ldc, int splits, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Fused Adam step over flat fp32 buffers (replaces torch.optim.Adam(lr, weight_decay=l2).step(),
+ * run_train_erc.py:512,212): L2 folded into the gradient, bias-corrected, `step` = 1, 2, ...
+ * p, m, v updated in place; n elements (16-byte aligned buffers).
+ * ------------------------------------------------------------------------- */
+int mmdfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,51 @@
+"""FlatAdam: the reference's optimizer (torch.optim.Adam(lr, weight_decay=l2), run_train_erc.py:512) as ONE
+fused HIP launch per step over flat buffers.
+
+All parameters that receive gradients are re-pointed at slices of one contiguous fp32 buffer and their
+gradients are packed into a matching flat buffer (the same bucket the data-parallel all-reduce uses), so the
+update is a single elementwise kernel (csrc/optimizer.hip).  Parameters the MM-DFN configuration never reaches
+get no gradient and are left untouched, exactly like torch.optim.Adam skips ``grad is None``.
+"""
+import torch
+
+from . import _hip
+from .distributed import GradientBucket
+
+
+class FlatAdam:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket=None):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.bucket = bucket if bucket is not None else GradientBucket(model, average=True)
+        self.t = 0
+        self.flat_p = self.m = self.v = None
+
+    def zero_grad(self, set_to_none=True):
+        self.model.zero_grad(set_to_none=True)
+
+    def _materialise(self):
+        params = self.bucket.params
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view_as(p)
+            off += n
+        self.flat_p = flat
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+
+    @torch.no_grad()
+    def step(self, grads_already_flat=False):
+        """Pack gradients (unless the caller already did, e.g. after the data-parallel all-reduce) and update."""
+        if not grads_already_flat:
+            self.bucket.flatten()
+        g = self.bucket.flat
+        _hip.require_cuda(g)
+        if self.flat_p is None:
+            self._materialise()
+        self.t += 1
+        rc = _hip.lib().mmdfn_adam_step(_hip.ptr(self.flat_p), _hip.ptr(g), _hip.ptr(self.m), _hip.ptr(self.v),
+                                        g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                        self.t, _hip.stream())
+        _hip.check(rc, "mmdfn_adam_step")
