@@ -119,6 +119,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from mm_dfn_amd import FocalLoss, synthetic, train, ops, distributed
+    if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # eager + captured steps share parameters
 
     if world > 1:
         distributed.init(backend=a.backend)
