@@ -240,21 +240,25 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
     // Raw loads only; the zero-masking happens when a set is consumed, otherwise the selects would
     // force a vmcnt(0) wait right behind the loads.  The loop is unrolled by two so that the ring
     // index is static (runtime-indexed register arrays would go to scratch).
-    float4 hset[2][NH4];
-    float4 aset[2][RPW][NSUB];
+    float4 hset[2][NH4] = {};
+    float4 aset[2][RPW][NSUB] = {};
     const int nchunks = (L + BKT - 1) / BKT;
 
 #define MMDFN_ISSUE(SET, K0)                                                                              \
     do {                                                                                                  \
-        _Pragma("unroll") for (int e = 0; e < NH4; ++e) {                                                 \
-            const int k_ = (K0) + s_kk[e];                                                                \
-            hset[SET][e] = *reinterpret_cast<const float4*>(s_ptr[e] + (int64_t)(k_ < L ? k_ : L - 1) * ldh); \
-        }                                                                                                 \
-        _Pragma("unroll") for (int rp = 0; rp < RPW; ++rp)                                                \
-            _Pragma("unroll") for (int h = 0; h < NSUB; ++h) {                                            \
-                const int ka_ = (K0) + 16 * h + 4 * g;                                                    \
-                aset[SET][rp][h] = *reinterpret_cast<const float4*>(a_ptr[rp] + (ka_ < ld ? ka_ : ld - 4)); \
+        if (!(abl & 4)) {                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < NH4; ++e) {                                             \
+                const int k_ = (K0) + s_kk[e];                                                            \
+                hset[SET][e] = *reinterpret_cast<const float4*>(s_ptr[e] + (int64_t)(k_ < L ? k_ : L - 1) * ldh); \
             }                                                                                             \
+        }                                                                                                 \
+        if (!(abl & 8)) {                                                                                 \
+            _Pragma("unroll") for (int rp = 0; rp < RPW; ++rp)                                            \
+                _Pragma("unroll") for (int h = 0; h < NSUB; ++h) {                                        \
+                    const int ka_ = (K0) + 16 * h + 4 * g;                                                \
+                    aset[SET][rp][h] = *reinterpret_cast<const float4*>(a_ptr[rp] + (ka_ < ld ? ka_ : ld - 4)); \
+                }                                                                                         \
+        }                                                                                                 \
     } while (0)
 
 #define MMDFN_CHUNK(SET, C)                                                                               \
