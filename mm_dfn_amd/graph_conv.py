@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
-from . import ops
+from . import _hip, ops
 from .layout import BlockTileAdjacency
 
 
@@ -31,6 +31,7 @@ class GraphConvolution(nn.Module):
             self.weight.uniform_(-bound, bound)
 
     def forward(self, input, adj, h0, lamda, alpha, l):
+        _hip.require_cuda(input)                      # MI355X path only: no CPU fallback
         theta = math.log(lamda / l + 1)
         if isinstance(adj, BlockTileAdjacency):
             hi = ops.propagate(adj, input)           # HIP K6
@@ -80,6 +81,7 @@ class GCNII_lyc(nn.Module):
         if adj is None:
             raise NotImplementedError("GCNII_lyc without an explicit adjacency (reference model_GCN.py:490-584) "
                                       "is outside the MM-DFN hot path; pass adj from MM_GCN.create_big_adj")
+        _hip.require_cuda(x)                          # MI355X path only: no CPU fallback
         fused = isinstance(adj, BlockTileAdjacency) and all(c.variant and not c.residual for c in self.convs)
         return self._forward_fused(x, adj) if fused else self._forward_generic(x, adj)
 
