@@ -53,10 +53,15 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIBPATH
-    if not os.path.exists(path):
-        raise HipLibraryError(
-            "libmmdfn_hip.so not built (%s missing): run `python -m mm_dfn_amd.build` "
-            "(needs hipcc); the MI355X path has no CPU fallback" % path)
+    if _build.is_stale():
+        # missing or older than the sources: rebuild in place when a compiler is at hand (the GPU box has hipcc)
+        try:
+            _build.build(verbose=False)
+        except Exception as e:
+            if not os.path.exists(path):
+                raise HipLibraryError(
+                    "libmmdfn_hip.so not built (%s missing) and could not be built (%s): run `python -m "
+                    "mm_dfn_amd.build` (needs hipcc); the MI355X path has no CPU fallback" % (path, e)) from e
     handle = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         try:
