@@ -41,8 +41,18 @@ def hipcc():
 
 
 def build(force=False, verbose=True):
-    """Compile every csrc/*.hip for gfx950 into lib/libmmdfn_hip.so."""
+    """Compile every csrc/*.hip for gfx950 into lib/libmmdfn_hip.so (serialised across processes)."""
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)          # one builder at a time (data-parallel ranks share the tree)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     stamp = os.path.join(LIBDIR, "libmmdfn_hip.sha256")
     digest = _digest()
     if not force and os.path.exists(LIBPATH) and os.path.exists(stamp):
