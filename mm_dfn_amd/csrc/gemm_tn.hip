@@ -10,6 +10,7 @@
 // of the GRU buffers in place.
 #include "mmdfn_internal.h"
 #include "../../include/mmdfn_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -144,12 +145,20 @@ __global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, const floa
 }  // namespace
 
 extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) {
-    const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    int s = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
-    const int max_s = (R + 4 * BR - 1) / (4 * BR);  // at least 4 chunks per split
+    if (const char* e = getenv("MMDFN_TN_SPLITS")) {   // tuning aid (tools/bench_gemm_tn.py)
+        const int v = atoi(e);
+        if (v > 0) return v;
+    }
+    // measured on MI355X (tools/bench_gemm_tn.py): ~330-660 rows per split is the sweet spot for every hot-path
+    // shape (R = 1.7k .. 10.5k, outputs 100x200 .. 600x200); more splits only inflate the slab reduction
+    (void)M;
+    (void)N;
+    int s = (R + 329) / 330;
+    if (s < 8) s = 8;
+    if (s > 16) s = 16;
+    const int max_s = (R + 2 * BR - 1) / (2 * BR);  // at least two staged chunks per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
     return s;
 }
 
