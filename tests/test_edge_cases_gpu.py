@@ -1,0 +1,108 @@
+"""GPU parity on edge cases of the path: degenerate dialogue lengths, silent speakers, single-dialogue batches,
+two-modality graphs, the optional speaker / modality embeddings, non-default modal_weight."""
+import numpy as np
+import pytest
+import torch
+
+import mmdfn_oracle as O
+from mm_dfn_amd import MM_GCN, synthetic, ops
+from util import abs_err, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _run_model(cfg, lengths, seed, qmask_edit=None):
+    m = synthetic.build_model(**cfg)
+    sd = synthetic.seeded_state_dict(m.state_dict(), seed)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    b = synthetic.make_batch(seed + 1, lengths=lengths, **cfg)
+    if qmask_edit is not None:
+        qmask_edit(b["qmask"])
+    logp = m(b["textf"].to(DEV), b["qmask"].to(DEV), b["umask"].to(DEV), b["lengths"], b["acouf"].to(DEV),
+             b["visuf"].to(DEV))[0]
+    w = torch.from_numpy(np.random.RandomState(seed).randn(*logp.shape).astype(np.float32))
+    (logp * w.to(DEV)).sum().backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = O.forward(params, b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"],
+                     O.default_cfg(cfg["nlayers"]), engine="aten")
+    (want * w).sum().backward()
+    return m, logp, params, want
+
+
+@pytest.mark.parametrize("lengths", [[1], [1, 1, 2], [2, 1], [3], [17, 1, 9]])
+def test_degenerate_dialogue_lengths(lengths):
+    cfg = dict(B=len(lengths), L=max(lengths), P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+    m, logp, params, want = _run_model(cfg, lengths, 31)
+    assert abs_err(logp, want) < 1e-4
+    for k in ("linear_l.weight", "rnn_parties.weight_hh_l0", "graph_model.graph_net.convs.1.weight", "smax_fc.weight"):
+        g = dict(m.named_parameters())[k].grad
+        assert rel_err(g, params[k].grad) < 5e-4, k
+
+
+def test_silent_speaker_and_unflagged_utterance():
+    """Speaker 1 never speaks in dialogue 0; one valid utterance carries no speaker flag at all (its party term is 0)."""
+    cfg = dict(B=2, L=9, P=3, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+
+    def edit(q):
+        q[:, 0, 1] = 0.0
+        q[:, 0, 0] = torch.maximum(q[:, 0, 0], (q[:, 0].sum(1) == 0).float() * (torch.arange(9) < 9).float())
+        q[4, 1, :] = 0.0
+    m, logp, params, want = _run_model(cfg, [9, 6], 32, edit)
+    assert abs_err(logp, want) < 1e-4
+    assert rel_err(m.rnn_parties.weight_ih_l0.grad, params["rnn_parties.weight_ih_l0"].grad) < 5e-4
+
+
+@pytest.mark.parametrize("modals", ["av", "al", "vl"])
+@pytest.mark.parametrize("modal_weight", [1.0, 0.6])
+def test_two_modality_graph_module(modals, modal_weight):
+    rs = np.random.RandomState(40)
+    lengths = [11, 4, 7]
+    N = sum(lengths)
+    net = MM_GCN(200, 200, 200, 200, 3, 100, 6, 0.0, 0.5, 0.2, True, True, True, n_speakers=2, modals=list(modals),
+                 use_speaker=False, use_modal=False, reason_flag=True, modal_weight=modal_weight)
+    sd = synthetic.seeded_state_dict(net.state_dict(), 41)
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    feats = {k: torch.from_numpy(rs.randn(N, 200).astype(np.float32)) for k in "avl"}
+    q = torch.zeros(max(lengths), len(lengths), 2)
+    dev = {k: v.to(DEV).requires_grad_(True) for k, v in feats.items()}
+    out = net(dev["a"] if "a" in modals else [], dev["v"] if "v" in modals else [], dev["l"] if "l" in modals else [],
+              lengths, q.to(DEV))
+    w = torch.from_numpy(rs.randn(*out.shape).astype(np.float32))
+    (out * w.to(DEV)).sum().backward()
+    cpu = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    params = {"graph_model." + k: v for k, v in sd.items()}
+    cfg = O.default_cfg(3, modal_weight=modal_weight)
+    want = O.mm_gcn([cpu[k] for k in modals], lengths, params, cfg)
+    (want * w).sum().backward()
+    assert abs_err(out, want) < 5e-5
+    for k in modals:
+        assert rel_err(dev[k].grad, cpu[k].grad) < 2e-4, k
+
+
+def test_speaker_and_modality_embeddings_enabled():
+    """use_speaker / use_modal (model_mm.py:78-93): l += speaker_embeddings[argmax qmask], x_m += modal_embeddings[m]."""
+    rs = np.random.RandomState(50)
+    lengths = [8, 5]
+    N = sum(lengths)
+    L, B, P = 8, 2, 2
+    net = MM_GCN(200, 200, 200, 200, 2, 100, 6, 0.0, 0.5, 0.2, True, True, True, n_speakers=P, modals=list("avl"),
+                 use_speaker=True, use_modal=True, reason_flag=True)
+    sd = synthetic.seeded_state_dict(net.state_dict(), 51)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    a, v, l = (torch.from_numpy(rs.randn(N, 200).astype(np.float32)) for _ in range(3))
+    spk = rs.randint(0, P, size=(L, B))
+    q = torch.zeros(L, B, P)
+    for b_, n in enumerate(lengths):
+        q[np.arange(n), b_, spk[:n, b_]] = 1
+    with torch.no_grad():
+        got = net(a.clone().to(DEV), v.clone().to(DEV), l.clone().to(DEV), lengths, q.to(DEV))
+        flat_spk = torch.cat([torch.from_numpy(spk[:n, b_]) for b_, n in enumerate(lengths)])
+        l2 = l + sd["speaker_embeddings.weight"][flat_spk]
+        emb = sd["modal_embeddings.weight"]
+        feats = [a + emb[0], v + emb[1], l2 + emb[2]]
+        want = O.mm_gcn(feats, lengths, {"graph_model." + k: t for k, t in sd.items()}, O.default_cfg(2))
+    assert abs_err(got, want) < 5e-5
