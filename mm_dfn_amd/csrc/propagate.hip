@@ -91,6 +91,9 @@ __global__ __launch_bounds__(64 * NW) void propagate_kernel(
             }
             a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
             a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+            // the row padding (columns L .. ld-1) is not data and may hold anything, NaN included
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (kbase + j < L) ? a[j] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -274,10 +277,13 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
         float av[RPW][4 * NSUB];                                                                          \
         _Pragma("unroll") for (int rp = 0; rp < RPW; ++rp)                                                \
             _Pragma("unroll") for (int h = 0; h < NSUB; ++h) {                                            \
-                const bool ok = a_ok[rp] && (kc0 + 16 * h + 4 * g < ld);                                  \
+                /* per element: the row padding (columns L .. ld-1) is not data, it may hold NaN */      \
+                const int ka_ = kc0 + 16 * h + 4 * g;                                                     \
                 const float4 v = aset[SET][rp][h];                                                        \
-                av[rp][4 * h + 0] = ok ? v.x : 0.f; av[rp][4 * h + 1] = ok ? v.y : 0.f;                   \
-                av[rp][4 * h + 2] = ok ? v.z : 0.f; av[rp][4 * h + 3] = ok ? v.w : 0.f;                   \
+                av[rp][4 * h + 0] = (a_ok[rp] && ka_ + 0 < L) ? v.x : 0.f;                                \
+                av[rp][4 * h + 1] = (a_ok[rp] && ka_ + 1 < L) ? v.y : 0.f;                                \
+                av[rp][4 * h + 2] = (a_ok[rp] && ka_ + 2 < L) ? v.z : 0.f;                                \
+                av[rp][4 * h + 3] = (a_ok[rp] && ka_ + 3 < L) ? v.w : 0.f;                                \
             }                                                                                             \
         __syncthreads();                                                                                  \
         if ((C) + 2 < nchunks) MMDFN_ISSUE(SET, ((C) + 2) * BKT);                                         \
@@ -420,7 +426,7 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
         return small_rows ? launch<2, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s)
                           : launch<4, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s);
     }
-    const int ov = tuning_override();
+    const int ov = tuning_override();   // 0-7: f32-MFMA tilings, 8: bf16-piece kernel, 9: never the bf16-piece kernel
     if (ov >= 0) {
         switch (ov) {
             case 0: return V2(4, 1, 7, 16, 1);
@@ -431,13 +437,31 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
             case 5: return V2(4, 2, 4, 16, 1);
             case 6: return V2(4, 1, 7, 16, 2);
             case 7: return V2(4, 2, 7, 16, 1);
+            case 8: {
+                const int rc = mmdfn_launch_propagate_split(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d,
+                                                            ldh, ldo, max_len, s);
+                if (rc != -2) return rc;
+                break;
+            }
             default: break;
         }
+    }
+    if (ov == 9) {
+        if (d <= 112) return ((long)B * M * max_len <= 32768L) ? V2(2, 4, 2, 16, 1) : V2(8, 1, 7, 16, 1);
+        if (d <= 224) return V2(4, 2, 7, 16, 1);
+        return V2(4, 2, 4, 16, 1);
     }
     // measured on MI355X (profiles/r01_propagate_tuning.md): many small workgroups with the columns split
     // over 4 waves win while the launch is latency-bound; 8-wave row blocks win once the H-row staging
     // traffic (one pass over the H tile per row block) dominates.
     const long approx_rows = (long)B * M * max_len;
+    if (d <= 128 && approx_rows > 32768L && max_len >= 128) {
+        // large launches are bound by the exact-f32 MFMA rate: carry the product on bf16 MFMAs (three exact
+        // bf16 pieces per operand, fp32-level error; propagate_split.hip): 124 -> 88 us at L=512, M=6, B=32
+        const int rc = mmdfn_launch_propagate_split(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh,
+                                                    ldo, max_len, s);
+        if (rc != -2) return rc;
+    }
     if (d <= 112) {
         if (approx_rows <= 32768L) return V2(2, 4, 2, 16, 1);
         return V2(8, 1, 7, 16, 1);

@@ -1,0 +1,365 @@
+// K6 (large-dialogue variant): out = A_hat . H with the fp32 product carried by bf16 MFMAs.
+//
+// Replaces torch.spmm(adj, input) (reference model_GCN.py:178) like propagate.hip, for launches that are
+// bound by the exact-f32 MFMA rate (v_mfma_f32_16x16x4_f32: 32 cycles per 2 kflop on a SIMD).  Each fp32
+// operand is cut -- exactly, by truncation -- into three bf16 pieces  x = x1 + x2 + x3  (8 + 8 + 8
+// significant bits) and the product is assembled from the six piece products whose weight is >= 2^-16:
+//     a.b ~= a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1          (dropped: a2b3 + a3b2 + a3b3 <= 2^-23 |a||b|)
+// Every piece product is exact in the fp32 accumulator, so the result carries fp32-level error (the dropped
+// terms are the size of one fp32 rounding of a.b; measured max |err| vs an fp64 product: 1.8e-7, the same as
+// the f32-MFMA kernel) while six bf16 MFMAs per K=16 replace four f32 MFMAs per K=16 at 1/16 of the cycles
+// per flop: 2.7x less matrix-pipe time.
+//
+// Work decomposition: workgroup = (dialogue, modality, 128 tile rows); 4 waves x 32 rows; 128 feature
+// columns (d <= 128) as 4 v_mfma_f32_32x32x16_bf16 column tiles.
+//   A (the tile strip) goes HBM -> registers in MFMA layout (lane (row, kg) holds 8 consecutive k per K=16
+//     step; the k permutation inside a 32-wide chunk makes each load instruction fetch 32 contiguous bytes per
+//     row) and is cut in registers.
+//   B (the H rows of the tile) is cut ONCE per workgroup and parked in LDS as three bf16 [col][k-slot] arrays
+//     whose 16-byte reads ARE the MFMA B fragments (row stride 20 dwords: conflict-free per quarter wave);
+//     double-buffered, one barrier per chunk.
+//   Each of the 48 MFMAs of a chunk is followed by one of the 48 cutting stages (~4 VALU) of the NEXT chunk,
+//     pinned there with scheduling barriers, so no wave ever sits in a VALU-only phase while the matrix pipe
+//     idles.  (Measured on MI355X, tools/ubench/mfma_bf16_fillers.hip + profiles/r01_propagate_tuning.md: a
+//     32x32x16 MFMA hides at most ~7 trailing VALU, and a second wave on the SIMD adds no VALU/MFMA overlap, so
+//     the kernel's time is ~ MFMA time + 4 cycles per other instruction: the instruction count of the cutting is
+//     what bounds it.)
+// Cross-modal diagonals are added in the LDS row epilogue as in propagate.hip.  XCD mapping: blockIdx % 8 ==
+// dialogue % 8.
+#include "mmdfn_internal.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int SBK = 32;    // k per chunk = two K=16 MFMA steps
+constexpr int SROW = 20;   // LDS row stride in dwords: 16 (32 bf16) + 4 pad; 16 consecutive rows -> 64 banks
+
+__device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ABLC (profiling aid, compile time): 1 = no cutting stages, 2 = no MFMAs
+template <int ABLC>
+__global__ __launch_bounds__(256, 2) void propagate_split_kernel(
+    const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
+    float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
+    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int abl) {
+    constexpr int NCT = 4;                 // 32-column MFMA tiles
+    constexpr int WROWS = 32;              // tile rows per wave
+    constexpr int BM = 4 * WROWS;          // 128 tile rows per workgroup
+    constexpr int CB = 32 * NCT;
+    constexpr int LDO = CB + 8;            // epilogue row stride (floats): 4 rows apart -> 32 banks apart
+    constexpr int OROWS = 64;              // output rows staged per epilogue pass
+    constexpr int split_stride = 128 * SROW;   // dwords per bf16 piece array: one row per column (rows >= d hold zeros)
+    constexpr int stage_stride = 3 * split_stride;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+
+    // XCD-aware decode: bid % 8 == dialogue % 8
+    const int Rd = M * max_rb;
+    const int bid = blockIdx.x;
+    const int yq = bid >> 3;
+    const int i = (yq / Rd) * 8 + (bid & 7);
+    if (i >= B) return;
+    const int rho = yq % Rd;
+    const int m = rho / max_rb;
+    const int rb = rho - m * max_rb;
+    const int L = dia_len[i];
+    const int r0 = rb * BM;
+    if (r0 >= L) return;
+    const int ld = (L + 3) & ~3;
+    const int rs = row_start[i];
+    const float* T = tiles + tile_base[i] + (int64_t)m * L * ld;
+    const float* Hm = H + ((int64_t)m * N + rs) * ldh;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int l32 = lane & 31;
+    const int kg = lane >> 5;
+    const int wrow0 = r0 + WROWS * w;
+
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+    // ---- k permutation inside a chunk: MFMA step kh (0,1), lane group kg (0,1), element e (0..7)  <->
+    //      k = 16 kh + 8 (e >> 2) + 4 kg + (e & 3)
+    // B staging tasks: thread -> column (tid & 127), slots (kh = 0 and 1, kg = tid >> 7): 2 x 8 k values
+    const int bcol = tid & 127;
+    const bool bok = bcol < d;
+    const int bcolc = bok ? bcol : 0;
+    const int bkg = __builtin_amdgcn_readfirstlane(tid >> 7);   // wave-uniform -> scalar row arithmetic
+    const int blds = bcol * SROW + 4 * bkg;                     // + 8 for the kh = 1 slot
+
+    const int arow = wrow0 + l32;
+    const float* a_lane = T + (int64_t)(arow < L ? arow : L - 1) * ld;
+    int boff[NCT];                         // fragment read offsets (dwords) inside a piece array, + 8 kh
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) boff[ct] = (32 * ct + l32) * SROW + 4 * kg;
+
+    const int nchunks = (L + SBK - 1) / SBK;
+    const int klast = (nchunks - 1) * SBK;
+    const int nfull = L / SBK;             // chunks whose 32 k values all lie inside the tile
+    const int limA = L - 4 * kg;           // strip column k0 + kpos is data iff k0 + kpos - 4 kg < limA
+    const int limB = bok ? L - 4 * bkg : -(1 << 30);   // threads of columns >= d stage zeros (no branch around the LDS stores)
+
+    // Software pipeline, period = one chunk C (parity P = C & 1, static after unrolling by two):
+    //   top     : issue the HBM/L2 loads of chunk C+2  -> raw set P        (unconditional, clamped: a branch
+    //             around loads makes the s_waitcnt at the join conservative and serialises the pipeline)
+    //   body    : 48 MFMAs of chunk C (pieces set P, LDS stage P), each followed by one cutting stage of chunk
+    //             C+1 (raw set P^1, loaded one period ago): B pieces -> LDS stage P^1, A pieces -> set P^1
+    //   barrier : stage P^1 complete, stage P free for chunk C+2
+    float4 araw[2][4];
+    float braw[2][2][8];
+    u32x4 ap1[2][2], ap2[2][2], ap3[2][2];     // [set][kh]
+
+    // SAFE = 0: every row / strip column the loads touch is inside the tile -> no clamps, no masks, and the
+    // addresses are (loop-invariant per-lane offset) + (scalar chunk base).  SAFE = 1: the ragged last chunk
+    // is involved (clamped addresses, out-of-range k zeroed when the values are cut).
+    int bsoff[2][8];                       // (scalar) element offsets of the 16 staged H rows inside a chunk
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsoff[e][j] = (16 * e + 4 * bkg + (j & 3) + 8 * (j >> 2)) * ldh;
+    const float* a_lane4 = a_lane + 4 * kg;
+
+#define SPLIT_ISSUE(SET, K0, SAFE)                                                                         \
+    do {                                                                                                   \
+        if (SAFE) {                                                                                        \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                  \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+                    const int k_ = (K0) + 16 * e + 4 * bkg + (j & 3) + 8 * (j >> 2);                       \
+                    const float* rowp_ = Hm + (int64_t)(k_ < L ? k_ : L - 1) * ldh;                        \
+                    braw[SET][e][j] = rowp_[bcolc];                                                        \
+                }                                                                                          \
+            _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                \
+                const int ka_ = (K0) + 8 * f + 4 * kg;                                                     \
+                araw[SET][f] = *reinterpret_cast<const float4*>(a_lane + (ka_ < ld ? ka_ : ld - 4));       \
+            }                                                                                              \
+        } else {                                                                                           \
+            const float* hb_ = Hm + (int64_t)(K0) * ldh;                                                   \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                  \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) braw[SET][e][j] = (hb_ + bsoff[e][j])[bcolc]; \
+            const float* ab_ = a_lane4 + (K0);                                                             \
+            _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                  \
+                araw[SET][f] = *reinterpret_cast<const float4*>(ab_ + 8 * f);                              \
+        }                                                                                                  \
+    } while (0)
+
+    // The cutting work of one chunk = 16 units (U 0..7: B pair (kh = U>>2, p = U&3) of this thread's staging
+    // tasks; U 8..15: A pair (kh = (U-8)>>2, p = U&3)) x 3 stages of ~5 VALU (mask + first piece, second
+    // piece, third piece).  Stage T (0..47) is issued right behind the T-th MFMA of the chunk.
+    float cx0 = 0.f, cx1 = 0.f;            // the pair in flight through the three stages
+    uint32_t himask;                       // in an SGPR: a literal operand would double the v_and encoding size
+    asm volatile("s_mov_b32 %0, 0xffff0000" : "=s"(himask));
+#define SPLIT_STAGE(SET, K0, STG, T, SAFE)                                                                     \
+    do {                                                                                                   \
+        const int u_ = (T) / 3, st_ = (T) % 3, p_ = u_ & 3, h_ = (u_ >> 2) & 1;                            \
+        const int kp_ = (K0) + 16 * h_ + 8 * (p_ >> 1) + 2 * (p_ & 1);   /* + 4 kg (folded into lim) */    \
+        if (st_ == 0) {                                                                                    \
+            if (u_ < 8) {                                                                                  \
+                cx0 = (!(SAFE) || kp_ < limB) ? braw[SET][h_][2 * p_] : 0.f;                               \
+                cx1 = (!(SAFE) || kp_ + 1 < limB) ? braw[SET][h_][2 * p_ + 1] : 0.f;                       \
+            } else {                                                                                       \
+                const float4 v_ = araw[SET][2 * h_ + (p_ >> 1)];                                           \
+                cx0 = (!(SAFE) || kp_ < limA) ? ((p_ & 1) ? v_.z : v_.x) : 0.f;                            \
+                cx1 = (!(SAFE) || kp_ + 1 < limA) ? ((p_ & 1) ? v_.w : v_.y) : 0.f;                        \
+            }                                                                                              \
+        }                                                                                                  \
+        const uint32_t w_ = __builtin_amdgcn_perm(as_u(cx1), as_u(cx0), 0x07060302u);                      \
+        if (u_ < 8) {                                                                                      \
+            if (st_ == 0) bp1[h_][p_] = w_; else if (st_ == 1) bp2[h_][p_] = w_; else bp3[h_][p_] = w_;    \
+        } else {                                                                                           \
+            if (st_ == 0) ap1[SET][h_][p_] = w_; else if (st_ == 1) ap2[SET][h_][p_] = w_; else ap3[SET][h_][p_] = w_; \
+        }                                                                                                  \
+        if (st_ < 2) {                                                                                     \
+            cx0 = cx0 - as_f(as_u(cx0) & himask);                                                          \
+            cx1 = cx1 - as_f(as_u(cx1) & himask);                                                          \
+        }                                                                                                  \
+        if (u_ < 8 && p_ == 3 && st_ == 2) {                                                               \
+            uint32_t* dst_ = smem + (STG) * stage_stride + blds + 8 * h_;                                  \
+            *reinterpret_cast<u32x4*>(dst_) = bp1[h_];                                                     \
+            *reinterpret_cast<u32x4*>(dst_ + split_stride) = bp2[h_];                                      \
+            *reinterpret_cast<u32x4*>(dst_ + 2 * split_stride) = bp3[h_];                                  \
+        }                                                                                                  \
+    } while (0)
+
+    // B fragments: bf_[column tile][piece] of ONE K=16 step, 48 registers, reloaded piece by piece as soon as a
+    // piece's last MFMA of the step has been issued (product order below), so the next step's fragments are
+    // in flight >= 12 MFMAs (384 cycles) before their first use without a second register set.
+#define SPLIT_LOADB(PIECE, STG, KH)                                                                        \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int ct_ = 0; ct_ < NCT; ++ct_)                                              \
+            bf_[ct_][PIECE] = *reinterpret_cast<const u32x4*>(smem + (STG) * stage_stride + (PIECE) * split_stride + \
+                                                              boff[ct_] + 8 * (KH));                       \
+    } while (0)
+
+    // one K=16 step: 6 piece products x 4 column tiles = 24 MFMAs, the four accumulators round-robin (a
+    // 32x32x16 MFMA's result is needed again only 4 MFMAs = 128 cycles later).  Product order
+    // a3b1 a2b1 a1b1 | a2b2 a1b2 | a1b3  frees b1, then b2, then b3 for the reload of step (NSTG, NKH).
+#define SPLIT_STEP(P, KH, NSTG, NKH, K1, SAFE)                                                             \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < 6; ++pc_) {                                              \
+            const u32x4 av_ = (pc_ == 0) ? ap3[P][KH] : (pc_ == 1 || pc_ == 3) ? ap2[P][KH] : ap1[P][KH];  \
+            const int bi_ = (pc_ < 3) ? 0 : (pc_ < 5) ? 1 : 2;                                             \
+            _Pragma("unroll") for (int ct_ = 0; ct_ < NCT; ++ct_) {                                        \
+                if (!(ABLC & 2)) acc[ct_] = mfma_bf16(av_, bf_[ct_][bi_], acc[ct_]);                       \
+                if (!(ABLC & 1)) SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 24 * (KH) + 4 * pc_ + ct_, SAFE);       \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+            if (pc_ == 2) SPLIT_LOADB(0, NSTG, NKH);                                                       \
+            if (pc_ == 4) SPLIT_LOADB(1, NSTG, NKH);                                                       \
+            if (pc_ == 5) SPLIT_LOADB(2, NSTG, NKH);                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                  \
+    } while (0)
+
+    // One barrier per chunk, in the MIDDLE: by then every wave has stored its B pieces of chunk C+1 (cutting
+    // stages 0..23) and has issued its last fragment read of chunk C (step 1's fragments are reloaded during
+    // step 0), so after it LDS stage P^1 may be read (fragments of chunk C+1, step 0) and stage P may be
+    // overwritten (chunk C+2, during the first half of the next period).
+#define SPLIT_BODY(P, C, SAFE)                                                                             \
+    do {                                                                                                   \
+        const int kn1_ = ((C) + 1) * SBK < klast ? ((C) + 1) * SBK : klast;                                \
+        const int kn2_ = ((C) + 2) * SBK < klast ? ((C) + 2) * SBK : klast;                                \
+        SPLIT_ISSUE(P, kn2_, SAFE);                                                                        \
+        __builtin_amdgcn_sched_barrier(0); /* the loads lead the period: one full chunk of MFMAs hides them */ \
+        u32x4 bp1[2], bp2[2], bp3[2];                                                                      \
+        /* one wait for the whole previous period's loads (only this period's 20 may stay in flight) */   \
+        /* instead of a decreasing vmcnt in front of every cutting stage */                               \
+        __builtin_amdgcn_s_waitcnt(0x4F74);  /* vmcnt(20) */                                               \
+        SPLIT_STEP(P, 0, P, 1, kn1_, SAFE);                                                                \
+        __syncthreads();                                                                                   \
+        SPLIT_STEP(P, 1, (P) ^ 1, 0, kn1_, SAFE);                                                          \
+    } while (0)
+
+    // chunks C+1 and C+2 (cut / loaded during chunk C) lie entirely inside the tile <=> C + 2 < nfull.
+    // (The fast body stages column 0 again in the LDS rows of columns >= d: those only feed accumulator
+    // columns >= d, which are never stored.)
+    u32x4 bf_[NCT][3];
+    {   // prologue: chunk 0 -> pieces set 0 / LDS stage 0; chunk 1 raw -> set 1
+        SPLIT_ISSUE(1, 0, 1);
+        u32x4 bp1[2], bp2[2], bp3[2];
+#pragma unroll
+        for (int t = 0; t < 48; ++t) SPLIT_STAGE(1, 0, 0, t, 1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) { ap1[0][kh] = ap1[1][kh]; ap2[0][kh] = ap2[1][kh]; ap3[0][kh] = ap3[1][kh]; }
+        SPLIT_ISSUE(1, (SBK < klast ? SBK : klast), 1);
+        __syncthreads();
+        SPLIT_LOADB(0, 0, 0);
+        SPLIT_LOADB(1, 0, 0);
+        SPLIT_LOADB(2, 0, 0);
+    }
+    {
+        int c = 0;
+        for (; c + 3 < nfull; c += 2) {        // steady state: chunks c+1 .. c+3 are full
+            SPLIT_BODY(0, c, 0);
+            SPLIT_BODY(1, c + 1, 0);
+        }
+        for (; c + 1 < nchunks; c += 2) {      // the last few chunks: clamped loads, masked cutting
+            SPLIT_BODY(0, c, 1);
+            SPLIT_BODY(1, c + 1, 1);
+        }
+        if (nchunks & 1) SPLIT_BODY(0, c, 1);
+    }
+#undef SPLIT_BODY
+#undef SPLIT_STEP
+#undef SPLIT_LOADB
+#undef SPLIT_STAGE
+#undef SPLIT_ISSUE
+
+    // ---- epilogue through LDS, OROWS rows per pass (the loop's last barrier has retired every fragment read).
+    // Four threads per output row, each owning every 4th float4 of it: the M-1 cross-modal weights of the
+    // row are loaded once per thread and all its H loads of one modality are in flight together.
+    float* Os = reinterpret_cast<float*>(smem);
+    if (abl & 32) return;
+    __syncthreads();   // the last step's (unused) fragment reloads have retired
+    constexpr int NJ = CB / 16;
+    const int cw4 = d / 4;
+    const int erow = tid >> 2;
+    const int eq = tid & 3;
+#pragma unroll
+    for (int pass = 0; pass < BM / OROWS; ++pass) {
+        if (pass) __syncthreads();
+        if ((w >> 1) == pass) {
+            const int lrow0 = WROWS * (w & 1) + 4 * kg;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Os[(lrow0 + (r & 3) + 8 * (r >> 2)) * LDO + 32 * ct + l32] = acc[ct][r];
+        }
+        __syncthreads();
+        const int row = r0 + pass * OROWS + erow;
+        if (row < L) {
+            const int64_t grow = rs + row;
+            float4 v[NJ];
+            int coff[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c4 = eq + 4 * j;
+                coff[j] = 4 * (c4 < cw4 ? c4 : cw4 - 1);
+                v[j] = *reinterpret_cast<const float4*>(&Os[erow * LDO + coff[j]]);
+            }
+            const int nq = (abl & 1) ? 0 : M - 1;
+#pragma unroll 2
+            for (int q = 0; q < nq; ++q) {
+                const int n = q + (q >= m ? 1 : 0);
+                const int pk = (m < n) ? mmdfn_pair_index(m, n, M) : mmdfn_pair_index(n, m, M);
+                const float cwt = cross[(int64_t)pk * N + grow];
+                const float* hrow = H + ((int64_t)n * N + grow) * ldh;
+                float4 h[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) h[j] = *reinterpret_cast<const float4*>(hrow + coff[j]);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    v[j].x = fmaf(cwt, h[j].x, v[j].x);
+                    v[j].y = fmaf(cwt, h[j].y, v[j].y);
+                    v[j].z = fmaf(cwt, h[j].z, v[j].z);
+                    v[j].w = fmaf(cwt, h[j].w, v[j].w);
+                }
+            }
+            float* orow = out + ((int64_t)m * N + grow) * ldo;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (eq + 4 * j < cw4) *reinterpret_cast<float4*>(orow + coff[j]) = v[j];
+        }
+    }
+}
+
+int split_ablation() {
+    const char* e = getenv("MMDFN_PROP_ABL");
+    return e ? atoi(e) : 0;
+}
+
+}  // namespace
+
+// d <= 128 only; returns -2 when the shape is not covered (caller falls back to the f32-MFMA kernel)
+int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const float* H, float* out,
+                                 const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                                 int B, int M, int N, int d, int ldh, int ldo, int max_len, hipStream_t s) {
+    if (d > 128 || (d & 3)) return -2;
+    const int max_rb = (max_len + 127) / 128;
+    const int lds_bytes = 2 * 3 * 128 * SROW * 4;   // 61440 B (>= the 64 x 136 float epilogue staging)
+    dim3 grid(((B + 7) / 8) * 8 * M * max_rb);
+    const char* ac = getenv("MMDFN_SPLIT_ABLC");  // profiling aid: compile-time ablations (1: no cutting, 2: no MFMA)
+    const int ablc = ac ? atoi(ac) : 0;
+#define SPLIT_LAUNCH(A)                                                                                          \
+    hipLaunchKernelGGL((propagate_split_kernel<A>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
+                       row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, split_ablation())
+    if (ablc == 1) SPLIT_LAUNCH(1);
+    else if (ablc == 2) SPLIT_LAUNCH(2);
+    else SPLIT_LAUNCH(0);
+#undef SPLIT_LAUNCH
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}

@@ -41,6 +41,61 @@ def test_propagate_forward_and_transpose(lengths, M, d):
     assert rel_err(out_t, dense.t() @ H) < 1e-5
 
 
+SPLIT_CASES = [
+    ([5], 3, 100),
+    ([7, 3, 1], 3, 100),
+    ([32, 33, 31, 64], 3, 100),
+    ([110, 64, 65, 27], 3, 100),
+    ([129, 127, 128, 200], 2, 128),
+    ([260, 40], 6, 64),
+    ([513], 3, 100),
+    ([9, 31], 1, 36),
+]
+
+
+@pytest.mark.parametrize("lengths,M,d", SPLIT_CASES)
+def test_propagate_bf16_piece_kernel(lengths, M, d, monkeypatch):
+    """The large-launch variant (three exact bf16 pieces per operand, six MFMA products) forced on every
+    shape: same fp32-level tolerance as the f32-MFMA kernel, ragged chunk tails, and tile padding columns
+    poisoned with NaN (they are not data and must never reach a product)."""
+    adj, dense, _, _ = random_block_adjacency(13, lengths, M, DEV)
+    lay = adj.layout
+    tiles = adj.tiles.clone()
+    for i, L in enumerate(lengths):
+        ld = int(lay.ld_host[i]); base = int(lay.tile_base_host[i])
+        if ld > L:
+            tiles[base: base + M * L * ld].view(M * L, ld)[:, L:] = float("nan")
+    rs = np.random.RandomState(7)
+    H = torch.from_numpy(rs.randn(M * sum(lengths), d).astype(np.float32))
+    monkeypatch.setenv("MMDFN_PROP_CFG", "8")
+    out = ops.propagate_raw(tiles, adj.cross, H.to(DEV), lay)
+    want = dense.double() @ H.double()
+    assert rel_err(out, want) < 1e-5
+    monkeypatch.setenv("MMDFN_PROP_CFG", "9")
+    ref = ops.propagate_raw(tiles, adj.cross, H.to(DEV), lay)
+    # both kernels sit at fp32 rounding level against the fp64 product
+    e_split = float((out.double().cpu() - want).abs().max())
+    e_f32 = float((ref.double().cpu() - want).abs().max())
+    assert e_split <= 4 * e_f32 + 1e-7
+
+
+def test_propagate_bf16_piece_kernel_is_the_large_launch_default(monkeypatch):
+    """At the long-dialogue stress shape (L=512, M=6) the dispatcher picks the bf16-piece kernel; results agree
+    with the f32-MFMA kernel to fp32 rounding."""
+    monkeypatch.delenv("MMDFN_PROP_CFG", raising=False)
+    lengths = [512] * 11 + [300]
+    M, d = 6, 100
+    rs = np.random.RandomState(8)
+    N = sum(lengths)
+    adj = ops.build_adjacency(torch.from_numpy(rs.randn(M, N, 200).astype(np.float32)).to(DEV), lengths)
+    H = torch.from_numpy(rs.randn(M * N, d).astype(np.float32)).to(DEV)
+    out = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    monkeypatch.setenv("MMDFN_PROP_CFG", "9")
+    ref = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    assert float((out - ref).abs().max()) < 2e-6
+    assert float((out - ref).abs().max()) > 0.0   # it really was a different kernel
+
+
 @pytest.mark.parametrize("lengths,M,d", CASES)
 def test_propagate_backward(lengths, M, d):
     adj, dense, tiles, cross = random_block_adjacency(12, lengths, M, DEV)
