@@ -44,6 +44,16 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(key):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_propagate_traffic.json): the counters need
+    their own rocprofv3 --pmc runs (FETCH_SIZE / WRITE_SIZE do not fit one pass), so they are not re-collected here."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_propagate_traffic.json")) as f:
+            return json.load(f)[key]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def time_propagate(adj_builder, lay_d, iters=200):
     """Average duration (ms) of one K6 propagate launch: `iters` back-to-back launches captured in a hipGraph
     (so the host is out of the picture) and bracketed by HIP events on the replay stream."""
@@ -244,7 +254,10 @@ def main():
                                                                    "value": total_utt / (adam_ms * 1e-3)},
             "roofline": {"bound": "hbm", "kernel": "propagate_kernel (K6 fwd, d=100)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3, "traffic": None},
+                         "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3,
+                         "traffic": measured_traffic("cfg2") if (a.config == "cfg2" and not a.ragged) else None,
+                         "traffic_source": "profiles/r01_propagate_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                                           "separate passes)"},
         }
         # the same kernel on BASELINE config 5 (L=512, M=6, d=100, 32 dialogues), where one launch moves 282 MB and
         # the launch-latency floor no longer hides the kernel (the >=40 % HBM target is a cfg5 property)
@@ -259,11 +272,13 @@ def main():
             ms5 = time_propagate(mk5, d, iters=20)
             lay5 = ops.DialogueLayout.get(l5, 6, dev)
             b5 = lay5.propagate_bytes(d)
-            out["roofline_cfg5"] = {"workload": "cfg5: B=32, L=512, M=6, d=100", "bound": "hbm (MFMA-bound at 47 %)",
+            out["roofline_cfg5"] = {"workload": "cfg5: B=32, L=512, M=6, d=100", "bound": "hbm",
+                                    "kernel": "propagate_split_kernel (K6 fwd, bf16-piece MFMA, fp32-level error)",
+                                    "traffic": measured_traffic("cfg5_b32"),
                                     "achieved": b5 / (ms5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b5,
                                     "avg_launch_us": ms5 * 1e3,
-                                    "f32_mfma_tflops": lay5.propagate_flops(d) / (ms5 * 1e-3) / 1e12}
+                                    "useful_tflops": lay5.propagate_flops(d) / (ms5 * 1e-3) / 1e12}
             del f5
         except Exception as exc:
             print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
