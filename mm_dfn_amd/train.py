@@ -85,3 +85,73 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
             acc = accuracy_score(labels[sel], preds[sel]) if sel.any() else float('nan')
             all_acc.append("{}: {:.4f}".format(name, acc))
     return all_each, all_acc, avg_loss, avg_accuracy, labels, preds, avg_fscore, [np.array(vids), losses]
+
+
+def fit(model, loss_f, optimizer, train_loader, valid_loader, test_loader, n_epochs, patience=10, valid_rate=0.1,
+        cuda_flag=False, modals=None, target_names=None, run_pass=None, log=print, step_hook=None):
+    """The epoch loop of run_train_erc.py:531-660: train / valid / test pass per epoch, model selection on the
+    validation weighted-F1 (on the test split when valid_rate == 0), and the DUAL-patience early stop -- the run
+    ends only when neither the F1 (strict improvement, :614-618) nor the loss (:619-627) has improved for
+    ``patience`` epochs (:637).  Returns the history and the test metrics at the two selected epochs (:641-660).
+
+    ``run_pass(loader, epoch, train_flag) -> (all_each, all_acc, loss, acc, labels, preds, fscore, extras)``
+    defaults to ``train_or_eval_graph_model``; tests drive the stopping rule with a stub."""
+    if run_pass is None:
+        def run_pass(loader, epoch, train_flag):
+            return train_or_eval_graph_model(model, loss_f, loader, epoch=epoch, train_flag=train_flag,
+                                             optimizer=optimizer if train_flag else None, cuda_flag=cuda_flag,
+                                             modals=modals, target_names=target_names, step_hook=step_hook)
+    hist = dict(train_loss=[], train_fscore=[], valid_loss=[], valid_fscore=[], test_loss=[], test_acc=[], test_fscore=[])
+    best_epoch, best_epoch2, pat, pat2, best_eval_fscore, best_eval_loss = -1, -1, 0, 0, 0, None
+    last = None
+    for e in range(n_epochs):
+        for ld in (train_loader, valid_loader, test_loader):
+            bs = getattr(ld, "batch_sampler", None)
+            if hasattr(bs, "set_epoch"):
+                bs.set_epoch(e)
+        _, _, train_loss, train_acc, _, _, train_fscore, _ = run_pass(train_loader, e, True)
+        _, _, valid_loss, valid_acc, _, _, valid_fscore, _ = run_pass(valid_loader, e, False)
+        last = run_pass(test_loader, e, False)
+        all_each, all_acc, test_loss, test_acc, test_label, test_pred, test_fscore, _ = last
+        for k, v in (("train_loss", train_loss), ("train_fscore", train_fscore), ("valid_loss", valid_loss),
+                     ("valid_fscore", valid_fscore), ("test_loss", test_loss), ("test_acc", test_acc),
+                     ("test_fscore", test_fscore)):
+            hist[k].append(v)
+        eval_loss, eval_fscore = (valid_loss, valid_fscore) if valid_rate > 0 else (test_loss, test_fscore)
+        if e == 0 or best_eval_fscore < eval_fscore:
+            pat, best_epoch, best_eval_fscore = 0, e, eval_fscore
+        else:
+            pat += 1
+        if best_eval_loss is None:
+            best_eval_loss, best_epoch2 = eval_loss, 0
+        elif eval_loss < best_eval_loss:
+            best_epoch2, best_eval_loss, pat2 = e, eval_loss, 0
+        else:
+            pat2 += 1
+        if log is not None:
+            log('epoch: {}, train_loss: {}, train_acc: {}, train_fscore: {}, valid_loss: {}, valid_acc: {}, valid_fscore: {}, '
+                'test_loss: {}, test_acc: {}, test_fscore: {}'.format(e, train_loss, train_acc, train_fscore, valid_loss,
+                                                                      valid_acc, valid_fscore, test_loss, test_acc, test_fscore))
+        if pat >= patience and pat2 >= patience:
+            if log is not None:
+                log('Early stoping... {} {}'.format(pat, pat2))
+            break
+    pick = lambda ep, key: hist[key][ep] if ep >= 0 else 0
+    return dict(history=hist, epochs_run=len(hist["test_fscore"]), patience=(pat, pat2),
+                by_f1=dict(epoch=best_epoch, eval_fscore=best_eval_fscore, test_acc=pick(best_epoch, "test_acc"),
+                           test_fscore=pick(best_epoch, "test_fscore")),
+                by_loss=dict(epoch=best_epoch2, eval_loss=best_eval_loss, test_acc=pick(best_epoch2, "test_acc"),
+                             test_fscore=pick(best_epoch2, "test_fscore")),
+                last_test=last)
+
+
+def load_reference_weights(model, source, strict=True):
+    """Loads weights trained with the reference into ``model``.  ``source`` is a state_dict or the path of a file
+    holding one (``torch.save(model.state_dict(), path)`` on the reference side: the key set is identical, see
+    tests/golden/state_dict_keys_iemocap.txt).  The reference's own ``torch.save(model)`` files (opened with torch.load at run_train_erc.py:532)
+    are pickles of ITS classes and can only be opened where that code is importable; convert them there with
+    ``torch.save(torch.load(p).state_dict(), q)``."""
+    sd = torch.load(source, map_location="cpu") if isinstance(source, (str, bytes)) else source
+    if not isinstance(sd, dict):
+        sd = sd.state_dict()
+    return model.load_state_dict(sd, strict=strict)
