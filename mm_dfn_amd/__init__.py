@@ -6,7 +6,7 @@ FocalLoss (loss.py) whose compute is hand-written HIP behind a C ABI
 (include/mmdfn_hip.h).  See DESIGN.md.
 """
 from .layout import DialogueLayout, BlockTileAdjacency  # noqa: F401
-from .graph_conv import GraphConvolution, GCNII_lyc  # noqa: F401
+from .graph_conv import GraphConvolution, GCNII_lyc, GCNII  # noqa: F401
 from .mm_gcn import MM_GCN  # noqa: F401
 from .dialogue_model import DialogueGNNModel  # noqa: F401
 from .loss import FocalLoss  # noqa: F401

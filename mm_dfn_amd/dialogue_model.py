@@ -23,6 +23,7 @@ import torch.nn.functional as F
 from . import gru as fused_gru
 from . import ops
 from .fusion import MFN, MMGatedAttention
+from .graph_conv import GCNII
 from .mm_gcn import MM_GCN
 
 _FLAT_CACHE = {}
@@ -85,12 +86,14 @@ class DialogueGNNModel(nn.Module):
                  dataset='IEMOCAP', use_speaker=True, use_modal=False, reason_flag=False, multi_modal=True,
                  use_crn_speaker=False, speaker_weights='1-1-1', modal_weight=1.0):
         super().__init__()
-        if base_model != 'LSTM' or not multi_modal or graph_type != 'GDF':
-            raise NotImplementedError("mm_dfn_amd implements the MM-DFN hot path only: base_model='LSTM', "
-                                      "multi_modal=True, graph_type='GDF' (got %r, %r, %r)"
+        if base_model != 'LSTM' or not multi_modal or graph_type not in ('GDF', 'DeepGCN'):
+            raise NotImplementedError("mm_dfn_amd implements the MM-DFN hot path (graph_type='GDF') and its unimodal-graph "
+                                      "sibling 'DeepGCN' only, with base_model='LSTM', multi_modal=True (got %r, %r, %r)"
                                       % (base_model, multi_modal, graph_type))
-        if att_type not in ('concat_subsequently', 'mfn'):
+        if graph_type == 'GDF' and att_type not in ('concat_subsequently', 'mfn'):
             raise NotImplementedError("att_type must be 'concat_subsequently' (the MM-DFN scripts) or 'mfn'")
+        if graph_type == 'DeepGCN' and att_type not in ('concat_subsequently', 'gated'):
+            raise NotImplementedError("DeepGCN: att_type must be 'concat_subsequently' or 'gated'")
         if av_using_lstm:
             raise NotImplementedError("av_using_lstm=True is not part of the MM-DFN configuration")
         if sorted(modals) != ['a', 'l', 'v']:
@@ -128,16 +131,25 @@ class DialogueGNNModel(nn.Module):
         self.rnn_parties = nn.GRU(input_size=hidden, hidden_size=D_e, num_layers=2, bidirectional=True,
                                   dropout=dropout)
         self.att_model = _EdgeAttentionParams(hidden, max_seq_len)
-        self.graph_model = MM_GCN(a_dim=hidden, v_dim=hidden, l_dim=hidden, n_dim=hidden, nlayers=Deep_GCN_nlayers,
-                                  nhidden=graph_hidden_size, nclass=n_classes, dropout=dropout, lamda=lamda,
-                                  alpha=alpha, variant=True, return_feature=True, use_residue=use_residue,
-                                  n_speakers=n_speakers, modals=self.modals, use_speaker=use_speaker,
-                                  use_modal=use_modal, reason_flag=reason_flag, modal_weight=modal_weight)
+        if graph_type == 'DeepGCN':
+            # one unimodal GCNII per modality, lamda / alpha hard-wired (model.py:922-941)
+            mk = lambda: GCNII(nfeat=hidden, nlayers=Deep_GCN_nlayers, nhidden=graph_hidden_size, nclass=n_classes,
+                               dropout=dropout, lamda=0.5, alpha=0.1, variant=True, return_feature=True,
+                               use_residue=use_residue, reason_flag=reason_flag)
+            self.graph_net_a, self.graph_net_v, self.graph_net_l = mk(), mk(), mk()
+        else:
+            self.graph_model = MM_GCN(a_dim=hidden, v_dim=hidden, l_dim=hidden, n_dim=hidden, nlayers=Deep_GCN_nlayers,
+                                      nhidden=graph_hidden_size, nclass=n_classes, dropout=dropout, lamda=lamda,
+                                      alpha=alpha, variant=True, return_feature=True, use_residue=use_residue,
+                                      n_speakers=n_speakers, modals=self.modals, use_speaker=use_speaker,
+                                      use_modal=use_modal, reason_flag=reason_flag, modal_weight=modal_weight)
         self.gatedatt = MMGatedAttention(hidden + graph_hidden_size, graph_hidden_size, att_type='general')
         self.dropout_ = nn.Dropout(dropout)
         if att_type == 'mfn':
             self.mfn = MFN()                                      # model.py:991-994
             self.smax_fc = nn.Linear(400, n_classes)
+        elif att_type == 'gated':
+            self.smax_fc = nn.Linear(100 * len(self.modals), n_classes)   # model.py:985-989 (three modalities)
         else:
             width = (hidden + graph_hidden_size) if use_residue else graph_hidden_size
             self.smax_fc = nn.Linear(width * len(self.modals), n_classes)
@@ -218,6 +230,16 @@ class DialogueGNNModel(nn.Module):
         if U_a is None or U_v is None:
             raise ValueError("the trimodal GDF path needs U_a and U_v")
         feats = self.encode(U, qmask, seq_lengths, U_a, U_v)
+        if self.graph_type == 'DeepGCN':
+            # model.py:1242-1290: three independent unimodal graphs, fused after the graph stage;
+            # NB dropout THEN ReLU on the fused features, as in the GDF head
+            ea = self.graph_net_a(feats[0], seq_lengths, qmask)
+            ev = self.graph_net_v(feats[1], seq_lengths, qmask)
+            el = self.graph_net_l(feats[2], seq_lengths, qmask)
+            fused = (self.gatedatt(ea, ev, el, self.modals) if self.att_type == 'gated'
+                     else torch.cat([ea, ev, el], dim=-1))
+            z = F.relu(self.dropout_(fused))
+            return F.log_softmax(ops.linear(z, self.smax_fc.weight, self.smax_fc.bias), 1), None, None, None, None
         fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label)
         if self.att_type == 'mfn':
             # re-pad (N, 900) -> (L, B, 900), memory fusion over time, strip again (model.py:1303-1326)

@@ -85,6 +85,11 @@ class GCNII_lyc(nn.Module):
         fused = isinstance(adj, BlockTileAdjacency) and all(c.variant and not c.residual for c in self.convs)
         return self._forward_fused(x, adj) if fused else self._forward_generic(x, adj)
 
+    # where the reference applies dropout around the layer loop: GCNII_lyc after every layer (model_GCN.py:470),
+    # GCNII once after the loop (model_GCN.py:273-278, the per-layer call is commented out there)
+    inner_dropout = True
+    final_dropout = False
+
     def _dropout_mask(self, like):
         """Keep-mask already scaled by 1/(1-p) (one launch), or None when dropout is inactive."""
         if not self.training or self.dropout <= 0:
@@ -112,7 +117,10 @@ class GCNII_lyc(nn.Module):
             theta = math.log(self.lamda / (i + 1) + 1)
             S2 = ops.propagate_concat(adj, cur, h0)
             P = ops.matmul_kn(S2, con.weight)
-            cur = ops.gcnii_combine(P, S2, q if self.reason_flag else None, self._dropout_mask(P), theta, self.alpha)
+            cur = ops.gcnii_combine(P, S2, q if self.reason_flag else None,
+                                    self._dropout_mask(P) if self.inner_dropout else None, theta, self.alpha)
+        if self.final_dropout:
+            cur = F.dropout(cur, self.dropout, training=self.training)
         if self.use_residue:
             cur = torch.cat([x, cur], dim=-1)
         if not self.return_feature:
@@ -132,11 +140,36 @@ class GCNII_lyc(nn.Module):
                 h, c = self._gate(q, h, c)
                 cur = h
             cur = self.act_fn(con(cur, adj, h0, self.lamda, self.alpha, i + 1))
-            cur = F.dropout(cur, self.dropout, training=self.training)
+            if self.inner_dropout:
+                cur = F.dropout(cur, self.dropout, training=self.training)
             if self.reason_flag:
                 cur = cur + q
+        if self.final_dropout:
+            cur = F.dropout(cur, self.dropout, training=self.training)
         if self.use_residue:
             cur = torch.cat([x, cur], dim=-1)
         if not self.return_feature:
             cur = F.log_softmax(self.fcs[-1](cur), dim=1)
         return cur
+
+
+class GCNII(GCNII_lyc):
+    """The unimodal sibling used by graph_type='DeepGCN' (reference model_GCN.py:224-310): same layer stack and
+    LSTM-cell gate as GCNII_lyc, but it builds its own single-modality adjacency from the node features
+    (create_big_adj, :288-310 -- the M = 1 case of the block-tile builder: one cosine/arccos tile per dialogue, no
+    cross-modal diagonals, D^-1/2 A D^-1/2) and applies dropout once after the layer loop instead of per layer."""
+    inner_dropout = False
+    final_dropout = True
+
+    def create_big_adj(self, x, dia_len):
+        return ops.build_adjacency(x.unsqueeze(0), [int(n) for n in dia_len])
+
+    def forward(self, x, dia_len, qmask=None):
+        if self.new_graph:
+            raise NotImplementedError("GCNII(new_graph=True) (speaker-directed message passing, model_GCN.py:312-411) "
+                                      "is outside the MM-DFN hot path")
+        _hip.require_cuda(x)
+        adj = self.create_big_adj(x, dia_len)
+        x = adj.stacked_feats[0]            # the tensor the adjacency gradient flows back through
+        fused = all(c.variant and not c.residual for c in self.convs)
+        return self._forward_fused(x, adj) if fused else self._forward_generic(x, adj.to_dense())

@@ -292,6 +292,51 @@ def gcnii_stack(x, adj, params, prefix, nlayers, lamda, alpha, dropout=0.0, trai
     return torch.cat([x, cur], -1) if use_residue else cur
 
 
+def gcnii_deep(x, dia_len, params, prefix, nlayers, lamda=0.5, alpha=0.1, dropout=0.0, training=False,
+               reason_flag=True, use_residue=True):
+    """GCNII.forward (model_GCN.py:258-286): unimodal adjacency from x itself (create_big_adj :288-310 = the M = 1
+    case), no dropout inside the layer loop (commented out at :275), one dropout after it (:279)."""
+    adj = create_big_adj([x], dia_len)
+    x = F.dropout(x, dropout, training)
+    h0 = torch.relu(F.linear(x, params[prefix + "fcs.0.weight"], params[prefix + "fcs.0.bias"]))
+    cur = F.dropout(h0, dropout, training)
+    h = torch.zeros_like(cur)
+    c = torch.zeros_like(cur)
+    for i in range(nlayers):
+        q = cur
+        if reason_flag:
+            h, c = lstm_cell(q, h, c, params[prefix + "rnn.weight_ih_l0"], params[prefix + "rnn.weight_hh_l0"],
+                             params[prefix + "rnn.bias_ih_l0"], params[prefix + "rnn.bias_hh_l0"])
+            cur = h
+        cur = torch.relu(graph_convolution(cur, adj, h0, lamda, alpha, i + 1, params[prefix + "convs.%d.weight" % i]))
+        if reason_flag:
+            cur = cur + q
+    cur = F.dropout(cur, dropout, training)
+    return torch.cat([x, cur], -1) if use_residue else cur
+
+
+def gated_attention_general(a, v, l, params, prefix="gatedatt."):
+    """MMGatedAttention.forward, att_type='general', three modalities, eval (model.py:761-781)."""
+    lin = lambda name, t: F.linear(t, params[prefix + name + ".weight"], params.get(prefix + name + ".bias"))
+    ha, hv, hl = torch.tanh(lin("transform_a", a)), torch.tanh(lin("transform_v", v)), torch.tanh(lin("transform_l", l))
+    z_av = torch.sigmoid(lin("transform_av", torch.cat([a, v, a * v], -1)))
+    z_al = torch.sigmoid(lin("transform_al", torch.cat([a, l, a * l], -1)))
+    z_vl = torch.sigmoid(lin("transform_vl", torch.cat([v, l, v * l], -1)))
+    return torch.cat([z_av * ha + (1 - z_av) * hv, z_al * ha + (1 - z_al) * hl, z_vl * hv + (1 - z_vl) * hl], -1)
+
+
+def forward_deepgcn(params, U, qmask, umask, lengths, U_a, U_v, cfg, training=False, engine="manual",
+                    att_type="concat_subsequently"):
+    """DialogueGNNModel.forward for graph_type='DeepGCN', multi_modal (model.py:1242-1290): the MM-DFN encoders,
+    one unimodal GCNII per modality (lamda 0.5, alpha 0.1 hard-wired at :927-939), fusion, dropout, ReLU, head.
+    att_type='gated' is restated for eval only (the module's own input dropout is inactive)."""
+    feats = encoders(params, U, qmask, lengths, U_a, U_v, cfg, training, engine)
+    e = [gcnii_deep(f, lengths, params, "graph_net_%s." % k, cfg["nlayers"], 0.5, 0.1, cfg.get("dropout", 0.0), training,
+                    cfg.get("reason_flag", True)) for f, k in zip(feats, "avl")]
+    fused = gated_attention_general(e[0], e[1], e[2], params) if att_type == "gated" else torch.cat(e, -1)
+    return head(fused, params, cfg.get("dropout", 0.0), training)
+
+
 def mm_gcn(feats, dia_len, params, cfg, training=False):
     """MM_GCN.forward, use_speaker/use_modal off (model_mm.py:77-120)."""
     adj = create_big_adj(feats, dia_len, cfg.get("modal_weight", 1.0))

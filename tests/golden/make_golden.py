@@ -209,6 +209,48 @@ def export_fusion_modules():
     print("fusion modules ok")
 
 
+def export_deepgcn():
+    """Sibling graph type 'DeepGCN' (model.py:922-941, 1242-1290): eval log-probs for both fusions the build supports,
+    and gradients of sum(logp * R) in train() with dropout 1e-12 (see module docstring)."""
+    _, _, _, _ = ref_shim.modules()
+    out = {}
+    cfg = dict(B=3, L=14, P=2, C=6, nlayers=3, D_t=100, D_a=100, D_v=512)
+    lengths = [14, 5, 9]
+    batch = synthetic.make_batch(801, lengths=lengths, **cfg)
+    args = (batch["textf"], batch["qmask"], batch["umask"], batch["lengths"], batch["acouf"], batch["visuf"])
+    for att in ("concat_subsequently", "gated"):
+        build = lambda p, rf=True: ref_shim.build_reference_model(cfg["D_t"], cfg["D_a"], cfg["D_v"], cfg["P"], cfg["C"],
+                                                                  cfg["nlayers"], dropout=p, graph_type="DeepGCN",
+                                                                  att_type=att, reason_flag=rf)
+        m = build(0.0)
+        sd = synthetic.seeded_state_dict(m.state_dict(), 800)
+        m.load_state_dict(sd)
+        m.eval()
+        with torch.no_grad():
+            out["logp_" + att] = m(*args)[0].numpy()
+        if att == "concat_subsequently":
+            with open(os.path.join(HERE, "state_dict_keys_deepgcn.txt"), "w") as fh:
+                fh.write("\n".join("%s %s" % (k, "x".join(map(str, v.shape))) for k, v in m.state_dict().items()) + "\n")
+            # gradients with reason_flag=False: with the gate on, the reference's own backward fails in every mode
+            # ("layer_inner += q" (model_GCN.py:277) overwrites the ReLU output autograd saved; GCNII has no
+            # dropout between the two that would make a fresh tensor, unlike GCNII_lyc)
+            mt = build(TINY, False)
+            mt.load_state_dict(sd)
+            mt.eval()
+            with torch.no_grad():
+                out["logp_nogate"] = mt(*args)[0].numpy()
+            mt.train()
+            logp = mt(*args)[0]
+            R = torch.from_numpy(np.random.RandomState(802).randn(*logp.shape).astype(np.float32))
+            (logp * R).sum().backward()
+            named = dict(mt.named_parameters())
+            for k in ("linear_a.weight", "rnn_parties.weight_hh_l0", "graph_net_a.convs.2.weight", "graph_net_v.fcs.0.weight",
+                      "graph_net_l.convs.0.weight", "smax_fc.weight"):
+                out["grad_" + k] = named[k].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "deepgcn.npz"), **out)
+    print("deepgcn ok")
+
+
 def export_state_keys():
     m = ref_shim.build_reference_model(100, 1582, 342, 2, 6, 2)
     keys = ["%s %s" % (k, "x".join(map(str, v.shape))) for k, v in m.state_dict().items()]
@@ -221,6 +263,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     export_state_keys()
     export_fusion_modules()
+    export_deepgcn()
     export_focal()
     export_adjacency()
     export_gcnii()

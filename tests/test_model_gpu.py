@@ -214,3 +214,43 @@ def test_fused_flat_adam_matches_torch_adam_and_reference_trace():
     # untouched parameters (no gradient on this path) stay bit-identical to their initial values
     init = synthetic.seeded_state_dict(m_fus.state_dict(), 500)
     assert abs_err(m_fus.gatedatt.transform_l.weight, init["gatedatt.transform_l.weight"]) == 0.0
+
+
+def test_deepgcn_sibling_against_reference_golden_and_oracle():
+    """graph_type='DeepGCN' on the HIP kernels (M = 1 adjacency tiles, same layer kernels): reference goldens for
+    the eval log-probs of both fusions and the gate-less gradients; the gated gradients against the oracle
+    (the reference itself cannot back-propagate them)."""
+    from test_oracle_golden import DEEP_CFG, DEEP_LENGTHS, deep_state
+    g = load("deepgcn.npz")
+    b = synthetic.make_batch(801, lengths=DEEP_LENGTHS, **DEEP_CFG)
+    for att in ("concat_subsequently", "gated"):
+        m, sd = deep_state(att)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            assert np.abs(run(m, b).cpu().numpy() - g["logp_" + att]).max() < 1e-4, att
+    R = torch.from_numpy(np.random.RandomState(802).randn(*g["logp_nogate"].shape).astype(np.float32))
+    m, sd = deep_state(reason_flag=False)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    logp = run(m, b)
+    assert np.abs(logp.detach().cpu().numpy() - g["logp_nogate"]).max() < 1e-4
+    (logp * R.to(DEV)).sum().backward()
+    named = dict(m.named_parameters())
+    for k in [f[5:] for f in g.files if f.startswith("grad_")]:
+        assert rel_err(named[k].grad, torch.from_numpy(g["grad_" + k])) < 5e-4, k
+    # gate on: oracle autograd (functional restatement, no in-place update) is the checker
+    m, sd = deep_state()
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    logp = run(m, b)
+    (logp * R.to(DEV)).sum().backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want = O.forward_deepgcn(params, b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"],
+                             O.default_cfg(DEEP_CFG["nlayers"]), engine="aten")
+    (want * R).sum().backward()
+    assert abs_err(logp, want) < 1e-4
+    named = dict(m.named_parameters())
+    for k in ("linear_l.weight", "lstm_l.weight_hh_l0", "graph_net_a.rnn.weight_hh_l0", "graph_net_l.convs.1.weight",
+              "graph_net_v.fcs.0.bias", "smax_fc.weight"):
+        assert rel_err(named[k].grad, params[k].grad) < 5e-4, k

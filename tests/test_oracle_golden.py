@@ -138,3 +138,42 @@ def test_three_step_training_trace():
     assert (np.concatenate(preds) == g["preds"]).mean() > 0.99
     assert np.abs(params["smax_fc.weight"].detach().numpy() - g["smax_fc.weight"]).max() < 1e-5
     assert np.abs(params["graph_model.graph_net.convs.1.weight"].detach().numpy() - g["convs1"]).max() < 1e-5
+
+
+DEEP_CFG = dict(B=3, L=14, P=2, C=6, nlayers=3, D_t=100, D_a=100, D_v=512)
+DEEP_LENGTHS = [14, 5, 9]
+
+
+def deep_state(att_type="concat_subsequently", reason_flag=True):
+    m = synthetic.build_model(graph_type="DeepGCN", att_type=att_type, reason_flag=reason_flag, **DEEP_CFG)
+    return m, synthetic.seeded_state_dict(m.state_dict(), 800)
+
+
+def test_deepgcn_state_dict_keys_match_reference():
+    m, _ = deep_state()
+    want = open(os.path.join(GOLD, "state_dict_keys_deepgcn.txt")).read().split("\n")[:-1]
+    got = ["%s %s" % (k, "x".join(map(str, v.shape))) for k, v in m.state_dict().items()]
+    assert sorted(got) == sorted(want)
+
+
+def test_deepgcn_oracle_against_reference_golden():
+    """graph_type='DeepGCN' (three unimodal GCNII graphs) -- eval log-probs for both fusions, and the
+    gradients of the gate-less variant (the reference cannot back-propagate the gated one, see make_golden.py)."""
+    g = load("deepgcn.npz")
+    b = synthetic.make_batch(801, lengths=DEEP_LENGTHS, **DEEP_CFG)
+    args = (b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])
+    cfg = O.default_cfg(DEEP_CFG["nlayers"])
+    for att in ("concat_subsequently", "gated"):
+        _, sd = deep_state(att)
+        with torch.no_grad():
+            logp = O.forward_deepgcn(sd, *args, cfg, att_type=att)
+        assert np.abs(logp.numpy() - g["logp_" + att]).max() < 2e-5, att
+    _, sd = deep_state()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    logp = O.forward_deepgcn(params, *args, dict(cfg, reason_flag=False))
+    assert np.abs(logp.detach().numpy() - g["logp_nogate"]).max() < 2e-5
+    R = torch.from_numpy(np.random.RandomState(802).randn(*logp.shape).astype(np.float32))
+    (logp * R).sum().backward()
+    for k in [f[5:] for f in g.files if f.startswith("grad_")]:
+        want = g["grad_" + k]
+        assert np.abs(params[k].grad.numpy() - want).max() / np.abs(want).max() < 2e-4, k
