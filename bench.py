@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs (cfg2 ragged, cfg3, cfg4 shard)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
@@ -80,6 +81,44 @@ def time_propagate(adj_builder, lay_d, iters=200, warm_replays=10, timed_replays
     e1.record(s)
     e1.synchronize()
     return e0.elapsed_time(e1) / (iters * timed_replays)
+
+
+def quick_leg(cfgname, ragged, dropout, steps=12, warmup=4):
+    """One more workload through the same captured step (SURVEY 8d asks for cfg2 ragged, cfg3 and the cfg4 shard
+    next to the headline): returns {utterances_per_s, ms_per_step, ...}.  Single GPU, fewer steps, not the headline."""
+    from mm_dfn_amd import FocalLoss, synthetic, train
+    from mm_dfn_amd.graphs import CapturedStep
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(synthetic.CONFIGS[cfgname])
+    model = synthetic.build_model(dropout=dropout, **cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
+    model = model.to(dev).train()
+    batch = synthetic.make_batch(2021, ragged=ragged, device=dev, **cfg)
+    lengths = batch["lengths"]
+    label = train.flatten_labels(batch["label"], lengths)
+    loss_f = FocalLoss(gamma=0.5)
+
+    def fwd_bwd():
+        logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
+        loss = loss_f(logp, label)
+        loss.backward()
+        return loss
+
+    cap = CapturedStep(model, fwd_bwd, warmup=2)
+    for _ in range(warmup):
+        cap.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cap.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n = sum(lengths)
+    return {"workload": "%s%s: B=%d, L<=%d, P=%d, %d GCN layers, dims %d/%d/%d" % (
+                cfgname, " ragged" if ragged else "", cfg["B"], cfg["L"], cfg["P"], cfg["nlayers"], cfg["D_t"], cfg["D_a"],
+                cfg["D_v"]),
+            "utterances": n, "padded_rows": max(lengths) * len(lengths), "ms_per_step": dt * 1e3,
+            "utterances_per_s": n / dt, "steps": steps}
 
 
 def cpu_baseline(cfg, batch, state, threads, budget_s=20.0):
@@ -286,6 +325,13 @@ def main():
             del f5
         except Exception as exc:
             print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
+        if world == 1 and not a.no_extra:
+            out["other_workloads"] = []
+            for cname, rag in (("cfg2", True), ("cfg3", True), ("cfg4", False), ("cfg4", True)):
+                try:
+                    out["other_workloads"].append(quick_leg(cname, rag, a.dropout))
+                except Exception as exc:
+                    print("[bench] extra workload %s skipped: %s" % (cname, exc), file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads)
         print(json.dumps(out), flush=True)
