@@ -195,6 +195,21 @@ int mmdfn_gemm_tn(const float* A, const float* B, float* C, float* colsum, float
                   int R, int M, int N, int lda, int ldb, int ldc, int splits, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * The same contraction for up to 8 independent problems in ONE launch pair, with an optional row shift on B:
+ *   C_p[m, n] = sum_r A_p[r, m] * B_p[r + bshift_p, n]     (rows of B_p outside [0, R_p) count as zero)
+ *   colsum_p[m] = sum_r A_p[r, m]                           (colsum may be NULL, or an array with NULL entries)
+ * Replaces the recurrent-weight gradients of nn.GRU on the path (autograd of model.py:866,868: for every GRU,
+ * layer and direction dW_hh = sum_t dgh_t (x) h_{t-1}, db_hh = sum_t dgh_t): h_{t-1} is the output sequence
+ * shifted by one time step (bshift = -rows_per_step forward, +rows_per_step reverse), and with the shift inside
+ * the kernel A spans every row so its column sums are the full bias gradient.  A, B, C, colsum, R .. bshift are
+ * HOST arrays of length n (device pointers / ints).  workspace: mmdfn_gemm_tn_grouped_workspace(n, R, M, N) floats.
+ * ------------------------------------------------------------------------- */
+int64_t mmdfn_gemm_tn_grouped_workspace(int n, const int* R, const int* M, const int* N);
+int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, float* const* C, float* const* colsum,
+                          const int* R, const int* M, const int* N, const int* lda, const int* ldb, const int* ldc,
+                          const int* bshift, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Fused Adam step over flat fp32 buffers (replaces torch.optim.Adam(lr, weight_decay=l2).step(),
  * run_train_erc.py:512,212): L2 folded into the gradient, bias-corrected, `step` = 1, 2, ...
  * p, m, v updated in place; n elements (16-byte aligned buffers).

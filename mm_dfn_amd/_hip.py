@@ -33,6 +33,8 @@ SIGNATURES = {
     "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_gemm_tn_splits": [_I, _I, _I],
     "mmdfn_gemm_tn": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_gemm_tn_grouped_workspace": [_I, _P, _P, _P],
+    "mmdfn_gemm_tn_grouped": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "mmdfn_party_gather": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -69,7 +71,7 @@ def lib():
         except AttributeError as e:
             raise HipLibraryError("libmmdfn_hip.so lacks symbol %s (stale build?)" % name) from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name.endswith("_workspace") else ctypes.c_int
     if handle.mmdfn_abi_version() != ABI_VERSION:
         raise HipLibraryError("libmmdfn_hip.so ABI version mismatch")
     _lib = handle

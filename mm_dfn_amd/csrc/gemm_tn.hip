@@ -19,15 +19,18 @@ constexpr int TM = 64, TN = 64; // output tile per workgroup
 constexpr int LDA = TM + 4;     // = 4 (mod 8)
 constexpr int LDB = TN + 4;
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                      float* __restrict__ part, float* __restrict__ colpart,
-                                                      int R, int M, int N, int lda, int ldb, int rows_per_split) {
+// One workgroup: output tile `tile` of split `split`.  B is read at row r + bshift (rows outside [0, R) count as
+// zero): the recurrent-weight gradient  dW_hh = sum_t dgh_t (x) h_{t-1}  pairs row t of dgh with row t-1 (forward
+// direction) or t+1 (reverse) of the output sequence, and with the shift inside the kernel A still covers every row,
+// so its column sums are the complete bias gradient.
+__device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const float* __restrict__ B,
+                                             float* __restrict__ part, float* __restrict__ colpart, int R, int M, int N,
+                                             int lda, int ldb, int rows_per_split, int bshift, int tile, int split) {
     __shared__ __attribute__((aligned(16))) float As[2][BR * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BR * LDB];
     const int nbn = (N + TN - 1) / TN;
-    const int bm = blockIdx.x / nbn;
-    const int bn = blockIdx.x - bm * nbn;
-    const int split = blockIdx.y;
+    const int bm = tile / nbn;
+    const int bn = tile - bm * nbn;
     const int r_begin = split * rows_per_split;
     const int r_end = min(R, r_begin + rows_per_split);
     const int m0 = bm * TM, n0 = bn * TN;
@@ -56,9 +59,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         for (int e = 0; e < 2; ++e) {
             const int r = r0 + s_r[e];
             const int rc = r < r_end ? r : r_end - 1;
+            const int rbs = rc + bshift;
+            const int rbc = rbs < 0 ? 0 : (rbs < R ? rbs : R - 1);
             const int ca = m0 + s_c[e], cb = n0 + s_c[e];
             ra[e] = *reinterpret_cast<const float4*>(A + (int64_t)rc * lda + (ca < M ? ca : 0));
-            rb[e] = *reinterpret_cast<const float4*>(B + (int64_t)rc * ldb + (cb < N ? cb : 0));
+            rb[e] = *reinterpret_cast<const float4*>(B + (int64_t)rbc * ldb + (cb < N ? cb : 0));
         }
     };
     const int nchunks = (r_end - r_begin + BR - 1) / BR;
@@ -70,7 +75,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const bool rok = (r0 + s_r[e]) < r_end;
-            const bool aok = rok && (m0 + s_c[e] < M), bok = rok && (n0 + s_c[e] < N);
+            const int rbs = r0 + s_r[e] + bshift;
+            const bool aok = rok && (m0 + s_c[e] < M), bok = rok && (n0 + s_c[e] < N) && rbs >= 0 && rbs < R;
             // M, N are multiples of 4 (checked by the launcher), so a float4 is fully inside or outside
             *reinterpret_cast<float4*>(&as[s_r[e] * LDA + s_c[e]]) =
                 make_float4(aok ? ra[e].x : 0.f, aok ? ra[e].y : 0.f, aok ? ra[e].z : 0.f, aok ? ra[e].w : 0.f);
@@ -122,12 +128,43 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ colpart,
-                                      float* __restrict__ C, float* __restrict__ colsum, int M, int N, int ldc,
-                                      int splits) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ part, float* __restrict__ colpart,
+                                                      int R, int M, int N, int lda, int ldb, int rows_per_split) {
+    gemm_tn_body(A, B, part, colpart, R, M, N, lda, ldb, rows_per_split, 0, blockIdx.x, blockIdx.y);
+}
+
+// up to TN_MAXG independent problems in one launch (each too small to fill the chip on its own)
+constexpr int TN_MAXG = 8;
+struct TnGroups {
+    const float* A[TN_MAXG];
+    const float* B[TN_MAXG];
+    float* part[TN_MAXG];
+    float* colpart[TN_MAXG];
+    float* C[TN_MAXG];
+    float* colsum[TN_MAXG];
+    int R[TN_MAXG], M[TN_MAXG], N[TN_MAXG], lda[TN_MAXG], ldb[TN_MAXG], ldc[TN_MAXG], bshift[TN_MAXG];
+    int rows_per_split[TN_MAXG], splits[TN_MAXG], tiles[TN_MAXG];
+    int wg_prefix[TN_MAXG + 1];    // workgroups of the contraction kernel
+    int blk_prefix[TN_MAXG + 1];   // 256-thread blocks of the slab reduction
+    int n;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroups gq) {
+    int p = 0;
+    while (p + 1 < gq.n && (int)blockIdx.x >= gq.wg_prefix[p + 1]) ++p;
+    const int local = blockIdx.x - gq.wg_prefix[p];
+    const int split = local / gq.tiles[p];
+    const int tile = local - split * gq.tiles[p];
+    gemm_tn_body(gq.A[p], gq.B[p], gq.part[p], gq.colpart[p], gq.R[p], gq.M[p], gq.N[p], gq.lda[p], gq.ldb[p],
+                 gq.rows_per_split[p], gq.bshift[p], tile, split);
+}
+
+__device__ __forceinline__ void gemm_tn_reduce_body(const float* __restrict__ part, const float* __restrict__ colpart,
+                                                    float* __restrict__ C, float* __restrict__ colsum, int M, int N,
+                                                    int ldc, int splits, int64_t first, int64_t stride) {
     const int64_t total = (int64_t)M * N;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total + M;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = first; idx < total + M; idx += stride) {
         if (idx < total) {
             float s = 0.f;
             for (int k = 0; k < splits; ++k) s += part[(int64_t)k * total + idx];
@@ -140,6 +177,21 @@ __global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, const floa
             colsum[m] = s;
         }
     }
+}
+
+__global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, const float* __restrict__ colpart,
+                                      float* __restrict__ C, float* __restrict__ colsum, int M, int N, int ldc,
+                                      int splits) {
+    gemm_tn_reduce_body(part, colpart, C, colsum, M, N, ldc, splits, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
+                        (int64_t)gridDim.x * blockDim.x);
+}
+
+__global__ void gemm_tn_grouped_reduce_kernel(const TnGroups gq) {
+    int p = 0;
+    while (p + 1 < gq.n && (int)blockIdx.x >= gq.blk_prefix[p + 1]) ++p;
+    const int nblk = gq.blk_prefix[p + 1] - gq.blk_prefix[p];
+    gemm_tn_reduce_body(gq.part[p], gq.colpart[p], gq.C[p], gq.colsum[p], gq.M[p], gq.N[p], gq.ldc[p], gq.splits[p],
+                        (blockIdx.x - gq.blk_prefix[p]) * (int64_t)blockDim.x + threadIdx.x, (int64_t)nblk * blockDim.x);
 }
 
 }  // namespace
@@ -181,6 +233,55 @@ extern "C" int mmdfn_gemm_tn(const float* A, const float* B, float* C, float* co
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid), dim3(256), 0, s, part, colpart, C, colsum, M, N, ldc,
                        eff_splits);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t mmdfn_gemm_tn_grouped_workspace(int n, const int* R, const int* M, const int* N) {
+    int64_t total = 0;
+    for (int p = 0; p < n; ++p) total += (int64_t)mmdfn_gemm_tn_splits(R[p], M[p], N[p]) * ((int64_t)M[p] * N[p] + M[p]);
+    return total;
+}
+
+extern "C" int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, float* const* C,
+                                     float* const* colsum, const int* R, const int* M, const int* N, const int* lda,
+                                     const int* ldb, const int* ldc, const int* bshift, float* workspace, void* stream) {
+    if (n < 1 || n > TN_MAXG) return -1;
+    TnGroups gq;
+    gq.n = n;
+    gq.wg_prefix[0] = 0;
+    gq.blk_prefix[0] = 0;
+    float* ws = workspace;
+    for (int p = 0; p < n; ++p) {
+        if (R[p] <= 0 || M[p] <= 0 || N[p] <= 0 || (M[p] & 3) || (N[p] & 3) || (lda[p] & 3) || (ldb[p] & 3) ||
+            lda[p] < M[p] || ldb[p] < N[p] || ldc[p] < N[p])
+            return -1;
+        const int splits = mmdfn_gemm_tn_splits(R[p], M[p], N[p]);
+        const int tiles = ((M[p] + TM - 1) / TM) * ((N[p] + TN - 1) / TN);
+        const int rps = ((R[p] + splits - 1) / splits + BR - 1) / BR * BR;
+        const int eff = (R[p] + rps - 1) / rps;
+        gq.A[p] = A[p]; gq.B[p] = B[p]; gq.C[p] = C[p]; gq.colsum[p] = colsum ? colsum[p] : nullptr;
+        gq.R[p] = R[p]; gq.M[p] = M[p]; gq.N[p] = N[p]; gq.lda[p] = lda[p]; gq.ldb[p] = ldb[p]; gq.ldc[p] = ldc[p];
+        gq.bshift[p] = bshift ? bshift[p] : 0;
+        gq.rows_per_split[p] = rps; gq.splits[p] = eff; gq.tiles[p] = tiles;
+        gq.part[p] = ws;
+        gq.colpart[p] = gq.colsum[p] ? ws + (int64_t)splits * M[p] * N[p] : nullptr;
+        ws += (int64_t)splits * ((int64_t)M[p] * N[p] + M[p]);
+        gq.wg_prefix[p + 1] = gq.wg_prefix[p] + tiles * eff;
+        int nblk = (int)(((int64_t)M[p] * N[p] + M[p] + 255) / 256);
+        if (nblk > 512) nblk = 512;
+        gq.blk_prefix[p + 1] = gq.blk_prefix[p] + nblk;
+    }
+    for (int p = n; p < TN_MAXG; ++p) {
+        gq.A[p] = gq.B[p] = nullptr; gq.part[p] = gq.colpart[p] = gq.C[p] = gq.colsum[p] = nullptr;
+        gq.R[p] = gq.M[p] = gq.N[p] = gq.lda[p] = gq.ldb[p] = gq.ldc[p] = gq.bshift[p] = 0;
+        gq.rows_per_split[p] = gq.splits[p] = gq.tiles[p] = 0;
+        gq.wg_prefix[p + 1] = gq.wg_prefix[n]; gq.blk_prefix[p + 1] = gq.blk_prefix[n];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(gq.wg_prefix[n]), dim3(256), 0, s, gq);
+    MMDFN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gemm_tn_grouped_reduce_kernel, dim3(gq.blk_prefix[n]), dim3(256), 0, s, gq);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

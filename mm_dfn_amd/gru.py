@@ -53,23 +53,23 @@ class _GruRecurrence(torch.autograd.Function):
                                           _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
                                           _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
         _hip.check(rc, "mmdfn_gru_seq_bwd")
-        out = []
+        # recurrent-weight gradients of every group and direction in ONE grouped launch (2n problems):
+        #   dW_hh = sum_t dgh_t (x) h_{t-1}   forward: h_{t-1} = y[t-1] (row shift -R), reverse: y[t+1] (+R)
+        #   db_hh = sum_t dgh_t                = the column sums of the same operand
+        # written straight into the (2, 3H, H) / (2, 3H) tensors autograd hands back (no stack / sum kernels)
+        problems, out = [], []
         for g in range(n):
             y, d = ys[g], dgh[g]
             T, R = y.shape[0], y.shape[1]
-            # dW_hh = sum_t dgh_t (x) h_{t-1}: forward direction h_{t-1} = y[t-1], reverse h_{t-1} = y[t+1];
-            # the time-shifted column slices are read in place (row-strided views) by the split-K kernel
             d2, y2 = d.view(T * R, 6 * H), y.view(T * R, 2 * H)
-            with ops._wgrad_scope(d, y):              # recurrent-weight gradients: off the critical path
-                if T > 1:
-                    dwf = ops.gemm_tn(d2[R:, :3 * H], y2[:-R, :H])[0]
-                    dwr = ops.gemm_tn(d2[:-R, 3 * H:], y2[R:, H:])[0]
-                else:
-                    dwf = torch.zeros(3 * H, H, dtype=torch.float32, device=y.device)
-                    dwr = torch.zeros_like(dwf)
-                dw = torch.stack([dwf, dwr], 0)
-                db = d2.sum(0).view(2, 3 * H)
+            dw = torch.empty(2, 3 * H, H, dtype=torch.float32, device=y.device)
+            db = torch.empty(2, 3 * H, dtype=torch.float32, device=y.device)
+            problems.append(dict(A=d2[:, :3 * H], B=y2[:, :H], C=dw[0], colsum=db[0], shift=-R))
+            problems.append(dict(A=d2[:, 3 * H:], B=y2[:, H:], C=dw[1], colsum=db[1], shift=R))
             out += [dgi[g], dw, db]
+        with ops._wgrad_scope(*dgh, *ys):             # off the critical path when the side stream is enabled
+            for i in range(0, len(problems), 8):
+                ops.gemm_tn_grouped(problems[i:i + 8])
         return tuple(out)
 
 

@@ -388,6 +388,40 @@ def gemm_tn(A, B, want_colsum=False):
     return C, colsum
 
 
+def gemm_tn_grouped(problems):
+    """ONE launch pair for up to 8 contractions  C_p = sum_r A_p[r]^T B_p[r + shift_p]  (+ column sums of A_p).
+
+    problems: list of dicts with A (R, M), B (R, N) row-strided views, C (M, N) output view (row stride ldc), optional
+    colsum (M,) output view and shift (int, rows; B rows outside [0, R) count as zero).  Outputs are written in place."""
+    n = len(problems)
+    if not 1 <= n <= 8:
+        raise ValueError("gemm_tn_grouped takes 1..8 problems")
+    A = [_strided_rows(p["A"]) for p in problems]
+    B = [_strided_rows(p["B"]) for p in problems]
+    _hip.require_cuda(*A, *B)
+    _hip.require_f32(*A, *B)
+    C = [p["C"] for p in problems]
+    cs = [p.get("colsum") for p in problems]
+    R = [a.shape[0] for a in A]
+    M = [a.shape[1] for a in A]
+    N = [b.shape[1] for b in B]
+    for p, a, b, c in zip(problems, A, B, C):
+        if b.shape[0] != a.shape[0] or tuple(c.shape) != (a.shape[1], b.shape[1]) or c.stride(1) != 1:
+            raise ValueError("gemm_tn_grouped: inconsistent problem shapes")
+    lib = _hip.lib()
+    ia = _hip.int_array
+    nws = lib.mmdfn_gemm_tn_grouped_workspace(n, ia(R), ia(M), ia(N))
+    ws = torch.empty(int(nws), dtype=torch.float32, device=A[0].device)
+    import ctypes
+    cs_arr = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in cs])
+    rc = lib.mmdfn_gemm_tn_grouped(n, _hip.ptr_array(A), _hip.ptr_array(B), _hip.ptr_array(C), cs_arr, ia(R), ia(M), ia(N),
+                                   ia([a.stride(0) for a in A]), ia([b.stride(0) for b in B]),
+                                   ia([c.stride(0) for c in C]), ia([int(p.get("shift", 0)) for p in problems]),
+                                   _hip.ptr(ws), _hip.stream())
+    _hip.check(rc, "mmdfn_gemm_tn_grouped")
+    return ws   # kept alive by the caller's frame until the launches are enqueued (stream-ordered allocator)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Weight-gradient side stream.  dW / db of the dense layers feed nothing else in the backward pass, so when
 # enabled they are enqueued on a second HIP stream (forked from / joined to the main stream with events; under

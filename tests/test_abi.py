@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "mmdfn_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(mmdfn_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(mmdfn_\w+)\s*\(", text)))
 
 
 def test_header_declares_symbols():

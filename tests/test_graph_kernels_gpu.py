@@ -301,3 +301,34 @@ def test_gemm_tn_weight_gradient_kernel(R, M, N):
     wideB = torch.from_numpy(rs.randn(R + 3, 2 * N).astype(np.float32)).to(DEV)
     C2, _ = ops.gemm_tn(wideA[3:, 4:4 + M], wideB[:-3, N:])
     assert rel_err(C2, wideA[3:, 4:4 + M].double().cpu().t() @ wideB[:-3, N:].double().cpu()) < 5e-6
+
+
+def test_gemm_tn_grouped_with_row_shifts():
+    """Grouped launch: mixed shapes, B read at row r + shift (outside rows count as zero), column sums of A,
+    outputs written into views of larger tensors; against a float64 torch composition."""
+    rs = np.random.RandomState(21)
+    specs = [(700, 300, 100, -16), (700, 300, 100, 16), (96, 300, 100, -96), (1760, 64, 200, 0), (333, 12, 36, 5),
+             (40, 300, 100, -48)]   # the last one: |shift| > R, every product masked -> zeros
+    probs, refs = [], []
+    for (R, M, N, sh) in specs:
+        wa = torch.from_numpy(rs.randn(R, M + 8).astype(np.float32)).to(DEV)
+        wb = torch.from_numpy(rs.randn(R, N + 4).astype(np.float32)).to(DEV)
+        A, B = wa[:, 4:4 + M], wb[:, :N]
+        Cfull = torch.full((2, M, N + 4), 7.0, device=DEV)
+        csfull = torch.full((3, M), 7.0, device=DEV)
+        probs.append(dict(A=A, B=B, C=Cfull[1, :, :N], colsum=csfull[2], shift=sh))
+        Bs = torch.zeros(R, N, dtype=torch.float64)
+        lo, hi = max(0, -sh), min(R, R - sh)
+        if hi > lo:
+            Bs[lo:hi] = B.double().cpu()[lo + sh:hi + sh]
+        refs.append((A.double().cpu().t() @ Bs, A.double().cpu().sum(0), Cfull, csfull))
+    ops.gemm_tn_grouped(probs)
+    for p, (Cw, csw, Cfull, csfull) in zip(probs, refs):
+        scale = max(float(Cw.abs().max()), 1.0)
+        assert float((p["C"].double().cpu() - Cw).abs().max()) / scale < 1e-5
+        assert float((p["colsum"].double().cpu() - csw).abs().max()) < 1e-3
+        assert float(Cfull[0].min()) == 7.0 and float(Cfull[1, :, -4:].min()) == 7.0 and float(csfull[:2].min()) == 7.0
+    # no column sums requested
+    C = torch.empty(300, 100, device=DEV)
+    ops.gemm_tn_grouped([dict(A=probs[0]["A"], B=probs[0]["B"], C=C, shift=-16)])
+    assert float((C.double().cpu() - refs[0][0]).abs().max()) / float(refs[0][0].abs().max()) < 1e-5
