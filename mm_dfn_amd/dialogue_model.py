@@ -212,9 +212,8 @@ class DialogueGNNModel(nn.Module):
         (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209).
         The context GRU and the batched party GRU are independent and share every recurrence launch;
         the party gather / scatter / pad-strip are the fused K3/K4 kernels (csrc/encoder_glue.hip)."""
-        Xa = ops.linear(U_a, self.linear_a.weight, self.linear_a.bias)
-        Xv = ops.linear(U_v, self.linear_v.weight, self.linear_v.bias)
-        Xl = ops.linear(U, self.linear_l.weight, self.linear_l.bias)
+        Xa, Xv, Xl = ops.linear_group([U_a, U_v, U], [self.linear_a.weight, self.linear_v.weight, self.linear_l.weight],
+                                      [self.linear_a.bias, self.linear_v.bias, self.linear_l.bias])
         L, B, H = Xa.shape
         idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
         if self.use_crn_speaker:

@@ -109,9 +109,7 @@ class GCNII_lyc(nn.Module):
         for i, con in enumerate(self.convs):
             q = cur
             if self.reason_flag:
-                G = ops.linear(q, w_ih, bias)
-                if h is not None:
-                    G = ops.linear(h, w_hh, None, base=G)
+                G = ops.linear(q, w_ih, bias) if h is None else ops.gate_linear(q, h, w_ih, w_hh, bias)
                 h, c = ops.lstm_pointwise(G, c)
                 cur = h
             theta = math.log(self.lamda / (i + 1) + 1)

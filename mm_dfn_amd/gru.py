@@ -89,10 +89,12 @@ def bigru2(xs, grus, dropout=0.0, training=False):
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
     cur = list(xs)
     for layer in range(2):
+        prm = [_layer_params(gru, layer) for gru in grus]
+        # hoisted input contractions (all t, both directions) of every group: one op, one weight-gradient launch
+        gis = ops.linear_group(cur, [p[0] for p in prm], [p[1] for p in prm])
         args = []
-        for x, gru in zip(cur, grus):
-            w_ih, b_ih, w_hh, b_hh = _layer_params(gru, layer)
-            args += [ops.linear(x, w_ih, b_ih), w_hh, b_hh]    # hoisted input contraction (all t, both directions)
+        for gi, p in zip(gis, prm):
+            args += [gi, p[2], p[3]]
         cur = list(_GruRecurrence.apply(*args))
         if layer == 0 and training and dropout > 0:
             cur = [F.dropout(y, dropout, True) for y in cur]

@@ -560,6 +560,115 @@ class _MatmulKN(torch.autograd.Function):
         return dx, dw
 
 
+def _linear_forward(x2, weight, bias, act):
+    """act(x2 W^T + b) with the engine _Linear picks for the shape."""
+    N, K = weight.shape
+    if linear_supported(x2, weight) and linear_preferred(x2.shape[0], K, N):
+        return linear_raw(x2, weight, bias, act)
+    y = torch.nn.functional.linear(x2, weight, bias)
+    return torch.relu_(y) if act else y
+
+
+def _linear_dx(dy2, weight):
+    N, K = weight.shape
+    if N % 4 == 0 and linear_preferred(dy2.shape[0], N, K):
+        return linear_raw(dy2, weight.t().contiguous(), None, 0)
+    return dy2 @ weight
+
+
+def _weight_grads(jobs):
+    """jobs: list of (dy2 (R, N), x2 (R, K), want_bias) -> list of (dW (N, K), db or None); every job the split-K
+    kernel covers goes into ONE grouped launch pair (the problems are far too small to fill the chip one by one)."""
+    res = [None] * len(jobs)
+    probs, slots = [], []
+    for i, (dy2, x2, wb) in enumerate(jobs):
+        N, K = dy2.shape[1], x2.shape[1]
+        if gemm_tn_supported(N, K):
+            dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
+            db = torch.empty(N, dtype=torch.float32, device=dy2.device) if wb else None
+            probs.append(dict(A=dy2, B=x2, C=dw, colsum=db))
+            slots.append(i)
+            res[i] = (dw, db)
+        else:
+            res[i] = (dy2.t() @ x2, dy2.sum(0) if wb else None)
+    with _wgrad_scope(*[t for j in jobs for t in j[:2]]):
+        for i in range(0, len(probs), 8):
+            gemm_tn_grouped(probs[i:i + 8])
+    return res
+
+
+class _LinearGroup(torch.autograd.Function):
+    """n independent projections y_g = act(x_g W_g^T + b_g) that become available together (the three modality
+    projections model.py:1065,1094,1129; the hoisted input contractions of the context and the party GRU).  Forward
+    is n launches as before; backward computes every dW_g / db_g in one grouped launch pair."""
+
+    @staticmethod
+    def forward(ctx, act, n, *args):
+        xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        ys, saved = [], []
+        for x, w, b in zip(xs, ws, bs):
+            x2 = x.reshape(-1, x.shape[-1])
+            y = _linear_forward(x2, w, b, act)
+            saved += [x2, w, y if act else None]
+            ys.append(y.view(*x.shape[:-1], w.shape[0]))
+        ctx.n, ctx.act = n, act
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.save_for_backward(*saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, sv = ctx.n, ctx.saved_tensors
+        dxs, jobs = [], []
+        for g in range(n):
+            x2, w, y = sv[3 * g], sv[3 * g + 1], sv[3 * g + 2]
+            dy2 = dys[g].reshape(-1, w.shape[0])
+            if ctx.act:
+                dy2 = dy2 * (y > 0).to(dy2.dtype)
+            dy2 = dy2.contiguous()
+            jobs.append((dy2, x2, ctx.has_bias[g]))
+            dxs.append(_linear_dx(dy2, w).view(*dys[g].shape[:-1], w.shape[1]) if ctx.needs_input_grad[2 + g] else None)
+        wg = _weight_grads(jobs)
+        return (None, None) + tuple(dxs) + tuple(r[0] for r in wg) + tuple(r[1] for r in wg)
+
+
+def linear_group(xs, weights, biases, act=0):
+    """[act(x W^T + b) for each group] with all weight gradients computed by one grouped launch."""
+    for x in xs:
+        _hip.require_cuda(x)
+    n = len(xs)
+    return list(_LinearGroup.apply(act, n, *xs, *weights, *biases))
+
+
+class _GateLinear(torch.autograd.Function):
+    """G = q W_ih^T + h W_hh^T + b: the pre-activation of the layer-shared LSTM cell (model_GCN.py:466, seq_len 1)
+    as one op; dW_ih, dW_hh and db come out of one grouped launch (they share the operand dG)."""
+
+    @staticmethod
+    def forward(ctx, q, h, w_ih, w_hh, bias):
+        G = _linear_forward(q, w_ih, bias, 0)
+        if linear_supported(h, w_hh) and linear_preferred(h.shape[0], w_hh.shape[1], w_hh.shape[0]):
+            linear_raw(h, w_hh, None, 0, out=G, accumulate=True)
+        else:
+            G = torch.addmm(G, h, w_hh.t())
+        ctx.save_for_backward(q, h, w_ih, w_hh)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        q, h, w_ih, w_hh = ctx.saved_tensors
+        dG = dG.contiguous()
+        dq = _linear_dx(dG, w_ih) if ctx.needs_input_grad[0] else None
+        dh = _linear_dx(dG, w_hh) if ctx.needs_input_grad[1] else None
+        (dwi, db), (dwh, _) = _weight_grads([(dG, q, True), (dG, h, False)])
+        return dq, dh, dwi, dwh, db
+
+
+def gate_linear(q, h, w_ih, w_hh, bias):
+    _hip.require_cuda(q, h)
+    return _GateLinear.apply(q, h, w_ih, w_hh, bias)
+
+
 def matmul_kn(x, w):
     _hip.require_cuda(x)
     return _MatmulKN.apply(x, w)
