@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 1). */
+/* Library / device sanity: returns the ABI version (currently 2). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -103,7 +103,8 @@ int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross,
  * One layer, both directions, `ngroups` independent GRUs in one launch
  * (host arrays of device pointers, one entry per group; ngroups <= 4):
  *   gi[g]    : (T, rows, 2, 3H)  X W_ih^T + b_ih for both directions (dir-major columns)
- *   w_hh[g]  : (2, 3H, H), b_hh[g] : (2, 3H)        gate order r, z, n
+ *   w_hh[2g + dir] : (3H, H), b_hh[2g + dir] : (3H)  per direction, exactly as nn.GRU stores
+ *              weight_hh_l*[_reverse] / bias_hh_l*[_reverse] (arrays of 2*ngroups pointers); gate order r, z, n
  *   y[g]     : (T, rows, 2H) out; direction 1 runs t = T-1 .. 0; zero initial state
  *   gates[g] : (T, rows, 2, 4, H) out: r, z, n and W_hn h + b_hn (saved for backward)
  * H must be 100 (the reference hard-codes D_e = 100).

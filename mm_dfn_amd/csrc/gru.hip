@@ -28,8 +28,8 @@ constexpr int MAXG = 4;
 struct FwdGroups {
     int n;
     const float* gi[MAXG];
-    const float* w_hh[MAXG];
-    const float* b_hh[MAXG];
+    const float* w_hh[2 * MAXG];   // [2g + direction]: (3H, H), the module's weight_hh_l*[_reverse] as stored
+    const float* b_hh[2 * MAXG];
     float* y[MAXG];
     float* gates[MAXG];
     int rows[MAXG];
@@ -42,7 +42,7 @@ struct BwdGroups {
     const float* dy[MAXG];
     const float* y[MAXG];
     const float* gates[MAXG];
-    const float* w_hh[MAXG];
+    const float* w_hh[2 * MAXG];
     float* dgi[MAXG];
     float* dgh[MAXG];
     int rows[MAXG];
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     const int T = G.T[gidx];
     const int row0 = ((int)blockIdx.x - G.slice0[gidx]) * R;
     const float* __restrict__ gi = G.gi[gidx];
-    const float* __restrict__ w_hh = G.w_hh[gidx] + (int64_t)dir * 3 * GH * GH;
-    const float* __restrict__ b_hh = G.b_hh[gidx] + dir * 3 * GH;
+    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
+    const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
     float* __restrict__ y = G.y[gidx];
     float* __restrict__ gates = G.gates[gidx];
 
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     const float* __restrict__ dy = G.dy[gidx];
     const float* __restrict__ y = G.y[gidx];
     const float* __restrict__ gates = G.gates[gidx];
-    const float* __restrict__ w_hh = G.w_hh[gidx] + (int64_t)dir * 3 * GH * GH;
+    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
     float* __restrict__ dgi = G.dgi[gidx];
     float* __restrict__ dgh = G.dgh[gidx];
 
@@ -417,7 +417,9 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     int sl = 0;
     for (int g = 0; g < ngroups; ++g) {
         if (rows[g] <= 0 || T[g] <= 0) return -1;
-        G.gi[g] = gi[g]; G.w_hh[g] = w_hh[g]; G.b_hh[g] = b_hh[g]; G.y[g] = y[g]; G.gates[g] = gates[g];
+        G.gi[g] = gi[g]; G.y[g] = y[g]; G.gates[g] = gates[g];
+        G.w_hh[2 * g] = w_hh[2 * g]; G.w_hh[2 * g + 1] = w_hh[2 * g + 1];
+        G.b_hh[2 * g] = b_hh[2 * g]; G.b_hh[2 * g + 1] = b_hh[2 * g + 1];
         G.rows[g] = rows[g]; G.T[g] = T[g]; G.slice0[g] = sl;
         sl += (rows[g] + R - 1) / R;
     }
@@ -441,7 +443,8 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     int sl = 0;
     for (int g = 0; g < ngroups; ++g) {
         if (rows[g] <= 0 || T[g] <= 0) return -1;
-        G.dy[g] = dy[g]; G.y[g] = y[g]; G.gates[g] = gates[g]; G.w_hh[g] = w_hh[g]; G.dgi[g] = dgi[g];
+        G.dy[g] = dy[g]; G.y[g] = y[g]; G.gates[g] = gates[g]; G.dgi[g] = dgi[g];
+        G.w_hh[2 * g] = w_hh[2 * g]; G.w_hh[2 * g + 1] = w_hh[2 * g + 1];
         G.dgh[g] = dgh[g]; G.rows[g] = rows[g]; G.T[g] = T[g]; G.slice0[g] = sl;
         sl += (rows[g] + R - 1) / R;
     }

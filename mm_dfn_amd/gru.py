@@ -15,15 +15,18 @@ H = 100
 
 
 class _GruRecurrence(torch.autograd.Function):
-    """args = (gi_0, w_hh_0, b_hh_0, gi_1, w_hh_1, b_hh_1, ...) -> (y_0, y_1, ...)."""
+    """args = per group (gi, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev), flattened -> (y_0, y_1, ...).  The recurrent
+    weights are the module's own parameters (no stack / cat per step): the kernels take one pointer per direction
+    and the gradients come back per parameter."""
 
     @staticmethod
     def forward(ctx, *args):
-        n = len(args) // 3
-        gis = [args[3 * g].contiguous() for g in range(n)]
-        whh = [args[3 * g + 1].contiguous() for g in range(n)]
-        bhh = [args[3 * g + 2].contiguous() for g in range(n)]
+        n = len(args) // 5
+        gis = [args[5 * g].contiguous() for g in range(n)]
+        whh = [args[5 * g + 1 + d].contiguous() for g in range(n) for d in range(2)]
+        bhh = [args[5 * g + 3 + d].contiguous() for g in range(n) for d in range(2)]
         _hip.require_cuda(*gis)
+        _hip.require_f32(*gis, *whh, *bhh)
         ys, gates, rows, Ts = [], [], [], []
         for gi in gis:
             T, R = gi.shape[0], gi.shape[1]
@@ -56,17 +59,16 @@ class _GruRecurrence(torch.autograd.Function):
         # recurrent-weight gradients of every group and direction in ONE grouped launch (2n problems):
         #   dW_hh = sum_t dgh_t (x) h_{t-1}   forward: h_{t-1} = y[t-1] (row shift -R), reverse: y[t+1] (+R)
         #   db_hh = sum_t dgh_t                = the column sums of the same operand
-        # written straight into the (2, 3H, H) / (2, 3H) tensors autograd hands back (no stack / sum kernels)
         problems, out = [], []
         for g in range(n):
             y, d = ys[g], dgh[g]
             T, R = y.shape[0], y.shape[1]
             d2, y2 = d.view(T * R, 6 * H), y.view(T * R, 2 * H)
-            dw = torch.empty(2, 3 * H, H, dtype=torch.float32, device=y.device)
-            db = torch.empty(2, 3 * H, dtype=torch.float32, device=y.device)
-            problems.append(dict(A=d2[:, :3 * H], B=y2[:, :H], C=dw[0], colsum=db[0], shift=-R))
-            problems.append(dict(A=d2[:, 3 * H:], B=y2[:, H:], C=dw[1], colsum=db[1], shift=R))
-            out += [dgi[g], dw, db]
+            dwf, dwr = (torch.empty(3 * H, H, dtype=torch.float32, device=y.device) for _ in range(2))
+            dbf, dbr = (torch.empty(3 * H, dtype=torch.float32, device=y.device) for _ in range(2))
+            problems.append(dict(A=d2[:, :3 * H], B=y2[:, :H], C=dwf, colsum=dbf, shift=-R))
+            problems.append(dict(A=d2[:, 3 * H:], B=y2[:, H:], C=dwr, colsum=dbr, shift=R))
+            out += [dgi[g], dwf, dwr, dbf, dbr]
         with ops._wgrad_scope(*dgh, *ys):             # off the critical path when the side stream is enabled
             for i in range(0, len(problems), 8):
                 ops.gemm_tn_grouped(problems[i:i + 8])
@@ -77,9 +79,9 @@ def _layer_params(gru, layer):
     sfx = "_l%d" % layer
     w_ih = torch.cat([getattr(gru, "weight_ih" + sfx), getattr(gru, "weight_ih" + sfx + "_reverse")], 0)
     b_ih = torch.cat([getattr(gru, "bias_ih" + sfx), getattr(gru, "bias_ih" + sfx + "_reverse")], 0)
-    w_hh = torch.stack([getattr(gru, "weight_hh" + sfx), getattr(gru, "weight_hh" + sfx + "_reverse")], 0)
-    b_hh = torch.stack([getattr(gru, "bias_hh" + sfx), getattr(gru, "bias_hh" + sfx + "_reverse")], 0)
-    return w_ih, b_ih, w_hh, b_hh
+    hh = [getattr(gru, "weight_hh" + sfx), getattr(gru, "weight_hh" + sfx + "_reverse"),
+          getattr(gru, "bias_hh" + sfx), getattr(gru, "bias_hh" + sfx + "_reverse")]
+    return w_ih, b_ih, hh
 
 
 def bigru2(xs, grus, dropout=0.0, training=False):
@@ -94,7 +96,7 @@ def bigru2(xs, grus, dropout=0.0, training=False):
         gis = ops.linear_group(cur, [p[0] for p in prm], [p[1] for p in prm])
         args = []
         for gi, p in zip(gis, prm):
-            args += [gi, p[2], p[3]]
+            args += [gi] + p[2]
         cur = list(_GruRecurrence.apply(*args))
         if layer == 0 and training and dropout > 0:
             cur = [F.dropout(y, dropout, True) for y in cur]
