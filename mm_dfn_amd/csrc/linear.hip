@@ -146,6 +146,20 @@ extern "C" int mmdfn_linear(const float* X, const float* W, const float* bias, f
     if (ov == 4) return launch<4, 4, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
     if (ov == 5) return launch<2, 2, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
     if (ov == 6) return launch<1, 4, 4, 1>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 7) {
+        const int rc = mmdfn_launch_linear_split(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
+        if (rc != -2) return rc;
+    }
+    if (ov != 8) {
+        // many 128 x 128 output tiles: the bf16-piece kernel (fp32-level error) outruns the exact-f32 MFMA path
+        // 1.5-2x (tools/bench_linear.py: 10560 x 200 -> 600: 54 -> 33 us; 98304 x 200 -> 100: 79 -> 51 us);
+        // with fewer tiles its 4-wave 128 x 128 workgroups leave the chip idle
+        const long tiles = (long)((R + 127) / 128) * ((N + 127) / 128);
+        if (tiles >= 384 && K >= 32) {
+            const int rc = mmdfn_launch_linear_split(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
+            if (rc != -2) return rc;
+        }
+    }
     // measured (tools/bench_linear.py): the 64 x 64 workgroup tile (2 x 2 MFMA tiles per wave) wins on every
     // hot-path shape -- the kernel is latency-bound, so more, smaller workgroups beat bigger register tiles
     return launch<2, 2, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);

@@ -354,7 +354,10 @@ def linear_preferred(rows, K, N):
     """Shapes where the MFMA kernel beats the library GEMM on MI355X (tools/bench_linear.py, round 1):
     many rows and a short contraction (the batched party-GRU input projection, the GCN input layer, the
     LSTM gate pre-activations).  Small-row / long-K projections stay on hipBLASLt (a plain library GEMM)."""
-    return rows >= 4096 and K <= 256
+    if rows >= 4096 and K <= 256:
+        return True
+    # many 128 x 128 output tiles: the bf16-piece variant (csrc/linear_split.hip) also wins at long K
+    return ((rows + 127) // 128) * ((N + 127) // 128) >= 384 and K <= 1024
 
 
 def _strided_rows(t):

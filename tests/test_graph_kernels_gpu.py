@@ -332,3 +332,33 @@ def test_gemm_tn_grouped_with_row_shifts():
     C = torch.empty(300, 100, device=DEV)
     ops.gemm_tn_grouped([dict(A=probs[0]["A"], B=probs[0]["B"], C=C, shift=-16)])
     assert float((C.double().cpu() - refs[0][0]).abs().max()) / float(refs[0][0].abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("R,K,N", [(300, 200, 600), (129, 100, 36), (1000, 36, 130), (257, 512, 200), (64, 8, 4),
+                                   (2000, 44, 256)])
+def test_linear_bf16_piece_kernel(R, K, N, monkeypatch):
+    """The many-row projection kernel (three exact bf16 pieces per operand, csrc/linear_split.hip) forced on small
+    and ragged shapes: K tails (K % 32 != 0), row / column tails, strided input and output, bias, ReLU, accumulate."""
+    monkeypatch.setenv("MMDFN_LIN_CFG", "7")
+    rs = np.random.RandomState(31)
+    xw = torch.from_numpy(rs.randn(R, K + 12).astype(np.float32)).to(DEV)
+    x = xw[:, 4:4 + K]                                   # row stride K + 12, 16-byte aligned start
+    w = torch.from_numpy(rs.randn(N, K).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rs.randn(N).astype(np.float32)).to(DEV)
+    want = x.double() @ w.double().t() + b.double()
+    scale = float(want.abs().max())
+    y = ops.linear_raw(x, w, b, 0)
+    assert float((y.double() - want).abs().max()) / scale < 2e-6
+    y = ops.linear_raw(x, w, b, 1)
+    assert float((y.double() - want.clamp(min=0)).abs().max()) / scale < 2e-6
+    wide = torch.full((R, N + 8), 3.0, device=DEV)
+    out = wide[:, :N]
+    ops.linear_raw(x, w, None, 0, out=out, accumulate=True)
+    assert float((out.double() - (want - b.double() + 3.0)).abs().max()) / scale < 2e-6
+    assert float(wide[:, N:].min()) == 3.0
+    # same answer as the exact-f32 MFMA kernel to fp32 rounding
+    monkeypatch.setenv("MMDFN_LIN_CFG", "8")
+    y32 = ops.linear_raw(x, w, b, 0)
+    assert float((y32 - ops.linear_raw(x, w, b, 0)).abs().max()) == 0.0
+    monkeypatch.setenv("MMDFN_LIN_CFG", "7")
+    assert float((ops.linear_raw(x, w, b, 0) - y32).abs().max()) / scale < 2e-6
