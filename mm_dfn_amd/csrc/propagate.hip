@@ -455,9 +455,12 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
     // over 4 waves win while the launch is latency-bound; 8-wave row blocks win once the H-row staging
     // traffic (one pass over the H tile per row block) dominates.
     const long approx_rows = (long)B * M * max_len;
-    if (d <= 128 && approx_rows > 32768L && max_len >= 128) {
-        // large launches are bound by the exact-f32 MFMA rate: carry the product on bf16 MFMAs (three exact
-        // bf16 pieces per operand, fp32-level error; propagate_split.hip): 124 -> 88 us at L=512, M=6, B=32
+    const long split_wgs = (long)B * M * ((max_len + 127) / 128) * ((d + 127) / 128);
+    if (max_len >= 128 && split_wgs >= 48) {
+        // dialogues of >= 128 utterances: the exact-f32 MFMA rate bounds the kernel; carry the product on bf16 MFMAs
+        // (three exact bf16 pieces per operand, fp32-level error; propagate_split.hip).  Measured: L=512 M=6 B=32
+        // 124 -> 86 us, B=8 47 -> 32 us, d=512 152 -> 100 us; L=128..384 M=3 10-25 % faster
+        // (profiles/r01_propagate_tuning.md)
         const int rc = mmdfn_launch_propagate_split(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh,
                                                     ldo, max_len, s);
         if (rc != -2) return rc;

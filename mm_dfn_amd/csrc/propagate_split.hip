@@ -10,8 +10,8 @@
 // the f32-MFMA kernel) while six bf16 MFMAs per K=16 replace four f32 MFMAs per K=16 at 1/16 of the cycles
 // per flop: 2.7x less matrix-pipe time.
 //
-// Work decomposition: workgroup = (dialogue, modality, 128 tile rows); 4 waves x 32 rows; 128 feature
-// columns (d <= 128) as 4 v_mfma_f32_32x32x16_bf16 column tiles.
+// Work decomposition: workgroup = (dialogue, modality, 128 tile rows, 128 feature columns); 4 waves x 32 rows x
+// 4 v_mfma_f32_32x32x16_bf16 column tiles.
 //   A (the tile strip) goes HBM -> registers in MFMA layout (lane (row, kg) holds 8 consecutive k per K=16
 //     step; the k permutation inside a 32-wide chunk makes each load instruction fetch 32 contiguous bytes per
 //     row) and is cut in registers.
@@ -50,7 +50,7 @@ template <int ABLC>
 __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
-    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int abl) {
+    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl) {
     constexpr int NCT = 4;                 // 32-column MFMA tiles
     constexpr int WROWS = 32;              // tile rows per wave
     constexpr int BM = 4 * WROWS;          // 128 tile rows per workgroup
@@ -62,21 +62,25 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 
     // XCD-aware decode: bid % 8 == dialogue % 8
-    const int Rd = M * max_rb;
+    // (wider feature blocks, d > 128: one workgroup per 128-column block, column blocks of a row block adjacent)
+    const int Rt = max_rb * ncb;
+    const int Rd = M * Rt;
     const int bid = blockIdx.x;
     const int yq = bid >> 3;
     const int i = (yq / Rd) * 8 + (bid & 7);
     if (i >= B) return;
     const int rho = yq % Rd;
-    const int m = rho / max_rb;
-    const int rb = rho - m * max_rb;
+    const int m = rho / Rt;
+    const int rb = (rho - m * Rt) / ncb;
+    const int c0 = ((rho - m * Rt) - rb * ncb) * CB;
+    const int dloc = (d - c0 < CB) ? d - c0 : CB;      // columns of this block that exist
     const int L = dia_len[i];
     const int r0 = rb * BM;
     if (r0 >= L) return;
     const int ld = (L + 3) & ~3;
     const int rs = row_start[i];
     const float* T = tiles + tile_base[i] + (int64_t)m * L * ld;
-    const float* Hm = H + ((int64_t)m * N + rs) * ldh;
+    const float* Hm = H + ((int64_t)m * N + rs) * ldh + c0;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     //      k = 16 kh + 8 (e >> 2) + 4 kg + (e & 3)
     // B staging tasks: thread -> column (tid & 127), slots (kh = 0 and 1, kg = tid >> 7): 2 x 8 k values
     const int bcol = tid & 127;
-    const bool bok = bcol < d;
+    const bool bok = bcol < dloc;
     const int bcolc = bok ? bcol : 0;
     const int bkg = __builtin_amdgcn_readfirstlane(tid >> 7);   // wave-uniform -> scalar row arithmetic
     const int blds = bcol * SROW + 4 * bkg;                     // + 8 for the kh = 1 slot
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     if (abl & 32) return;
     __syncthreads();   // the last step's (unused) fragment reloads have retired
     constexpr int NJ = CB / 16;
-    const int cw4 = d / 4;
+    const int cw4 = dloc / 4;
     const int erow = tid >> 2;
     const int eq = tid & 3;
 #pragma unroll
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
                 const int n = q + (q >= m ? 1 : 0);
                 const int pk = (m < n) ? mmdfn_pair_index(m, n, M) : mmdfn_pair_index(n, m, M);
                 const float cwt = cross[(int64_t)pk * N + grow];
-                const float* hrow = H + ((int64_t)n * N + grow) * ldh;
+                const float* hrow = H + ((int64_t)n * N + grow) * ldh + c0;
                 float4 h[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) h[j] = *reinterpret_cast<const float4*>(hrow + coff[j]);
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
                     v[j].w = fmaf(cwt, h[j].w, v[j].w);
                 }
             }
-            float* orow = out + ((int64_t)m * N + grow) * ldo;
+            float* orow = out + ((int64_t)m * N + grow) * ldo + c0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 if (eq + 4 * j < cw4) *reinterpret_cast<float4*>(orow + coff[j]) = v[j];
@@ -219,19 +223,20 @@ int split_ablation() {
 
 }  // namespace
 
-// d <= 128 only; returns -2 when the shape is not covered (caller falls back to the f32-MFMA kernel)
+// returns -2 when the shape is not covered (caller falls back to the f32-MFMA kernel)
 int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const float* H, float* out,
                                  const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                                  int B, int M, int N, int d, int ldh, int ldo, int max_len, hipStream_t s) {
-    if (d > 128 || (d & 3)) return -2;
+    if (d & 3) return -2;
     const int max_rb = (max_len + 127) / 128;
+    const int ncb = (d + 127) / 128;
     const int lds_bytes = 2 * 3 * 128 * SROW * 4;   // 61440 B (>= the 64 x 136 float epilogue staging)
-    dim3 grid(((B + 7) / 8) * 8 * M * max_rb);
+    dim3 grid(((B + 7) / 8) * 8 * M * max_rb * ncb);
     const char* ac = getenv("MMDFN_SPLIT_ABLC");  // profiling aid: compile-time ablations (1: no cutting, 2: no MFMA)
     const int ablc = ac ? atoi(ac) : 0;
 #define SPLIT_LAUNCH(A)                                                                                          \
     hipLaunchKernelGGL((propagate_split_kernel<A>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
-                       row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, split_ablation())
+                       row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation())
     if (ablc == 1) SPLIT_LAUNCH(1);
     else if (ablc == 2) SPLIT_LAUNCH(2);
     else SPLIT_LAUNCH(0);

@@ -50,6 +50,9 @@ SPLIT_CASES = [
     ([260, 40], 6, 64),
     ([513], 3, 100),
     ([9, 31], 1, 36),
+    ([140, 77], 3, 200),
+    ([70], 6, 512),
+    ([33, 200], 2, 132),
 ]
 
 

@@ -27,6 +27,10 @@ WORKLOADS = {
     "cfg5_b8_d100": dict(lengths=[512] * 8, M=6, d=100),
     "cfg5_b32_d100": dict(lengths=[512] * 32, M=6, d=100),
     "cfg5_b8_d512": dict(lengths=[512] * 8, M=6, d=512),
+    "mid_L256_b16": dict(lengths=[256] * 16, M=3, d=100),
+    "mid_L128_b64": dict(lengths=[128] * 64, M=3, d=100),
+    "mid_L200_b32": dict(lengths=[200] * 32, M=3, d=100),
+    "mid_L384_b8": dict(lengths=[384] * 8, M=3, d=100),
 }
 
 
