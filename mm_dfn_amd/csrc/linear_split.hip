@@ -31,32 +31,24 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void linear_split_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                              const float* __restrict__ bias, float* __restrict__ Y,
-                                                              int R, int K, int N, int ldx, int ldy, int act,
-                                                              int accumulate) {
+// One 128 x 128 output block:  Yb[r][c] = act( sum_k Xb[r][k] Wb[c][k] + bias[c] ) (+ Yb[r][c])  for r < Rv, c < Nstore;
+// columns Nv <= c < Nstore are written as exact zeros (row padding of the block-tile layout).
+__device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, const float* __restrict__ Wb,
+                                                 const float* __restrict__ bias, float* __restrict__ Yb, int Rv, int Nv,
+                                                 int Nstore, int K, int ldx, int ldw, int ldy, int act, int accumulate) {
     constexpr int NCT = 4;
     constexpr int ABLC = 0;
     constexpr int WROWS = 32;
-    constexpr int BM = 4 * WROWS;
-    constexpr int CB = 32 * NCT;
     constexpr int split_stride = 128 * SROW;
     constexpr int stage_stride = 3 * split_stride;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-
-    // column blocks fastest: the row blocks of one X strip run back to back and share it through L2
-    const int nbn = (N + CB - 1) / CB;
-    const int bm = blockIdx.x / nbn;
-    const int bn = blockIdx.x - bm * nbn;
-    const int r0 = bm * BM;
-    const int c0 = bn * CB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     const int l32 = lane & 31;
     const int kg = lane >> 5;
-    const int wrow0 = r0 + WROWS * w;
+    const int wrow0 = WROWS * w;
 
     f32x16 acc[NCT];
 #pragma unroll
@@ -64,15 +56,15 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
-    // B staging tasks: thread -> output column c0 + (tid & 127), slots (kh = 0 and 1, kg = tid >> 7)
+    // B staging tasks: thread -> output column (tid & 127), slots (kh = 0 and 1, kg = tid >> 7)
     const int bcol = tid & 127;
-    const bool bok = c0 + bcol < N;
+    const bool bok = bcol < Nv;
     const int bkg = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int blds = bcol * SROW + 4 * bkg;
-    const float* w_lane = W + (int64_t)(bok ? c0 + bcol : N - 1) * K + 4 * bkg;
+    const float* w_lane = Wb + (int64_t)(bok ? bcol : Nv - 1) * ldw + 4 * bkg;
 
     const int arow = wrow0 + l32;
-    const float* a_lane = X + (int64_t)(arow < R ? arow : R - 1) * ldx + 4 * kg;
+    const float* a_lane = Xb + (int64_t)(arow < Rv ? arow : Rv - 1) * ldx + 4 * kg;
     int boff[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) boff[ct] = (32 * ct + l32) * SROW + 4 * kg;
@@ -103,24 +95,117 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const float* __res
 
 #include "split_mfma_pipeline.h"
 
-    // ---- epilogue straight from the accumulators: C/D layout of the 32x32 tile: col = lane & 31,
-    //      row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); one row of a tile = 128 contiguous bytes
+    // ---- epilogue.  Vector path (16-byte aligned rows): accumulators -> LDS (64 rows per pass) -> four threads per
+    // output row write whole float4s (a 32x32 accumulator tile by itself only offers 4-byte stores, 128 bytes per
+    // row and instruction).  C/D layout of the tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    const bool vec_ok = ((Nstore & 3) == 0) && ((ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(Yb) & 15) == 0);
+    if (vec_ok) {
+        constexpr int LDO = 128 + 8;
+        float* Os = reinterpret_cast<float*>(smem);
+        const int erow = tid >> 2, eq = tid & 3;
+        __syncthreads();                               // the last step's (unused) fragment reloads have retired
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) __syncthreads();
+            if ((w >> 1) == pass) {
+                const int lrow0 = WROWS * (w & 1) + 4 * kg;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Os[(lrow0 + (r & 3) + 8 * (r >> 2)) * LDO + 32 * ct + l32] = acc[ct][r];
+            }
+            __syncthreads();
+            const int row = 64 * pass + erow;
+            if (row < Rv) {
+                float* yrow = Yb + (int64_t)row * ldy;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 4 * (eq + 4 * j);
+                    if (c >= Nstore) continue;
+                    float4 v = *reinterpret_cast<const float4*>(&Os[erow * LDO + c]);
+                    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (c + e < Nv) ? o[e] + (bias ? bias[c + e] : 0.f) : 0.f;
+                    if (accumulate) {
+                        const float4 old = *reinterpret_cast<const float4*>(yrow + c);
+                        o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+                    }
+                    if (act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                    }
+                    *reinterpret_cast<float4*>(yrow + c) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        return;
+    }
+    // scalar path straight from the accumulators
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        const int c = c0 + 32 * ct + l32;
-        if (c >= N) continue;
-        const float bb = bias ? bias[c] : 0.f;
+        const int c = 32 * ct + l32;
+        if (c >= Nstore) continue;
+        const float bb = (bias && c < Nv) ? bias[c] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            if (row >= R) continue;
-            float v = acc[ct][r] + bb;
-            float* y = Y + (int64_t)row * ldy + c;
+            if (row >= Rv) continue;
+            // columns Nv <= c < Nstore: the fast chunk body stages a clamped row there, the value is not a product
+            float v = (c < Nv) ? acc[ct][r] + bb : 0.f;
+            float* y = Yb + (int64_t)row * ldy + c;
             if (accumulate) v += *y;
             if (act == 1) v = fmaxf(v, 0.f);
             *y = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256, 2) void linear_split_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ Y,
+                                                              int R, int K, int N, int ldx, int ldy, int act,
+                                                              int accumulate) {
+    // column blocks fastest: the column blocks of one X strip run back to back and share it through L2
+    const int nbn = (N + 127) / 128;
+    const int bm = blockIdx.x / nbn;
+    const int bn = blockIdx.x - bm * nbn;
+    const int r0 = bm * 128, c0 = bn * 128;
+    const int Rv = (R - r0 < 128) ? R - r0 : 128;
+    const int Nv = (N - c0 < 128) ? N - c0 : 128;
+    split_gemm_block(X + (int64_t)r0 * ldx, W + (int64_t)c0 * K, bias ? bias + c0 : nullptr, Y + (int64_t)r0 * ldy + c0, Rv,
+                     Nv, Nv, K, ldx, K, ldy, act, accumulate);
+}
+
+// K6' on the same path: dtiles_{i,m}[p, q] (+)= X[(m,p), :] . Y[(m,q), :]  (the adjacency gradient dA = dOut . H^T on the
+// block-tile pattern; replaces the dense (MN x MN) product of SpmmBackward, reference model_GCN.py:178).  One workgroup
+// per 128 x 128 block of a tile; XCD mapping blockIdx % 8 == dialogue % 8 as in K6.
+__global__ __launch_bounds__(256, 2) void tile_dot_split_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                                float* __restrict__ out_tiles,
+                                                                const int32_t* __restrict__ dia_len,
+                                                                const int32_t* __restrict__ row_start,
+                                                                const int64_t* __restrict__ tile_base, int B, int M, int N,
+                                                                int K, int ldx, int ldy, int max_rb, int accumulate) {
+    const int Rt = max_rb * max_rb;
+    const int Rd = M * Rt;
+    const int bid = blockIdx.x;
+    const int yq = bid >> 3;
+    const int i = (yq / Rd) * 8 + (bid & 7);
+    if (i >= B) return;
+    const int rho = yq % Rd;
+    const int m = rho / Rt;
+    const int rb = (rho - m * Rt) / max_rb;
+    const int cb = (rho - m * Rt) - rb * max_rb;
+    const int L = dia_len[i];
+    const int r0 = rb * 128, c0 = cb * 128;
+    if (r0 >= L || c0 >= L) return;
+    const int ld = (L + 3) & ~3;
+    const int rs = row_start[i];
+    const float* Xm = X + ((int64_t)m * N + rs + r0) * ldx;
+    const float* Ym = Y + ((int64_t)m * N + rs + c0) * ldy;
+    float* T = out_tiles + tile_base[i] + (int64_t)m * L * ld + (int64_t)r0 * ld + c0;
+    const int Rv = (L - r0 < 128) ? L - r0 : 128;
+    const int Nv = (L - c0 < 128) ? L - c0 : 128;
+    const int Ns = (ld - c0 < 128) ? ld - c0 : 128;
+    split_gemm_block(Xm, Ym, nullptr, T, Rv, Nv, Ns, K, ldx, ldy, ld, 0, accumulate);
 }
 
 }  // namespace
@@ -132,6 +217,20 @@ int mmdfn_launch_linear_split(const float* X, const float* W, const float* bias,
     const int lds_bytes = 2 * 3 * 128 * SROW * 4;
     dim3 grid(((R + 127) / 128) * ((N + 127) / 128));
     hipLaunchKernelGGL(linear_split_kernel, grid, dim3(256), lds_bytes, s, X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+// EPI 0 (dtiles (+)= X . Y^T) only; -2: shape not covered
+int mmdfn_launch_tile_dot_split(const float* X, const float* Y, float* out_tiles, const int32_t* dia_len,
+                                const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx,
+                                int ldy, int max_len, int accumulate, hipStream_t s) {
+    if (K < 8 || (K & 3) || (ldx & 3) || (ldy & 3)) return -2;
+    const int max_rb = (max_len + 127) / 128;
+    const int lds_bytes = 2 * 3 * 128 * SROW * 4;
+    dim3 grid(((B + 7) / 8) * 8 * M * max_rb * max_rb);
+    hipLaunchKernelGGL(tile_dot_split_kernel, grid, dim3(256), lds_bytes, s, X, Y, out_tiles, dia_len, row_start, tile_base,
+                       B, M, N, K, ldx, ldy, max_rb, accumulate);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

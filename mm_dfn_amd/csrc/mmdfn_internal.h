@@ -49,6 +49,10 @@ int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const f
 int mmdfn_launch_linear_split(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N, int ldx,
                               int ldy, int act, int accumulate, hipStream_t s);
 
+int mmdfn_launch_tile_dot_split(const float* X, const float* Y, float* out_tiles, const int32_t* dia_len,
+                                const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx,
+                                int ldy, int max_len, int accumulate, hipStream_t s);
+
 // EPI 0: dtiles (+)= X.Y^T ; EPI 1: cosine Gram + raw similarity + row degree
 int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
                           const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,

@@ -311,6 +311,15 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
                           hipStream_t s) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 3) || max_len <= 0) return -1;
     if (ldx < K || ldy < K || (ldx & 3) || (ldy & 3)) return -1;
+    const char* sp = getenv("MMDFN_TILEDOT_SPLIT");   // tuning aid: 1 = always the bf16-piece kernel, 0 = never
+    const int mrb = (max_len + 127) / 128;
+    const bool want_split = sp ? (sp[0] == '1') : (max_len >= 128 && (long)B * M * mrb * mrb >= 48);
+    if (epi == 0 && want_split) {
+        // long dialogues: 128 x 128 blocks on the bf16 matrix path (three exact bf16 pieces per operand, linear_split.hip)
+        const int rc = mmdfn_launch_tile_dot_split(X, Y, out_tiles, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy,
+                                                   max_len, accumulate, s);
+        if (rc != -2) return rc;
+    }
     const char* e = getenv("MMDFN_TILEDOT_V1");   // A/B aid: the first-generation kernel
     if (e == nullptr || e[0] == '0') {
         if (K <= 112) return launch_v2<7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);

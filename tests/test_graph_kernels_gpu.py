@@ -365,3 +365,37 @@ def test_linear_bf16_piece_kernel(R, K, N, monkeypatch):
     assert float((y32 - ops.linear_raw(x, w, b, 0)).abs().max()) == 0.0
     monkeypatch.setenv("MMDFN_LIN_CFG", "7")
     assert float((ops.linear_raw(x, w, b, 0) - y32).abs().max()) / scale < 2e-6
+
+
+@pytest.mark.parametrize("lengths,M,d", [([5], 3, 100), ([130, 40, 129], 3, 100), ([257, 31], 2, 200), ([300], 6, 36),
+                                         ([128, 128], 1, 100)])
+def test_tile_outer_bf16_piece_kernel(lengths, M, d, monkeypatch):
+    """K6' (dA = dOut . H^T on the tile pattern) on the bf16-piece path, forced on small and ragged tiles: against a
+    float64 product per tile, zero row padding, accumulate mode, and the f32-MFMA kernel."""
+    rs = np.random.RandomState(41)
+    lay = DialogueLayout.get(lengths, M, DEV)
+    N = sum(lengths)
+    wide = torch.from_numpy(rs.randn(M * N, 2 * d + 4).astype(np.float32)).to(DEV)
+    X, Y = wide[:, :d], wide[:, d + 4:2 * d + 4]          # row-strided views
+    monkeypatch.setenv("MMDFN_TILEDOT_SPLIT", "1")
+    dt, dc = ops.tile_outer_raw(X, Y, lay)
+    monkeypatch.setenv("MMDFN_TILEDOT_SPLIT", "0")
+    dt0, dc0 = ops.tile_outer_raw(X, Y, lay)
+    assert dc.numel() == 0 or abs_err(dc, dc0) == 0.0
+    Xc, Yc = X.double().cpu(), Y.double().cpu()
+    start = 0
+    for i, L in enumerate(lengths):
+        ld = int(lay.ld_host[i]); base = int(lay.tile_base_host[i])
+        for m in range(M):
+            got = dt[base + m * L * ld: base + (m + 1) * L * ld].view(L, ld).double().cpu()
+            want = Xc[m * N + start:m * N + start + L] @ Yc[m * N + start:m * N + start + L].t()
+            assert float((got[:, :L] - want).abs().max()) / float(want.abs().max()) < 2e-6
+            if ld > L:
+                assert float(got[:, L:].abs().max()) == 0.0
+        start += L
+    assert float((dt - dt0).abs().max()) / float(dt0.abs().max()) < 2e-6
+    # accumulate into existing gradients
+    monkeypatch.setenv("MMDFN_TILEDOT_SPLIT", "1")
+    acc_t, acc_c = dt0.clone(), dc0.clone()
+    ops.tile_outer_raw(X, Y, lay, dtiles=acc_t, dcross=acc_c)
+    assert float((acc_t - 2 * dt0).abs().max()) / float(dt0.abs().max()) < 4e-6
