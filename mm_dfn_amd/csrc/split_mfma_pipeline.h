@@ -127,8 +127,12 @@
         SPLIT_LOADB(2, 0, 0);
     }
     {
+        // Period C loads chunk min(C+2, last) and cuts chunk min(C+1, last); only the PARTIAL last chunk (K % 32 != 0)
+        // needs clamps and masks, so the clamp/mask-free body runs for C + 2 < nfull, and for every C when K % 32 == 0
+        // (the past-the-end loads then re-read the last full chunk).
+        const int nsafe0 = (nfull == nchunks) ? nchunks : (nfull > 2 ? nfull - 2 : 0);
         int c = 0;
-        for (; c + 3 < nfull; c += 2) {        // steady state: chunks c+1 .. c+3 are full
+        for (; c + 1 < nsafe0; c += 2) {
             SPLIT_BODY(0, c, 0);
             SPLIT_BODY(1, c + 1, 0);
         }
