@@ -106,3 +106,29 @@ def test_speaker_and_modality_embeddings_enabled():
         feats = [a + emb[0], v + emb[1], l2 + emb[2]]
         want = O.mm_gcn(feats, lengths, {"graph_model." + k: t for k, t in sd.items()}, O.default_cfg(2))
     assert abs_err(got, want) < 5e-5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_ragged_batches_against_oracle(seed):
+    """Random batch shapes (B, lengths, speakers, depth, input dims): train-mode (dropout 0) log-probs and the
+    gradients of every live parameter against the CPU oracle."""
+    rs = np.random.RandomState(900 + seed)
+    B = int(rs.randint(1, 7))
+    lengths = [int(x) for x in rs.randint(1, 41, size=B)]
+    cfg = dict(B=B, L=max(lengths), P=int(rs.randint(2, 10)), C=int(rs.choice([6, 7])), nlayers=int(rs.randint(1, 5)),
+               D_t=4 * int(rs.randint(5, 160)), D_a=4 * int(rs.randint(5, 100)), D_v=4 * int(rs.randint(5, 140)))
+    m, logp, params, want = _run_model(cfg, lengths, 950 + seed)
+    assert abs_err(logp, want) < 1e-4
+    checked = 0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
+            continue
+        g_ref = params[k].grad
+        assert g_ref is not None, k
+        if float(g_ref.abs().max()) < 1e-6:
+            assert float(p.grad.abs().max()) < 1e-4, k
+        else:
+            assert rel_err(p.grad, g_ref) < 1e-3, k
+        checked += 1
+    assert checked >= 40
