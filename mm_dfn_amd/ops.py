@@ -3,6 +3,8 @@
 Every function here launches hand-written gfx950 kernels on the current HIP
 stream.  There is no CPU / eager fallback: CPU tensors raise.
 """
+import ctypes
+
 import torch
 
 from . import _hip
@@ -415,7 +417,6 @@ def gemm_tn_grouped(problems):
     ia = _hip.int_array
     nws = lib.mmdfn_gemm_tn_grouped_workspace(n, ia(R), ia(M), ia(N))
     ws = torch.empty(int(nws), dtype=torch.float32, device=A[0].device)
-    import ctypes
     cs_arr = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in cs])
     rc = lib.mmdfn_gemm_tn_grouped(n, _hip.ptr_array(A), _hip.ptr_array(B), _hip.ptr_array(C), cs_arr, ia(R), ia(M), ia(N),
                                    ia([a.stride(0) for a in A]), ia([b.stride(0) for b in B]),
