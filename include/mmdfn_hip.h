@@ -218,6 +218,19 @@ int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, f
 int mmdfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K10  FocalLoss (reference loss.py:14-34) as one launch each way:
+ *   loss = reduce_i( -(1 - pt_i)^gamma * alpha[t_i] * log_prob[i, t_i] ),  pt_i = exp(log_prob[i, t_i]) held constant
+ *   (the reference detaches it), reduce = mean if size_average else sum; alpha (C) may be NULL.
+ *   fwd writes loss[0] and coef[i] = -(1 - pt_i)^gamma * alpha[t_i] * (1/N or 1); the sum is reduced in a fixed order
+ *   (bit-reproducible).  bwd: dlogp[i, c] = (c == t_i) * coef[i] * dloss[0]   (all N*C entries written).
+ *   log_prob: (N, C) contiguous fp32; target: N int64.
+ * ------------------------------------------------------------------------- */
+int mmdfn_focal_loss_fwd(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
+                         int64_t N, int C, float gamma, int size_average, void* stream);
+int mmdfn_focal_loss_bwd(const float* coef, const int64_t* target, const float* dloss, float* dlogp, int64_t N, int C,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

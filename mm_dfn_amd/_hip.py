@@ -35,6 +35,8 @@ SIGNATURES = {
     "mmdfn_gemm_tn": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_gemm_tn_grouped_workspace": [_I, _P, _P, _P],
     "mmdfn_gemm_tn_grouped": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_focal_loss_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
+    "mmdfn_focal_loss_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "mmdfn_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "mmdfn_party_gather": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -1,0 +1,75 @@
+// K10: FocalLoss forward / backward as one launch each.
+//
+// Replaces the gather / exp / pow / mul / mean chain of FocalLoss.forward (reference loss.py:14-34) and its autograd:
+//   logpt_i = log_prob[i, t_i];  pt_i = exp(logpt_i)  (treated as a constant: the reference detaches it, loss.py:26)
+//   loss = reduce_i( -(1 - pt_i)^gamma * alpha[t_i] * logpt_i ),  reduce = mean (size_average) or sum
+//   d loss / d log_prob[i, c] = (c == t_i) * ( -(1 - pt_i)^gamma * alpha[t_i] ) * (1/N or 1)
+// Forward: ONE workgroup walks the rows with a fixed row -> thread assignment and reduces in a fixed tree, so the sum
+// is bit-reproducible (no float atomics); it also stores the per-row coefficient the backward multiplies with.
+#include "mmdfn_internal.h"
+#include "../../include/mmdfn_hip.h"
+
+namespace {
+
+constexpr int FL_NT = 1024;
+
+__global__ __launch_bounds__(FL_NT) void focal_loss_fwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
+                                                               const float* __restrict__ alpha, float* __restrict__ loss,
+                                                               float* __restrict__ coef, int64_t N, int C, float gamma,
+                                                               float scale) {
+    __shared__ float part[FL_NT / 64];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < N; i += FL_NT) {
+        int64_t t = target[i];
+        t = t < 0 ? 0 : (t >= C ? C - 1 : t);          // out-of-range labels are the caller's bug; stay in bounds
+        const float lp = logp[i * C + t];
+        const float pt = expf(lp);
+        float wgt = (gamma == 0.f) ? 1.f : powf(fmaxf(1.f - pt, 0.f), gamma);
+        if (alpha != nullptr) wgt *= alpha[t];
+        coef[i] = -wgt * scale;
+        acc += -wgt * lp;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < FL_NT / 64; ++w) s += part[w];
+        loss[0] = s * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_loss_bwd_kernel(const float* __restrict__ coef, const int64_t* __restrict__ target,
+                                                             const float* __restrict__ dloss, float* __restrict__ dlogp,
+                                                             int64_t N, int C) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= N * C) return;
+    const int64_t i = idx / C;
+    const int c = (int)(idx - i * C);
+    int64_t t = target[i];
+    t = t < 0 ? 0 : (t >= C ? C - 1 : t);
+    dlogp[idx] = (c == t) ? coef[i] * dloss[0] : 0.f;
+}
+
+}  // namespace
+
+extern "C" int mmdfn_focal_loss_fwd(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
+                                    int64_t N, int C, float gamma, int size_average, void* stream) {
+    if (N <= 0 || C <= 0) return -1;
+    const float scale = size_average ? 1.0f / (float)N : 1.0f;
+    hipLaunchKernelGGL(focal_loss_fwd_kernel, dim3(1), dim3(FL_NT), 0, (hipStream_t)stream, logp, target, alpha, loss, coef, N, C,
+                       gamma, scale);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_focal_loss_bwd(const float* coef, const int64_t* target, const float* dloss, float* dlogp, int64_t N,
+                                    int C, void* stream) {
+    if (N <= 0 || C <= 0) return -1;
+    const int64_t total = N * C;
+    hipLaunchKernelGGL(focal_loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coef,
+                       target, dloss, dlogp, N, C);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}

@@ -254,3 +254,28 @@ def test_deepgcn_sibling_against_reference_golden_and_oracle():
     for k in ("linear_l.weight", "lstm_l.weight_hh_l0", "graph_net_a.rnn.weight_hh_l0", "graph_net_l.convs.1.weight",
               "graph_net_v.fcs.0.bias", "smax_fc.weight"):
         assert rel_err(named[k].grad, params[k].grad) < 5e-4, k
+
+
+@pytest.mark.parametrize("gamma,use_alpha,size_average", [(0.0, False, True), (0.5, False, True), (1.0, True, True),
+                                                          (2.0, True, False), (0.5, False, False)])
+def test_fused_focal_loss_kernels_against_oracle(gamma, use_alpha, size_average):
+    """K10 (one launch each way) against the oracle's restatement of loss.py:14-34, incl. pt == 1 rows (log-prob 0),
+    class weights, sum reduction, and an upstream gradient that is not 1."""
+    rs = np.random.RandomState(77)
+    N, C = 1237, 7
+    logp = torch.log_softmax(torch.from_numpy(rs.randn(N, C).astype(np.float32)) * 3, 1)
+    tgt = torch.from_numpy(rs.randint(0, C, size=N))
+    logp[5] = torch.tensor([0.0] + [-100.0] * (C - 1))
+    tgt[5] = 0                                              # pt = 1 exactly: (1 - pt)^gamma = 0 (or 1 at gamma 0)
+    alpha = torch.from_numpy(rs.uniform(0.5, 2.0, size=C).astype(np.float32)) if use_alpha else None
+    lo = logp.clone().requires_grad_(True)
+    want = O.focal_loss(lo, tgt, gamma, alpha, size_average)
+    (want * 1.7).backward()
+    lg = logp.clone().to(DEV).requires_grad_(True)
+    f = FocalLoss(gamma=gamma, alpha=None if alpha is None else alpha.tolist(), size_average=size_average)
+    got = f(lg, tgt.to(DEV))
+    (got * 1.7).backward()
+    assert abs(got.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
+    assert abs_err(lg.grad, lo.grad) <= 1e-6 * max(1.0, float(lo.grad.abs().max()))
+    got2 = f(lg.detach(), tgt.to(DEV))
+    assert got2.item() == got.item()                        # fixed reduction order
