@@ -239,7 +239,10 @@ class DialogueGNNModel(nn.Module):
                      else torch.cat([ea, ev, el], dim=-1))
             z = F.relu(self.dropout_(fused))
             return F.log_softmax(ops.linear(z, self.smax_fc.weight, self.smax_fc.bias), 1), None, None, None, None
-        fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label)
+        if self.use_speaker or self.use_modal:
+            fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label)
+        else:
+            fused = self.graph_model.forward_stacked(feats, seq_lengths, qmask, test_label)
         if self.att_type == 'mfn':
             # re-pad (N, 900) -> (L, B, 900), memory fusion over time, strip again (model.py:1303-1326)
             L, B = U.shape[0], U.shape[1]

@@ -64,9 +64,24 @@ class MM_GCN(nn.Module):
             if 'l' in self.modals:
                 l += emb[2].reshape(1, -1)
         adj = self.create_big_adj(a, v, l, dia_len, self.modals, self.modal_weight)
+        return self._graph(adj, qmask, test_label)
+
+    def _graph(self, adj, qmask, test_label):
         M, N, D = adj.stacked_feats.shape
         features = self.graph_net(adj.stacked_feats.reshape(M * N, D), None, qmask, adj, test_label)
-        features = torch.cat([features[m * N:(m + 1) * N] for m in range(M)], dim=-1)
+        # cat([F[:N], F[N:2N], ...], -1) (model_mm.py:117) as ONE strided copy: sliced, the backward is M zero-filled
+        # (MN, 300) buffers, M slice copies and M-1 adds
+        features = features.view(M, N, -1).permute(1, 0, 2).reshape(N, -1)
         if self.return_feature:
             return features
         return F.softmax(self.final_fc(features), dim=-1)
+
+    def forward_stacked(self, feats, dia_len, qmask, test_label=False):
+        """Same as forward(a, v, l, ...) for features that are already one (M, N, D) stack in modality order (what the
+        fused encoder epilogue writes): skips the unbind / re-stack round trip and its select-backward zero fills.
+        Not available with use_speaker / use_modal (they edit single modalities in place, model_mm.py:78-93)."""
+        if self.use_speaker or self.use_modal:
+            raise NotImplementedError("forward_stacked: use forward(a, v, l, ...) with use_speaker / use_modal")
+        if feats.dim() != 3 or feats.shape[0] != len(''.join(self.modals)) or feats.shape[0] < 2:
+            raise ValueError("forward_stacked expects a (len(modals), N, D) stack")
+        return self._graph(ops.build_adjacency(feats, dia_len, self.modal_weight), qmask, test_label)
