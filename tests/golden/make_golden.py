@@ -251,6 +251,45 @@ def export_deepgcn():
     print("deepgcn ok")
 
 
+ENC_CASES = {  # name: (L, P, lengths): SURVEY 8c G4
+    "l15_p3": (15, 3, [15, 6, 11]),
+    "l33_p9": (33, 9, [33, 9, 1, 20]),
+    "l110_p2": (110, 2, [110, 47]),
+}
+
+
+def export_encoders_and_graphconv():
+    """G4: the speaker-aware encoder stack in isolation (what DialogueGNNModel hands to MM_GCN: features_a / _v / _l,
+    model.py:1062-1209), captured with a forward pre-hook on graph_model.  G2: GraphConvolution.forward at layer
+    indices 1, 2, 16 (model_GCN.py:176-189)."""
+    _, _, ref_gcn, _ = ref_shim.modules()
+    out = {}
+    for name, (L, P, lengths) in ENC_CASES.items():
+        cfg = dict(B=len(lengths), L=L, P=P, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+        m = ref_model(cfg, 600, 0.0).eval()
+        batch = synthetic.make_batch(601, lengths=lengths, **cfg)
+        grabbed = []
+        h = m.graph_model.register_forward_pre_hook(lambda mod, args: grabbed.append([t.detach().clone() for t in args[:3]]))
+        with torch.no_grad():
+            m(batch["textf"], batch["qmask"], batch["umask"], batch["lengths"], batch["acouf"], batch["visuf"])
+        h.remove()
+        a, v, l = grabbed[0]
+        out["enc_%s" % name] = torch.stack([a, v, l], 0).numpy()
+    rs = np.random.RandomState(610)
+    n = 37
+    conv = ref_gcn.GraphConvolution(100, 100, variant=True)
+    conv.load_state_dict(synthetic.seeded_state_dict(conv.state_dict(), 611))
+    x = torch.from_numpy(rs.randn(n, 100).astype(np.float32))
+    h0 = torch.from_numpy(rs.randn(n, 100).astype(np.float32))
+    adj = torch.from_numpy(rs.uniform(0, 1, size=(n, n)).astype(np.float32))
+    adj = adj / adj.sum(1, keepdim=True)
+    for l in (1, 2, 16):
+        with torch.no_grad():
+            out["gconv_l%d" % l] = conv(x, adj, h0, 0.5, 0.2, l).numpy()
+    np.savez_compressed(os.path.join(HERE, "encoders_graphconv.npz"), **out)
+    print("encoders + graphconv ok")
+
+
 def export_state_keys():
     m = ref_shim.build_reference_model(100, 1582, 342, 2, 6, 2)
     keys = ["%s %s" % (k, "x".join(map(str, v.shape))) for k, v in m.state_dict().items()]
@@ -263,6 +302,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     export_state_keys()
     export_fusion_modules()
+    export_encoders_and_graphconv()
     export_deepgcn()
     export_focal()
     export_adjacency()

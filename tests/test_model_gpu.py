@@ -279,3 +279,35 @@ def test_fused_focal_loss_kernels_against_oracle(gamma, use_alpha, size_average)
     assert abs_err(lg.grad, lo.grad) <= 1e-6 * max(1.0, float(lo.grad.abs().max()))
     got2 = f(lg.detach(), tgt.to(DEV))
     assert got2.item() == got.item()                        # fixed reduction order
+
+
+@pytest.mark.parametrize("name", ["l15_p3", "l33_p9", "l110_p2"])
+def test_encoder_stack_on_device_against_reference_golden(name):
+    """G4 on the HIP path: DialogueGNNModel.encode (fused projections, party gather, both BiGRUs in shared launches,
+    combine + pad strip) against the features captured from the reference."""
+    from test_oracle_golden import enc_setup
+    g = load("encoders_graphconv.npz")
+    cfg, sd, b, m = enc_setup(name)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        feats = m.encode(b["textf"].to(DEV), b["qmask"].to(DEV), b["lengths"], b["acouf"].to(DEV), b["visuf"].to(DEV))
+    assert np.abs(feats.cpu().numpy() - g["enc_" + name]).max() < 2e-5
+
+
+def test_graph_convolution_module_against_reference_golden():
+    """G2 on the device: the drop-in GraphConvolution with a dense adjacency tensor."""
+    from mm_dfn_amd import GraphConvolution
+    g = load("encoders_graphconv.npz")
+    rs = np.random.RandomState(610)
+    n = 37
+    conv = GraphConvolution(100, 100, variant=True)
+    conv.load_state_dict(synthetic.seeded_state_dict(conv.state_dict(), 611))
+    conv = conv.to(DEV)
+    x = torch.from_numpy(rs.randn(n, 100).astype(np.float32)).to(DEV)
+    h0 = torch.from_numpy(rs.randn(n, 100).astype(np.float32)).to(DEV)
+    adj = torch.from_numpy(rs.uniform(0, 1, size=(n, n)).astype(np.float32))
+    adj = (adj / adj.sum(1, keepdim=True)).to(DEV)
+    for l in (1, 2, 16):
+        with torch.no_grad():
+            assert np.abs(conv(x, adj, h0, 0.5, 0.2, l).cpu().numpy() - g["gconv_l%d" % l]).max() < 1e-5

@@ -177,3 +177,40 @@ def test_deepgcn_oracle_against_reference_golden():
     for k in [f[5:] for f in g.files if f.startswith("grad_")]:
         want = g["grad_" + k]
         assert np.abs(params[k].grad.numpy() - want).max() / np.abs(want).max() < 2e-4, k
+
+
+ENC_CASES = {"l15_p3": (15, 3, [15, 6, 11]), "l33_p9": (33, 9, [33, 9, 1, 20]), "l110_p2": (110, 2, [110, 47])}
+
+
+def enc_setup(name):
+    L, P, lengths = ENC_CASES[name]
+    cfg = dict(B=len(lengths), L=L, P=P, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+    m = synthetic.build_model(**cfg)
+    return cfg, synthetic.seeded_state_dict(m.state_dict(), 600), synthetic.make_batch(601, lengths=lengths, **cfg), m
+
+
+@pytest.mark.parametrize("name", sorted(ENC_CASES))
+def test_encoder_stack_against_reference_golden(name):
+    """the features DialogueGNNModel hands to MM_GCN (projections, context BiGRU, speaker-party BiGRU,
+    pad strip) for 3 / 9 / 2 speakers."""
+    g = load("encoders_graphconv.npz")
+    cfg, sd, b, _ = enc_setup(name)
+    with torch.no_grad():
+        feats = O.encoders(sd, b["textf"], b["qmask"], b["lengths"], b["acouf"], b["visuf"], O.default_cfg(2), engine="aten")
+    got = torch.stack(list(feats), 0).numpy()
+    assert got.shape == g["enc_" + name].shape
+    assert np.abs(got - g["enc_" + name]).max() < 2e-5
+
+
+def test_graph_convolution_against_reference_golden():
+    """GraphConvolution.forward (variant) at layer indices 1, 2, 16."""
+    g = load("encoders_graphconv.npz")
+    rs = np.random.RandomState(610)
+    n = 37
+    w = synthetic.seeded_state_dict({"weight": torch.empty(200, 100)}, 611)["weight"]
+    x = torch.from_numpy(rs.randn(n, 100).astype(np.float32))
+    h0 = torch.from_numpy(rs.randn(n, 100).astype(np.float32))
+    adj = torch.from_numpy(rs.uniform(0, 1, size=(n, n)).astype(np.float32))
+    adj = adj / adj.sum(1, keepdim=True)
+    for l in (1, 2, 16):
+        assert np.abs(O.graph_convolution(x, adj, h0, 0.5, 0.2, l, w).numpy() - g["gconv_l%d" % l]).max() < 1e-5
