@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const floa
             const bool f = (t < L) && (qmask[((int64_t)t * B + b) * P + p] != 0.f);
             const unsigned long long bal = __ballot(f);
             const int pre = __popcll(bal & ((1ull << tid) - 1ull));
-            if (t < L) rank[((int64_t)t * B + b) * P + p] = f ? base + pre : -1;
+            if (t < L && blockIdx.y == 0) rank[((int64_t)t * B + b) * P + p] = f ? base + pre : -1;
             if (f) sel[base + pre] = t;
             base += __popcll(bal);
         }
@@ -53,7 +53,12 @@ __global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const floa
     const int H4 = H / 4;
     const int per_k = Mn * H4;
     const int64_t cols = (int64_t)Mn * B * P;
-    for (int idx = tid; idx < L * per_k; idx += 256) {
+    // the copy is cut into gridDim.y row ranges (B*P workgroups alone leave most of the chip idle; every slice
+    // redoes the cheap scan above)
+    const int kper = (L + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kper;
+    const int k_hi = (k_lo + kper < L) ? k_lo + kper : L;
+    for (int idx = k_lo * per_k + tid; idx < k_hi * per_k; idx += 256) {
         const int k = idx / per_k;
         const int rem = idx - k * per_k;
         const int m = rem / H4;
@@ -169,8 +174,11 @@ extern "C" int mmdfn_party_gather(int Mn, const float* const* X, const float* qm
     if (Mn <= 0 || Mn > MAXMOD || L <= 0 || L > MAXL || B <= 0 || P <= 0 || H <= 0 || (H & 3)) return -1;
     ModPtrs x;
     for (int m = 0; m < MAXMOD; ++m) x.p[m] = m < Mn ? X[m] : nullptr;
-    hipLaunchKernelGGL(party_gather_kernel, dim3(B * P), dim3(256), 0, (hipStream_t)stream, x, qmask, S, rank, L, B, P,
-                       Mn, H);
+    int ny = 1024 / (B * P);                 // aim at ~4 workgroups per CU
+    if (ny > (L + 7) / 8) ny = (L + 7) / 8;  // at least 8 rows per slice
+    if (ny < 1) ny = 1;
+    hipLaunchKernelGGL(party_gather_kernel, dim3(B * P, ny), dim3(256), 0, (hipStream_t)stream, x, qmask, S, rank, L, B,
+                       P, Mn, H);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
