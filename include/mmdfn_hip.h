@@ -175,11 +175,15 @@ int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, cons
                             int L, int B, int P, int N, int H, void* stream);
 
 /* ---------------------------------------------------------------------------
- * K1  dense projection on exact-f32 MFMA (replaces nn.Linear / F.linear / torch.mm on the hot path:
+ * K1  dense projection, fp32 in / fp32 out (replaces nn.Linear / F.linear / torch.mm on the hot path:
  * model.py:1065,1094,1129; the hoisted nn.GRU input contraction; model_GCN.py:454,466,186):
  *   Y[r, n] = act( sum_k X[r, k] W[n, k] + bias[n] ) (+ Y[r, n] if accumulate)
  *   X: R rows of K floats, row stride ldx; W: (N, K) contiguous (nn.Linear layout); bias: N or NULL;
  *   Y: R rows of N floats, row stride ldy.  act: 0 = identity, 1 = ReLU.  K % 4 == 0, ldx % 4 == 0.
+ * Arithmetic: exact-f32 MFMA (v_mfma_f32_16x16x4_f32); launches with >= 384 output tiles of 128 x 128 run on the
+ * bf16 matrix path with every fp32 operand cut exactly into three bf16 pieces and six piece products per MAC
+ * (fp32-level error, < 2e-6 relative to max|Y| on the tested shapes; the same scheme serves K6 / K6' on dialogues
+ * of >= 128 utterances).
  * ------------------------------------------------------------------------- */
 int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N,
                  int ldx, int ldy, int act, int accumulate, void* stream);
