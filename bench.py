@@ -187,16 +187,17 @@ def main():
     n_utt = sum(lengths)
     label = train.flatten_labels(batch["label"], lengths)
     loss_f = FocalLoss(gamma=0.5)
-    dp = distributed.GradientBucket(model) if world > 1 else None
+    # sum-reduce with the 1/world factor folded into the loss scale below: no separate averaging kernel after the all-reduce
+    dp = distributed.GradientBucket(model, average=False) if world > 1 else None
     total_utt = distributed.all_reduce_scalar(n_utt) if world > 1 else n_utt
 
-    scale = (n_utt * world / total_utt) if dp is not None else 1.0
+    scale = (n_utt / total_utt) if dp is not None else 1.0   # local mean -> this rank's share of the GLOBAL mean
 
     def fwd_bwd():
         logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
         loss = loss_f(logp, label)
         if dp is not None:
-            loss = loss * scale        # mean over the GLOBAL utterance count once the bucket is averaged
+            loss = loss * scale        # the summed bucket is then the gradient of the mean over ALL ranks' utterances
         loss.backward()
         return loss
 
