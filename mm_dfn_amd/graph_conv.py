@@ -49,6 +49,11 @@ class GraphConvolution(nn.Module):
         return out
 
 
+def con_width(convs):
+    """Output width of the (uniform) layer stack."""
+    return convs[0].out_features
+
+
 class GCNII_lyc(nn.Module):
     def __init__(self, nfeat, nlayers, nhidden, nclass, dropout, lamda, alpha, variant, return_feature, use_residue,
                  new_graph=False, reason_flag=False):
@@ -106,6 +111,11 @@ class GCNII_lyc(nn.Module):
         if self.reason_flag:
             w_ih, w_hh = self.rnn.weight_ih_l0, self.rnn.weight_hh_l0
             bias = self.rnn.bias_ih_l0 + self.rnn.bias_hh_l0
+        masks = None
+        if self.inner_dropout and self.training and self.dropout > 0:
+            # the keep-masks of all layers in one fill + one dropout launch (already scaled by 1/(1-p))
+            masks = F.dropout(torch.ones(len(self.convs), h0.shape[0], con_width(self.convs), dtype=h0.dtype,
+                                         device=h0.device), self.dropout, True)
         for i, con in enumerate(self.convs):
             q = cur
             if self.reason_flag:
@@ -115,8 +125,8 @@ class GCNII_lyc(nn.Module):
             theta = math.log(self.lamda / (i + 1) + 1)
             S2 = ops.propagate_concat(adj, cur, h0)
             P = ops.matmul_kn(S2, con.weight)
-            cur = ops.gcnii_combine(P, S2, q if self.reason_flag else None,
-                                    self._dropout_mask(P) if self.inner_dropout else None, theta, self.alpha)
+            cur = ops.gcnii_combine(P, S2, q if self.reason_flag else None, None if masks is None else masks[i], theta,
+                                    self.alpha)
         if self.final_dropout:
             cur = F.dropout(cur, self.dropout, training=self.training)
         if self.use_residue:
