@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use GPU 0")
+    ap.add_argument("--deferred-wgrad", action="store_true",
+                    help="queue weight-gradient kernels and issue them on a side stream in batches (overlapping the GRU backward)")
     ap.add_argument("--async-wgrad", action="store_true",
                     help="enqueue weight-gradient kernels on a side stream (measured slower on MI355X: 2.16 vs 1.99 ms)")
     return ap.parse_args()
@@ -201,7 +203,7 @@ def main():
         loss.backward()
         return loss
 
-    ops.set_async_weight_grads(a.async_wgrad)
+    ops.set_async_weight_grads("deferred" if a.deferred_wgrad else a.async_wgrad)
 
     def eager_step():
         model.zero_grad(set_to_none=True)

@@ -52,6 +52,7 @@ class _GruRecurrence(torch.autograd.Function):
         dgh = [torch.empty_like(t) for t in dgi]
         rows = [y.shape[1] for y in ys]
         Ts = [y.shape[0] for y in ys]
+        ops.flush_weight_grads()      # queued weight gradients of later layers overlap this latency-bound recurrence
         rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
                                           _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
                                           _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
@@ -69,9 +70,10 @@ class _GruRecurrence(torch.autograd.Function):
             problems.append(dict(A=d2[:, :3 * H], B=y2[:, :H], C=dwf, colsum=dbf, shift=-R))
             problems.append(dict(A=d2[:, 3 * H:], B=y2[:, H:], C=dwr, colsum=dbr, shift=R))
             out += [dgi[g], dwf, dwr, dbf, dbr]
-        with ops._wgrad_scope(*dgh, *ys):             # off the critical path when the side stream is enabled
+        def launch():
             for i in range(0, len(problems), 8):
                 ops.gemm_tn_grouped(problems[i:i + 8])
+        ops._run_wgrad(launch, list(dgh) + list(ys) + [t for o in out for t in ([o] if torch.is_tensor(o) else [])])
         return tuple(out)
 
 

@@ -434,11 +434,15 @@ def gemm_tn_grouped(problems):
 # mm_dfn_amd.graphs.CapturedStep do.  Off by default: on MI355X at IEMOCAP sizes the fork/join cost outweighs
 # the overlap (cfg2 step 2.16 ms with the side stream vs 1.99 ms without, bench.py --async-wgrad).
 # ---------------------------------------------------------------------------------------------------
-_WG = {"enabled": False, "stream": None, "dirty": False}
+_WG = {"enabled": False, "stream": None, "dirty": False, "pending": []}
 
 
 def set_async_weight_grads(flag):
-    _WG["enabled"] = bool(flag)
+    """False: weight-gradient kernels run in line.  True: each one is forked onto the side stream as it is issued.
+    "deferred": they are queued and issued on the side stream in batches -- right before each GRU backward
+    recurrence (a long, latency-bound launch that leaves most of the chip idle) and at join_weight_grads() -- so a
+    step has two or three fork points instead of ten."""
+    _WG["enabled"] = flag if flag == "deferred" else bool(flag)
 
 
 def async_weight_grads_enabled():
@@ -451,8 +455,34 @@ def _wgrad_stream():
     return _WG["stream"]
 
 
+def _run_wgrad(fn, tensors):
+    """Run (or queue) a weight-gradient launch closure; ``tensors`` are the main-stream buffers it reads / writes."""
+    if _WG["enabled"] == "deferred":
+        _WG["pending"].append((fn, tensors))
+        return
+    with _wgrad_scope(*tensors):
+        fn()
+
+
+def flush_weight_grads():
+    """Issue every queued weight-gradient launch on the side stream behind the current stream's work so far."""
+    if not _WG["pending"]:
+        return
+    pending, _WG["pending"] = _WG["pending"], []
+    side = _wgrad_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for fn, tensors in pending:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(side)
+            fn()
+    _WG["dirty"] = True
+
+
 def join_weight_grads():
     """Make the current stream wait for every weight-gradient kernel launched on the side stream."""
+    flush_weight_grads()
     if _WG["dirty"]:
         torch.cuda.current_stream().wait_stream(_WG["stream"])
         _WG["dirty"] = False
@@ -468,7 +498,7 @@ class _wgrad_scope:
         self.ctx = None
 
     def __enter__(self):
-        if _WG["enabled"]:
+        if _WG["enabled"] is True:
             side = _wgrad_stream()
             side.wait_stream(torch.cuda.current_stream())
             for t in self.tensors:
@@ -527,12 +557,7 @@ class _Linear(torch.autograd.Function):
         dy2 = dy2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            with _wgrad_scope(dy2, x2):
-                if gemm_tn_supported(N, K):
-                    dw, db = gemm_tn(dy2, x2, want_colsum=ctx.has_bias)      # dW and db in one pass over dY
-                else:
-                    dw = dy2.t() @ x2
-                    db = dy2.sum(0) if ctx.has_bias else None
+            (dw, db), = _weight_grads([(dy2, x2, ctx.has_bias)])           # dW and db in one pass over dY
         if ctx.needs_input_grad[0]:
             if N % 4 == 0 and linear_preferred(dy2.shape[0], N, K):
                 dx = linear_raw(dy2, weight.t().contiguous(), None, 0)
@@ -557,8 +582,7 @@ class _MatmulKN(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            with _wgrad_scope(dy, x):
-                dw = gemm_tn(x, dy)[0] if gemm_tn_supported(w.shape[0], w.shape[1]) else x.t() @ dy
+            (dw, _), = _weight_grads([(x, dy, False)])                     # dW = x^T dy
         if ctx.needs_input_grad[0]:
             dx = dy @ w.t()
         return dx, dw
@@ -582,22 +606,28 @@ def _linear_dx(dy2, weight):
 
 def _weight_grads(jobs):
     """jobs: list of (dy2 (R, N), x2 (R, K), want_bias) -> list of (dW (N, K), db or None); every job the split-K
-    kernel covers goes into ONE grouped launch pair (the problems are far too small to fill the chip one by one)."""
-    res = [None] * len(jobs)
-    probs, slots = [], []
-    for i, (dy2, x2, wb) in enumerate(jobs):
+    kernel covers goes into ONE grouped launch pair (the problems are far too small to fill the chip one by one).
+    Outputs are allocated here and filled by a launch closure (run now, forked, or deferred: _run_wgrad)."""
+    res, probs, other = [], [], []
+    for dy2, x2, wb in jobs:
         N, K = dy2.shape[1], x2.shape[1]
+        dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
+        db = torch.empty(N, dtype=torch.float32, device=dy2.device) if wb else None
+        res.append((dw, db))
         if gemm_tn_supported(N, K):
-            dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
-            db = torch.empty(N, dtype=torch.float32, device=dy2.device) if wb else None
             probs.append(dict(A=dy2, B=x2, C=dw, colsum=db))
-            slots.append(i)
-            res[i] = (dw, db)
         else:
-            res[i] = (dy2.t() @ x2, dy2.sum(0) if wb else None)
-    with _wgrad_scope(*[t for j in jobs for t in j[:2]]):
+            other.append((dy2, x2, dw, db))
+
+    def launch():
         for i in range(0, len(probs), 8):
             gemm_tn_grouped(probs[i:i + 8])
+        for dy2, x2, dw, db in other:
+            torch.mm(dy2.t(), x2, out=dw)
+            if db is not None:
+                torch.sum(dy2, 0, out=db)
+
+    _run_wgrad(launch, [t for j in jobs for t in j[:2]] + [t for r in res for t in r])
     return res
 
 
