@@ -325,7 +325,35 @@ def main():
                                     "frac": b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b5,
                                     "avg_launch_us": ms5 * 1e3,
                                     "useful_tflops": lay5.propagate_flops(d) / (ms5 * 1e-3) / 1e12}
-            del f5
+            # K6 backward at the same workload, reported separately: dH = A^T dO (the forward kernel, A is
+            # symmetric) + dA = dO . H^T on the tile pattern (tile_dot + cross_dot); bytes_bwd = 8 nnz + 16 M N d
+            adj5, H5 = mk5()
+            dO5 = torch.randn_like(H5)
+            for _ in range(3):
+                ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
+                ops.tile_outer_raw(dO5, H5, adj5.layout)
+            torch.cuda.synchronize()
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                for _ in range(10):
+                    ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
+                    ops.tile_outer_raw(dO5, H5, adj5.layout)
+            for _ in range(10):
+                gb.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                gb.replay()
+            e1.record()
+            e1.synchronize()
+            msb = e0.elapsed_time(e1) / 50
+            bb = 8 * lay5.nnz + 16 * 6 * sum(l5) * d
+            out["roofline_cfg5_bwd"] = {"workload": "cfg5 backward of one K6 call: dH (propagate) + dA (tile_dot + cross_dot)",
+                                        "bound": "hbm", "achieved": bb / (msb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes": bb, "avg_us": msb * 1e3}
+            del f5, adj5, H5, dO5, gb
         except Exception as exc:
             print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
         if world == 1 and not a.no_extra:
