@@ -158,7 +158,10 @@ int mmdfn_gcnii_combine_bwd(const float* P, const float* S2, const float* mask, 
  *   rank   : (L, B, P) int32 out: position of utterance t inside its party sequence, -1 otherwise
  * combine: out[m][n][:] = base[m][t,b,:] + weights[m] * E[rank[t,b,p*], ((m*B+b)*P+p*), :]
  *   with flat_idx[n] = t*B + b (dialogue-major order), p* = LAST flagged speaker (the reference
- *   scatters speaker by speaker), E = party-GRU output (L, Mn*B*P, H) or NULL; out: (Mn, N, H).
+ *   scatters speaker by speaker), E = party-GRU output or NULL; out: (Mn, N, H).  E holds ONE column block per
+ *   modality whose weight is non-zero, in modality order: (L, nact*B*P, H), column ((slot(m)*B+b)*P+p) with
+ *   slot(m) = #{m' < m : weights[m'] != 0}.  (The reference also encodes the zero-weight modality and multiplies the
+ *   result by 0, model.py:1121; that block is never needed.)
  *   `weights` is a HOST array of Mn floats (speaker_weights, model.py:816).
  * Backward entries: dX / dbase are Mn host-array entries of device (L, B, H) buffers;
  *   combine_bwd expects dbase and dE pre-zeroed (it writes only the rows that exist).

@@ -102,8 +102,13 @@ __global__ void party_combine_kernel(ModPtrs base, const float* __restrict__ E, 
                                      float w1, float w2, float w3, int L, int B, int P, int Mn, int N, int H) {
     const int H4 = H / 4;
     const int64_t total = (int64_t)Mn * N * H4;
-    const int64_t cols = (int64_t)Mn * B * P;
     const float wv[MAXMOD] = {w0, w1, w2, w3};
+    // E holds one column block per modality whose weight is non-zero (a zero weight means the reference computes the
+    // party encoding and multiplies it by 0, model.py:1121: that block is simply not produced here)
+    int slot[MAXMOD], nact = 0;
+#pragma unroll
+    for (int q = 0; q < MAXMOD; ++q) { slot[q] = nact; nact += (q < Mn && wv[q] != 0.f) ? 1 : 0; }
+    const int64_t cols = (int64_t)nact * B * P;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % H4);
@@ -118,9 +123,9 @@ __global__ void party_combine_kernel(ModPtrs base, const float* __restrict__ E, 
             const int k = rank[tb * P + p];
             if (k >= 0) { ps = p; ks = k; }
         }
-        if (ps >= 0 && E != nullptr) {
+        if (ps >= 0 && E != nullptr && wv[m] != 0.f) {
             const float4 e =
-                *reinterpret_cast<const float4*>(E + ((int64_t)ks * cols + ((int64_t)m * B + b) * P + ps) * H + 4 * c4);
+                *reinterpret_cast<const float4*>(E + ((int64_t)ks * cols + ((int64_t)slot[m] * B + b) * P + ps) * H + 4 * c4);
             const float w = wv[m];
             v.x = fmaf(w, e.x, v.x); v.y = fmaf(w, e.y, v.y); v.z = fmaf(w, e.z, v.z); v.w = fmaf(w, e.w, v.w);
         }
@@ -135,8 +140,11 @@ __global__ void party_combine_bwd_kernel(const float* __restrict__ dout, const i
                                          int B, int P, int Mn, int N, int H) {
     const int H4 = H / 4;
     const int64_t total = (int64_t)Mn * N * H4;
-    const int64_t cols = (int64_t)Mn * B * P;
     const float wv[MAXMOD] = {w0, w1, w2, w3};
+    int slot[MAXMOD], nact = 0;
+#pragma unroll
+    for (int q = 0; q < MAXMOD; ++q) { slot[q] = nact; nact += (q < Mn && wv[q] != 0.f) ? 1 : 0; }
+    const int64_t cols = (int64_t)nact * B * P;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % H4);
@@ -152,9 +160,9 @@ __global__ void party_combine_bwd_kernel(const float* __restrict__ dout, const i
             const int k = rank[tb * P + p];
             if (k >= 0) { ps = p; ks = k; }
         }
-        if (ps >= 0 && dE != nullptr) {
+        if (ps >= 0 && dE != nullptr && wv[m] != 0.f) {
             const float w = wv[m];
-            *reinterpret_cast<float4*>(dE + ((int64_t)ks * cols + ((int64_t)m * B + b) * P + ps) * H + 4 * c4) =
+            *reinterpret_cast<float4*>(dE + ((int64_t)ks * cols + ((int64_t)slot[m] * B + b) * P + ps) * H + 4 * c4) =
                 make_float4(w * g.x, w * g.y, w * g.z, w * g.w);
         }
     }

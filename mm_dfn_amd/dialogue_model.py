@@ -217,9 +217,15 @@ class DialogueGNNModel(nn.Module):
         L, B, H = Xa.shape
         idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
         if self.use_crn_speaker:
-            S, rank = ops.party_gather([Xa, Xv, Xl], qmask)
-            ctx, E = self._run_grus([Xl, S], [self.lstm_l, self.rnn_parties])
-            return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
+            # only modalities with a non-zero speaker weight go through the party encoder: the reference also encodes
+            # the others and multiplies the result by 0 (model.py:1090,1121,1154 with '3-0-1'), which changes neither
+            # the features nor any gradient
+            Xs = [Xa, Xv, Xl]
+            act = [x for x, w in zip(Xs, self.speaker_weights) if w != 0.0]
+            if act:
+                S, rank = ops.party_gather(act, qmask)
+                ctx, E = self._run_grus([Xl, S], [self.lstm_l, self.rnn_parties])
+                return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
         ctx = self._run_grus([Xl], [self.lstm_l])[0]
         rank = torch.full((L, B, qmask.shape[2]), -1, dtype=torch.int32, device=Xa.device)
         return ops.party_combine([Xa, Xv, ctx], None, rank, idx, [0.0, 0.0, 0.0])

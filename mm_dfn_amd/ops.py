@@ -292,7 +292,8 @@ def party_gather(Xs, qmask):
 
 
 class _PartyCombine(torch.autograd.Function):
-    """out (Mn, N, H) = strip_pad(base_m + w_m * scatter(E)); E may be None (no speaker encoder)."""
+    """out (Mn, N, H) = strip_pad(base_m + w_m * scatter(E)); E may be None (no speaker encoder), else it holds one
+    (B*P)-column block per modality with a NON-ZERO weight, in modality order."""
 
     @staticmethod
     def forward(ctx, E, rank, flat_idx, weights, *bases):
@@ -319,7 +320,8 @@ class _PartyCombine(torch.autograd.Function):
         L, B, P, H, Mn, N = ctx.dims
         dout = dout.contiguous()
         dbase = torch.zeros(Mn, L, B, H, dtype=torch.float32, device=dout.device)
-        dE = torch.zeros(L, Mn * B * P, H, dtype=torch.float32, device=dout.device) if ctx.has_E else None
+        nact = sum(1 for w in ctx.weights[:Mn] if w != 0.0)
+        dE = torch.zeros(L, nact * B * P, H, dtype=torch.float32, device=dout.device) if ctx.has_E else None
         rc = _hip.lib().mmdfn_party_combine_bwd(Mn, _hip.ptr(dout), _hip.ptr(rank), _hip.ptr(flat_idx),
                                                 _hip.ptr_array([dbase[m] for m in range(Mn)]), _hip.ptr(dE),
                                                 _hip.float_array(ctx.weights), L, B, P, N, H, _hip.stream())

@@ -132,3 +132,32 @@ def test_random_ragged_batches_against_oracle(seed):
             assert rel_err(p.grad, g_ref) < 1e-3, k
         checked += 1
     assert checked >= 40
+
+
+@pytest.mark.parametrize("weights", ["1-2-0.5", "0-0-0", "0-4-0"])
+def test_other_speaker_weight_settings(weights):
+    """speaker_weights other than the scripts' '3-0-1': every modality active, none (the party encoder is skipped
+    altogether), only the visual one -- against the oracle, forward and the encoder gradients."""
+    cfg = dict(B=3, L=12, P=3, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+    lengths = [12, 5, 8]
+    m = synthetic.build_model(speaker_weights=weights, **cfg)
+    sd = synthetic.seeded_state_dict(m.state_dict(), 61)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    b = synthetic.make_batch(62, lengths=lengths, **cfg)
+    logp = m(b["textf"].to(DEV), b["qmask"].to(DEV), b["umask"].to(DEV), b["lengths"], b["acouf"].to(DEV),
+             b["visuf"].to(DEV))[0]
+    R = torch.from_numpy(np.random.RandomState(63).randn(*logp.shape).astype(np.float32))
+    (logp * R.to(DEV)).sum().backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocfg = O.default_cfg(2, speaker_weights=[float(x) for x in weights.split("-")])
+    want = O.forward(params, b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"], ocfg, engine="aten")
+    (want * R).sum().backward()
+    assert abs_err(logp, want) < 1e-4
+    named = dict(m.named_parameters())
+    for k in ("linear_a.weight", "linear_v.weight", "linear_l.weight", "lstm_l.weight_ih_l0", "rnn_parties.weight_hh_l1"):
+        g, gr = named[k].grad, params[k].grad
+        if gr is None or float(gr.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, k
+        else:
+            assert rel_err(g, gr) < 5e-4, k

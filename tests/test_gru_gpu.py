@@ -55,8 +55,9 @@ def test_matches_torch_gru_module_eval():
     assert abs_err(got, want) < 2e-6
 
 
+@pytest.mark.parametrize("w", [[3.0, 0.0, 1.0], [1.0, 2.0, 0.5], [0.0, 0.0, 2.0]])
 @pytest.mark.parametrize("P,lengths", [(2, [15, 9, 1, 6]), (9, [12, 12, 3]), (3, [1]), (2, [110, 64, 80])])
-def test_party_gather_combine_kernels_match_index_composition(P, lengths):
+def test_party_gather_combine_kernels_match_index_composition(P, lengths, w):
     """K3/K4 kernels vs the torch index-op composition (itself checked against the oracle on CPU in
     tests/test_host_logic.py), forward and backward, including a non-one-hot qmask row."""
     from mm_dfn_amd import ops
@@ -72,7 +73,6 @@ def test_party_gather_combine_kernels_match_index_composition(P, lengths):
     rs = np.random.RandomState(5)
     Xs = [torch.from_numpy(rs.randn(L, B, 200).astype(np.float32)).to(DEV) for _ in range(3)]
     idx = _flat_index(lengths, L, B, DEV)
-    w = [3.0, 0.0, 1.0]
     Wg = torch.from_numpy(rs.randn(3, sum(lengths), 200).astype(np.float32)).to(DEV)
     # reference composition (torch index ops)
     Xr = [x.clone().requires_grad_(True) for x in Xs]
@@ -84,11 +84,15 @@ def test_party_gather_combine_kernels_match_index_composition(P, lengths):
     (outr * Wg).sum().backward()
     # kernels
     Xk = [x.clone().requires_grad_(True) for x in Xs]
-    Sk, rank = ops.party_gather(Xk, q)
+    # the party encoder only sees the modalities with a non-zero weight (E: one column block per such modality)
+    act = [i for i in range(3) if w[i] != 0.0]
+    Sk, rank = ops.party_gather([Xk[i] for i in act], q)
     Ek = torch.tanh(Sk * 0.7 + 0.1)
     outk = ops.party_combine(Xk, Ek, rank, idx, w)
     (outk * Wg).sum().backward()
-    assert abs_err(Sk, Sr) == 0.0
+    BP = B * P
+    for slot, i in enumerate(act):
+        assert abs_err(Sk[:, slot * BP:(slot + 1) * BP], Sr[:, i * BP:(i + 1) * BP]) == 0.0
     assert abs_err(outk, outr) < 1e-6
     for i in range(3):
         assert rel_err(Xk[i].grad, Xr[i].grad) < 1e-6
