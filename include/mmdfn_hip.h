@@ -183,7 +183,7 @@ int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, cons
  *   Y[r, n] = act( sum_k X[r, k] W[n, k] + bias[n] ) (+ Y[r, n] if accumulate)
  *   X: R rows of K floats, row stride ldx; W: (N, K) contiguous (nn.Linear layout); bias: N or NULL;
  *   Y: R rows of N floats, row stride ldy.  act: 0 = identity, 1 = ReLU.  K % 4 == 0, ldx % 4 == 0.
- * Arithmetic: exact-f32 MFMA (v_mfma_f32_16x16x4_f32); launches with >= 384 output tiles of 128 x 128 run on the
+ * Arithmetic: exact-f32 MFMA (v_mfma_f32_16x16x4_f32); launches with >= 256 output tiles of 128 x 128 run on the
  * bf16 matrix path with every fp32 operand cut exactly into three bf16 pieces and six piece products per MAC
  * (fp32-level error, < 2e-6 relative to max|Y| on the tested shapes; the same scheme serves K6 / K6' on dialogues
  * of >= 128 utterances).

@@ -155,7 +155,7 @@ extern "C" int mmdfn_linear(const float* X, const float* W, const float* bias, f
         // 1.5-2x (tools/bench_linear.py: 10560 x 200 -> 600: 54 -> 33 us; 98304 x 200 -> 100: 79 -> 51 us);
         // with fewer tiles its 4-wave 128 x 128 workgroups leave the chip idle
         const long tiles = (long)((R + 127) / 128) * ((N + 127) / 128);
-        if (tiles >= 384 && K >= 32) {
+        if (tiles >= 256 && K >= 32) {
             const int rc = mmdfn_launch_linear_split(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
             if (rc != -2) return rc;
         }

@@ -361,7 +361,7 @@ def linear_preferred(rows, K, N):
     if rows >= 4096 and K <= 256:
         return True
     # many 128 x 128 output tiles: the bf16-piece variant (csrc/linear_split.hip) also wins at long K
-    return ((rows + 127) // 128) * ((N + 127) // 128) >= 384 and K <= 1024
+    return ((rows + 127) // 128) * ((N + 127) // 128) >= 256 and K <= 1024
 
 
 def _strided_rows(t):
