@@ -298,7 +298,7 @@ def main():
                        "utterances_per_gpu": n_utt, "parallelism": "dp%d" % world},
             "with_fused_adam_step": None if adam_ms is None else {"ms_per_step": adam_ms,
                                                                    "value": total_utt / (adam_ms * 1e-3)},
-            "roofline": {"bound": "hbm", "kernel": "propagate_kernel (K6 fwd, d=100)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "propagate_v2_kernel<2,4,2,16,1> (K6 fwd, d=100, exact-f32 MFMA)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3,
                          "traffic": measured_traffic("cfg2") if (a.config == "cfg2" and not a.ragged) else None,
