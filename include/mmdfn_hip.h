@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 2). */
+/* Library / device sanity: returns the ABI version (currently 3). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -155,6 +155,9 @@ int mmdfn_gcnii_combine_bwd(const float* P, const float* S2, const float* mask, 
  *   qmask  : (L, B, P) fp32 speaker flags (non-zero = speaker p utters t in dialogue b)
  *   S      : (L, Mn*B*P, H) out: column ((m*B+b)*P+p) holds speaker p's utterances of dialogue b
  *            compacted to the front in time order, zero rows behind (the party-GRU input)
+ *   bias   : NULL, or H floats added to EVERY row of S.  With it the gather can run after a bias-free projection
+ *            (gather(X) W^T + b == gather(X W^T) + b, padding rows = b): the input contraction of the first party-GRU
+ *            layer then runs over the L*B real utterances instead of the L*P*B mostly-zero party rows
  *   rank   : (L, B, P) int32 out: position of utterance t inside its party sequence, -1 otherwise
  * combine: out[m][n][:] = base[m][t,b,:] + weights[m] * E[rank[t,b,p*], ((m*B+b)*P+p*), :]
  *   with flat_idx[n] = t*B + b (dialogue-major order), p* = LAST flagged speaker (the reference
@@ -166,8 +169,8 @@ int mmdfn_gcnii_combine_bwd(const float* P, const float* S2, const float* mask, 
  * Backward entries: dX / dbase are Mn host-array entries of device (L, B, H) buffers;
  *   combine_bwd expects dbase and dE pre-zeroed (it writes only the rows that exist).
  * ------------------------------------------------------------------------- */
-int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, float* S, int32_t* rank,
-                       int L, int B, int P, int H, void* stream);
+int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, const float* bias, float* S,
+                       int32_t* rank, int L, int B, int P, int H, void* stream);
 int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX,
                            int L, int B, int P, int H, void* stream);
 int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const int32_t* rank,

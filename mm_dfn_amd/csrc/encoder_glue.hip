@@ -28,8 +28,9 @@ struct ModPtrsW {
 
 // S: (L, Mn*B*P, H) with column ((m*B + b)*P + p);  rank: (L, B, P) int32, -1 = not this speaker
 __global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const float* __restrict__ qmask,
-                                                           float* __restrict__ S, int32_t* __restrict__ rank,
-                                                           int L, int B, int P, int Mn, int H) {
+                                                           const float* __restrict__ bias, float* __restrict__ S,
+                                                           int32_t* __restrict__ rank, int L, int B, int P, int Mn,
+                                                           int H) {
     __shared__ int sel[MAXL];
     __shared__ int cnt_s;
     const int b = blockIdx.x / P;
@@ -65,6 +66,10 @@ __global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const floa
         const int c4 = rem - m * H4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < cnt) v = *reinterpret_cast<const float4*>(X.p[m] + ((int64_t)sel[k] * B + b) * H + 4 * c4);
+        if (bias != nullptr) {   // rows gathered AFTER a bias-free projection: every row, padding included, gets the bias
+            const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * c4);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
         *reinterpret_cast<float4*>(S + ((int64_t)k * cols + ((int64_t)m * B + b) * P + p) * H + 4 * c4) = v;
     }
 }
@@ -177,16 +182,16 @@ inline int grid_for(int64_t total) {
 
 }  // namespace
 
-extern "C" int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, float* S, int32_t* rank, int L,
-                                  int B, int P, int H, void* stream) {
+extern "C" int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, const float* bias, float* S,
+                                  int32_t* rank, int L, int B, int P, int H, void* stream) {
     if (Mn <= 0 || Mn > MAXMOD || L <= 0 || L > MAXL || B <= 0 || P <= 0 || H <= 0 || (H & 3)) return -1;
     ModPtrs x;
     for (int m = 0; m < MAXMOD; ++m) x.p[m] = m < Mn ? X[m] : nullptr;
     int ny = 1024 / (B * P);                 // aim at ~4 workgroups per CU
     if (ny > (L + 7) / 8) ny = (L + 7) / 8;  // at least 8 rows per slice
     if (ny < 1) ny = 1;
-    hipLaunchKernelGGL(party_gather_kernel, dim3(B * P, ny), dim3(256), 0, (hipStream_t)stream, x, qmask, S, rank, L, B,
-                       P, Mn, H);
+    hipLaunchKernelGGL(party_gather_kernel, dim3(B * P, ny), dim3(256), 0, (hipStream_t)stream, x, qmask, bias, S, rank,
+                       L, B, P, Mn, H);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -86,8 +86,11 @@ def _layer_params(gru, layer):
     return w_ih, b_ih, hh
 
 
-def bigru2(xs, grus, dropout=0.0, training=False):
-    """xs[g]: (T, rows_g, 200) -> ys[g]: (T, rows_g, 200); grus[g]: the nn.GRU holding group g's weights."""
+def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
+    """xs[g]: (T, rows_g, 200) -> ys[g]: (T, rows_g, 200); grus[g]: the nn.GRU holding group g's weights.
+    gi0[g] (optional): the first layer's gate pre-activations X W_ih^T + b_ih (T, rows_g, 600) computed by the caller
+    (the party encoder projects the L*B utterances once and gathers the result instead of projecting the L*P*B
+    party rows); xs[g] is then ignored."""
     for gru in grus:
         if gru.hidden_size != H or gru.num_layers != 2 or not gru.bidirectional or gru.batch_first:
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
@@ -95,7 +98,12 @@ def bigru2(xs, grus, dropout=0.0, training=False):
     for layer in range(2):
         prm = [_layer_params(gru, layer) for gru in grus]
         # hoisted input contractions (all t, both directions) of every group: one op, one weight-gradient launch
-        gis = ops.linear_group(cur, [p[0] for p in prm], [p[1] for p in prm])
+        pre = gi0 if (layer == 0 and gi0 is not None) else [None] * len(grus)
+        todo = [g for g in range(len(grus)) if pre[g] is None]
+        done = ops.linear_group([cur[g] for g in todo], [prm[g][0] for g in todo], [prm[g][1] for g in todo]) if todo else []
+        gis = list(pre)
+        for g, gi in zip(todo, done):
+            gis[g] = gi
         args = []
         for gi, p in zip(gis, prm):
             args += [gi] + p[2]

@@ -255,22 +255,31 @@ def gcnii_combine(P, S2, q, mask, theta, alpha):
 
 
 class _PartyGather(torch.autograd.Function):
-    """(X_0..X_{Mn-1} each (L,B,H), qmask) -> S (L, Mn*B*P, H); also returns rank (L,B,P) int32 (no grad)."""
+    """(X_0..X_{Mn-1} each (L,B,H) -- or ONE stacked (Mn,L,B,H) tensor --, qmask[, bias]) -> S (L, Mn*B*P, H) (+ bias on
+    every row); also returns rank (L,B,P) int32 (no grad)."""
 
     @staticmethod
-    def forward(ctx, qmask, *Xs):
+    def forward(ctx, qmask, bias, *Xs):
         _hip.require_cuda(qmask, *Xs)
-        Xs = [x.contiguous() for x in Xs]
+        stacked = len(Xs) == 1 and Xs[0].dim() == 4
+        if stacked:
+            X4 = Xs[0].contiguous()
+            mods = [X4[m] for m in range(X4.shape[0])]
+        else:
+            mods = [x.contiguous() for x in Xs]
         qmask = qmask.contiguous()
         L, B, P = qmask.shape
-        H = Xs[0].shape[-1]
-        Mn = len(Xs)
+        H = mods[0].shape[-1]
+        Mn = len(mods)
+        bias_ = bias.contiguous() if bias is not None else None
         S = torch.empty(L, Mn * B * P, H, dtype=torch.float32, device=qmask.device)
         rank = torch.empty(L, B, P, dtype=torch.int32, device=qmask.device)
-        rc = _hip.lib().mmdfn_party_gather(Mn, _hip.ptr_array(Xs), _hip.ptr(qmask), _hip.ptr(S), _hip.ptr(rank), L, B, P,
-                                           H, _hip.stream())
+        rc = _hip.lib().mmdfn_party_gather(Mn, _hip.ptr_array(mods), _hip.ptr(qmask), _hip.ptr(bias_), _hip.ptr(S),
+                                           _hip.ptr(rank), L, B, P, H, _hip.stream())
         _hip.check(rc, "mmdfn_party_gather")
         ctx.dims = (L, B, P, H, Mn)
+        ctx.stacked = stacked
+        ctx.has_bias = bias is not None
         ctx.save_for_backward(rank)
         ctx.mark_non_differentiable(rank)
         return S, rank
@@ -284,11 +293,17 @@ class _PartyGather(torch.autograd.Function):
         rc = _hip.lib().mmdfn_party_gather_bwd(Mn, _hip.ptr(dS), _hip.ptr(rank), _hip.ptr_array([dX[m] for m in range(Mn)]),
                                                L, B, P, H, _hip.stream())
         _hip.check(rc, "mmdfn_party_gather_bwd")
-        return (None,) + tuple(dX[m] for m in range(Mn))
+        dbias = dS.sum((0, 1)) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        if ctx.stacked:
+            return None, dbias, dX
+        return (None, dbias) + tuple(dX[m] for m in range(Mn))
 
 
-def party_gather(Xs, qmask):
-    return _PartyGather.apply(qmask, *Xs)
+def party_gather(Xs, qmask, bias=None):
+    """Xs: list of (L, B, H) tensors or one stacked (Mn, L, B, H) tensor."""
+    if torch.is_tensor(Xs):
+        return _PartyGather.apply(qmask, bias, Xs)
+    return _PartyGather.apply(qmask, bias, *Xs)
 
 
 class _PartyCombine(torch.autograd.Function):
