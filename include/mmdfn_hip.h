@@ -63,6 +63,7 @@ int mmdfn_propagate(const float* tiles, const float* cross, const float* H, floa
  *   dtiles_{i,m}[p,q] (+)= X[(m,p),:] . Y[(m,q),:]
  *   dcross_{mn}[r]    (+)= X[(m,r),:].Y[(n,r),:] + X[(n,r),:].Y[(m,r),:]
  *   with X = dOut, Y = H (row strides ldx / ldy floats).  accumulate != 0 adds into dtiles/dcross.
+ *   Any d % 4 == 0 (wide d runs on the bf16-piece kernel); the adjacency build below needs D <= 512.
  * ------------------------------------------------------------------------- */
 int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, float* dcross,
                      const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,

@@ -345,7 +345,8 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
     if (ldx < K || ldy < K || (ldx & 3) || (ldy & 3)) return -1;
     const char* sp = getenv("MMDFN_TILEDOT_SPLIT");   // tuning aid: 1 = always the bf16-piece kernel, 0 = never
     const int mrb = (max_len + 127) / 128;
-    const bool want_split = sp ? (sp[0] == '1') : (max_len >= 128 && (long)B * M * mrb * mrb >= 48);
+    // (K > 512 has no f32-MFMA instantiation: the register-resident A strip would not fit; the piece kernel walks K)
+    const bool want_split = (K > 512) || (sp ? (sp[0] == '1') : (max_len >= 128 && (long)B * M * mrb * mrb >= 48));
     if (epi == 0 && want_split) {
         // long dialogues: 128 x 128 blocks on the bf16 matrix path (three exact bf16 pieces per operand, linear_split.hip)
         const int rc = mmdfn_launch_tile_dot_split(X, Y, out_tiles, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy,

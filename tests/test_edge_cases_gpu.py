@@ -108,7 +108,7 @@ def test_speaker_and_modality_embeddings_enabled():
     assert abs_err(got, want) < 5e-5
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_random_ragged_batches_against_oracle(seed):
     """Random batch shapes (B, lengths, speakers, depth, input dims): train-mode (dropout 0) log-probs and the
     gradients of every live parameter against the CPU oracle."""
@@ -120,6 +120,25 @@ def test_random_ragged_batches_against_oracle(seed):
     m, logp, params, want = _run_model(cfg, lengths, 950 + seed)
     assert abs_err(logp, want) < 1e-4
     checked = 0
+    ref64 = {}
+
+    def grads_fp64():
+        """The same oracle in float64: second opinion when a pre-activation sits within fp32 rounding of a ReLU kink
+        and two fp32 evaluations land on different sides.  (Seen once in 46 random cases, seed 45 of
+        tools/campaign.sh: the gradient of convs.0.weight moved by 2.4 % between the device / the build container's
+        fp32 oracle on one side and the GPU box's fp32 oracle / fp64 on the other, log-probs equal to 5e-7; every other
+        weight draw on the same shapes agrees to 3e-6.)"""
+        if not ref64:
+            sd = synthetic.seeded_state_dict(m.state_dict(), 950 + seed)
+            b = synthetic.make_batch(950 + seed + 1, lengths=lengths, **cfg)
+            p64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+            out = O.forward(p64, b["textf"].double(), b["qmask"].double(), b["umask"].double(), b["lengths"],
+                            b["acouf"].double(), b["visuf"].double(), O.default_cfg(cfg["nlayers"]), engine="manual")
+            w = torch.from_numpy(np.random.RandomState(950 + seed).randn(*out.shape).astype(np.float32)).double()
+            (out * w).sum().backward()
+            ref64.update({k: v.grad for k, v in p64.items()})
+        return ref64
+
     for k, p in m.named_parameters():
         if p.grad is None:
             assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
@@ -128,8 +147,8 @@ def test_random_ragged_batches_against_oracle(seed):
         assert g_ref is not None, k
         if float(g_ref.abs().max()) < 1e-6:
             assert float(p.grad.abs().max()) < 1e-4, k
-        else:
-            assert rel_err(p.grad, g_ref) < 1e-3, k
+        elif rel_err(p.grad, g_ref) >= 1e-3:
+            assert rel_err(p.grad.double().cpu(), grads_fp64()[k]) < 1e-3, k
         checked += 1
     assert checked >= 40
 
