@@ -280,45 +280,57 @@ int launch(const float* X, const float* Y, float* out_tiles, float* out_aux, flo
     return 0;
 }
 
-// dcross_{mn}[r] (+)= X[(m,r)].Y[(n,r)] + X[(n,r)].Y[(m,r)]   -- one wave per row.
-// Every modality's X and Y row is loaded ONCE into registers (lane k holds elements k, k+64, ...), the M(M-1)/2 pair
-// products are formed from registers and reduced with one butterfly each (the first version re-read the rows from
-// L1 for every pair: 40 us at L=512, M=6).
-template <int MMAX>
+// dcross_{mn}[r] (+)= X[(m,r)].Y[(n,r)] + X[(n,r)].Y[(m,r)]
+// Four rows per wave: a 16-lane group owns one row, lane j of the group holds elements j, j+16, ... of every
+// modality's X and Y row in registers (each loaded ONCE), the M(M-1)/2 pair products are formed from registers and
+// reduced over the 16 lanes with four DPP steps -- all four rows of the wave share every instruction.  (First
+// version: one row per wave, rows re-read from L1 for every pair, 15 full-wave reductions per row: 40 us at L=512,
+// M=6.)
+template <int MMAX, int KSL>
 __global__ __launch_bounds__(256) void cross_dot_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                         float* __restrict__ dcross, int M, int N, int K,
                                                         int ldx, int ldy, int accumulate) {
-    constexpr int KSL = 4;                          // register slices of 64 columns: K <= 256 on the fast path
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool rok = row < N;
+    const int rowc = rok ? row : N - 1;
+    float xv[MMAX][KSL], yv[MMAX][KSL];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int sidx = 0; sidx < KSL; ++sidx) {
+            const int k = j + 16 * sidx;
+            const bool ok = (m < M) && (k < K);
+            xv[m][sidx] = ok ? X[((int64_t)m * N + rowc) * ldx + k] : 0.f;
+            yv[m][sidx] = ok ? Y[((int64_t)m * N + rowc) * ldy + k] : 0.f;
+        }
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int n = m + 1; n < MMAX; ++n) {
+            if (n >= M) continue;
+            float s = 0.f;
+#pragma unroll
+            for (int sidx = 0; sidx < KSL; ++sidx) s += xv[m][sidx] * yv[n][sidx] + xv[n][sidx] * yv[m][sidx];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            if (j == 0 && rok) {
+                const int64_t o = (int64_t)mmdfn_pair_index(m, n, M) * N + row;
+                dcross[o] = accumulate ? dcross[o] + s : s;
+            }
+        }
+}
+
+// any M (<= 9) / K: one wave per row, rows streamed per pair
+__global__ __launch_bounds__(256) void cross_dot_generic_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                                float* __restrict__ dcross, int M, int N, int K,
+                                                                int ldx, int ldy, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
-    if (M <= MMAX && K <= 64 * KSL) {
-        float xv[MMAX][KSL], yv[MMAX][KSL];
-#pragma unroll
-        for (int m = 0; m < MMAX; ++m)
-#pragma unroll
-            for (int sidx = 0; sidx < KSL; ++sidx) {
-                const int k = lane + 64 * sidx;
-                const bool ok = (m < M) && (k < K);
-                xv[m][sidx] = ok ? X[((int64_t)m * N + row) * ldx + k] : 0.f;
-                yv[m][sidx] = ok ? Y[((int64_t)m * N + row) * ldy + k] : 0.f;
-            }
-#pragma unroll
-        for (int m = 0; m < MMAX; ++m)
-#pragma unroll
-            for (int n = m + 1; n < MMAX; ++n) {
-                if (n >= M) continue;
-                float s = 0.f;
-#pragma unroll
-                for (int sidx = 0; sidx < KSL; ++sidx) s += xv[m][sidx] * yv[n][sidx] + xv[n][sidx] * yv[m][sidx];
-                s = wave_sum(s);
-                if (lane == 0) {
-                    const int64_t o = (int64_t)mmdfn_pair_index(m, n, M) * N + row;
-                    dcross[o] = accumulate ? dcross[o] + s : s;
-                }
-            }
-        return;
-    }
     for (int m = 0; m < M; ++m)
         for (int n = m + 1; n < M; ++n) {
             const float* xm = X + ((int64_t)m * N + row) * ldx;
@@ -373,10 +385,16 @@ extern "C" int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, f
                                    max_len, 0, accumulate, s);
     if (rc) return rc;
     if (M > 1 && dcross) {
-        if (M <= 3)
-            hipLaunchKernelGGL(cross_dot_kernel<3>, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy, accumulate);
+#define CROSS_DOT(MM, KS) \
+    hipLaunchKernelGGL((cross_dot_kernel<MM, KS>), dim3((N + 15) / 16), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy, accumulate)
+        if (M <= 3 && d <= 112) CROSS_DOT(3, 7);
+        else if (M <= 3 && d <= 208) CROSS_DOT(3, 13);
+        else if (M <= 6 && d <= 112) CROSS_DOT(6, 7);
+        else if (M <= 6 && d <= 208) CROSS_DOT(6, 13);
         else
-            hipLaunchKernelGGL(cross_dot_kernel<6>, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy, accumulate);
+            hipLaunchKernelGGL(cross_dot_generic_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy,
+                               accumulate);
+#undef CROSS_DOT
         MMDFN_CHECK_LAUNCH();
     }
     return 0;
