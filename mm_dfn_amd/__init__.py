@@ -11,3 +11,4 @@ from .mm_gcn import MM_GCN  # noqa: F401
 from .dialogue_model import DialogueGNNModel  # noqa: F401
 from .loss import FocalLoss  # noqa: F401
 from .fusion import MFN, MMGatedAttention  # noqa: F401
+from .multistream import MultiStreamGraphModel  # noqa: F401

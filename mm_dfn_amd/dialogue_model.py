@@ -155,57 +155,9 @@ class DialogueGNNModel(nn.Module):
             self.smax_fc = nn.Linear(width * len(self.modals), n_classes)
 
     # ------------------------------------------------------------------ encoders
-    @staticmethod
-    def _party_plan(qmask):
-        """Device-side gather/scatter plan of the speaker-party encoder.
-
-        qmask: (L, B, P).  rank[t,b,p] = position of utterance t among speaker p's
-        utterances of dialogue b; src[k,b,p] = time index of the k-th such utterance
-        (L = "none": reads a zero row)."""
-        L, B, P = qmask.shape
-        mask = qmask != 0
-        rank = torch.cumsum(mask.to(torch.int64), 0) - 1
-        t_grid = torch.arange(L, device=qmask.device).view(L, 1, 1).expand(L, B, P)
-        src = torch.full((L + 1, B, P), L, dtype=torch.int64, device=qmask.device)
-        src.scatter_(0, torch.where(mask, rank, torch.full_like(rank, L)), t_grid)
-        src = src[:L]
-        # the reference scatters speaker by speaker, so with a non-one-hot qmask the last speaker wins
-        later = torch.flip(torch.cumsum(torch.flip(mask, [2]).to(torch.int64), 2), [2]) - mask.to(torch.int64)
-        sel = mask & (later == 0)
-        return src, rank.clamp_(min=0), sel
-
-    @staticmethod
-    def _party_gather(X_list, plan):
-        """Per-modality (L, B, H) projections -> (L, Mn*B*P, H) speaker-compacted party sequences."""
-        src, rank, sel = plan
-        L, B, P = src.shape
-        Mn = len(X_list)
-        X = torch.stack(X_list, 0)                                      # (Mn, L, B, H)
-        H = X.shape[-1]
-        Xp = torch.cat([X, X.new_zeros(Mn, 1, B, H)], 1)               # zero row at index L
-        g_idx = src.view(1, L, B, P, 1).expand(Mn, L, B, P, H)
-        S = Xp.unsqueeze(3).expand(Mn, L + 1, B, P, H).gather(1, g_idx)  # (Mn, L, B, P, H)
-        return S.permute(1, 0, 2, 3, 4).reshape(L, Mn * B * P, H)
-
-    @staticmethod
-    def _party_scatter(E, plan, Mn):
-        """(L, Mn*B*P, H) party encodings -> per-modality U_p (L, B, H) at the speakers' own positions."""
-        src, rank, sel = plan
-        L, B, P = src.shape
-        H = E.shape[-1]
-        E = E.view(L, Mn, B, P, H).permute(1, 0, 2, 3, 4)               # (Mn, L, B, P, H)
-        s_idx = rank.view(1, L, B, P, 1).expand(Mn, L, B, P, H)
-        back = E.gather(1, s_idx) * sel.view(1, L, B, P, 1).to(E.dtype)
-        U = back.sum(3)                                                  # (Mn, L, B, H)
-        return [U[i] for i in range(Mn)]
-
     def _run_grus(self, xs, grus):
         """Always the fused HIP recurrence (raises on CPU tensors: there is no fallback)."""
         return fused_gru.bigru2(xs, grus, self.dropout, self.training)
-
-    def _party_encode(self, X_list, plan):
-        E = self._run_grus([self._party_gather(X_list, plan)], [self.rnn_parties])[0]
-        return self._party_scatter(E, plan, len(X_list))
 
     def encode(self, U, qmask, seq_lengths, U_a, U_v):
         """Projection + context BiGRU (text) + speaker-party BiGRU (all modalities) ->

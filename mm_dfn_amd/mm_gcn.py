@@ -76,6 +76,19 @@ class MM_GCN(nn.Module):
             return features
         return F.softmax(self.final_fc(features), dim=-1)
 
+    def forward_streams(self, feats, dia_len, qmask=None, test_label=False):
+        """M-stream entry: ``feats`` is a list of M (N, D) node-feature matrices -- or one (M, N, D) stack -- for
+        2 <= M <= 9 modality streams of the same dialogues.  The reference builds the same graph for subsets of
+        'avl' only (model_mm.py:97-106, M <= 3); the block-tile kernels take any M <= 9, which is what BASELINE
+        config 5 (six streams) runs.  Output (N, M * (D + nhidden)), stream-major columns like model_mm.py:113."""
+        if not torch.is_tensor(feats):
+            feats = torch.stack(list(feats), 0)
+        if feats.dim() != 3 or not 2 <= feats.shape[0] <= 9:
+            raise ValueError("forward_streams expects 2..9 streams of (N, D) features")
+        if self.use_speaker or self.use_modal:
+            raise NotImplementedError("forward_streams: speaker / modality embeddings exist for 'avl' graphs only")
+        return self._graph(ops.build_adjacency(feats, dia_len, self.modal_weight), qmask, test_label)
+
     def forward_stacked(self, feats, dia_len, qmask, test_label=False):
         """Same as forward(a, v, l, ...) for features that are already one (M, N, D) stack in modality order (what the
         fused encoder epilogue writes): skips the unbind / re-stack round trip and its select-backward zero fills.

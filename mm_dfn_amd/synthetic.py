@@ -17,6 +17,14 @@ CONFIGS = {
     "cfg4": dict(B=32, L=110, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512),  # per-GPU shard of 256
 }
 
+# BASELINE.json config 5: long-dialogue stress, six modality streams of 512-d inputs, 8 GCN layers (graph hidden
+# d = 100 as in the reference).  Per-GPU batch 8..32 dialogues; M = 6 is beyond the reference's
+# trimodal wiring, so this runs through mm_dfn_amd.multistream.MultiStreamGraphModel.
+STREAM_CONFIGS = {
+    "cfg5": dict(B=8, L=512, P=2, C=6, nlayers=8, D_streams=[512] * 6),
+    "cfg5_b32": dict(B=32, L=512, P=2, C=6, nlayers=8, D_streams=[512] * 6),
+}
+
 
 def make_lengths(rs, B, L, ragged, min_len=None):
     if not ragged:
@@ -74,3 +82,31 @@ def build_model(D_t, D_a, D_v, P, C, nlayers, dropout=0.0, speaker_weights="3-0-
                             att_type=att_type, Deep_GCN_nlayers=nlayers, dataset="IEMOCAP",
                             use_speaker=False, use_modal=False, reason_flag=reason_flag, multi_modal=True,
                             use_crn_speaker=True, speaker_weights=speaker_weights)
+
+
+def make_stream_batch(seed, B, L, P, C, D_streams, ragged=False, lengths=None, device="cpu", **_):
+    """M-stream counterpart of make_batch: ``streams[m]`` is (L, B, D_m), zero beyond each dialogue's length."""
+    rs = np.random.RandomState(seed)
+    lens = lengths if lengths is not None else make_lengths(rs, B, L, ragged)
+    L = max(lens)
+    B = len(lens)
+    streams = [rs.randn(L, B, int(d)).astype(np.float32) for d in D_streams]
+    spk = rs.randint(0, P, size=(L, B))
+    lab = rs.randint(0, C, size=(B, L)).astype(np.int64)
+    qmask = np.zeros((L, B, P), np.float32)
+    umask = np.zeros((B, L), np.float32)
+    for b, n in enumerate(lens):
+        for s_ in streams:
+            s_[n:, b] = 0
+        qmask[np.arange(n), b, spk[:n, b]] = 1
+        umask[b, :n] = 1
+        lab[b, n:] = 0
+    t = lambda a: torch.from_numpy(a).to(device)
+    return dict(streams=[t(s_) for s_ in streams], qmask=t(qmask), umask=t(umask), label=t(lab),
+                lengths=[int(x) for x in lens])
+
+
+def build_stream_model(D_streams, C, nlayers, dropout=0.0, reason_flag=True, modal_weight=1.0, **_):
+    from .multistream import MultiStreamGraphModel
+    return MultiStreamGraphModel(D_streams, n_classes=C, nlayers=nlayers, dropout=dropout, lamda=0.5, alpha=0.2,
+                                 reason_flag=reason_flag, modal_weight=modal_weight)

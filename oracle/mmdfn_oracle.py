@@ -371,6 +371,17 @@ def forward(params, U, qmask, umask, lengths, U_a, U_v, cfg, training=False, eng
     return head(fused, params, cfg.get("dropout", 0.0), training)
 
 
+def forward_streams(params, U_list, lengths, cfg, training=False):
+    """M-stream composition of the restated pieces (per-stream projection model.py:1065, pad strip :553-565, MM_GCN
+    model_mm.py:77-120, head model.py:1328-1337) for mm_dfn_amd.multistream.MultiStreamGraphModel.  The reference
+    itself stops at three streams (model_mm.py:97-106): for M > 3 this is the oracle's own generalisation of functions
+    that are reference-pinned at M = 2 and 3 (create_big_adj / gcnii_stack take any number of feature matrices)."""
+    feats = [flatten_dialogues(F.linear(u, params["linears.%d.weight" % m], params["linears.%d.bias" % m]), lengths)
+             for m, u in enumerate(U_list)]
+    fused = mm_gcn(feats, lengths, params, cfg, training)
+    return head(fused, params, cfg.get("dropout", 0.0), training)
+
+
 def lengths_from_umask(umask):
     """run_train_erc.py:194."""
     return [int((umask[j] == 1).nonzero().tolist()[-1][0]) + 1 for j in range(len(umask))]

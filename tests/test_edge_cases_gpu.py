@@ -38,7 +38,7 @@ def test_degenerate_dialogue_lengths(lengths):
     assert abs_err(logp, want) < 1e-4
     for k in ("linear_l.weight", "rnn_parties.weight_hh_l0", "graph_model.graph_net.convs.1.weight", "smax_fc.weight"):
         g = dict(m.named_parameters())[k].grad
-        assert rel_err(g, params[k].grad) < 5e-4, k
+        assert rel_err(g, params[k].grad) < 1e-4, k
 
 
 def test_silent_speaker_and_unflagged_utterance():
@@ -51,7 +51,7 @@ def test_silent_speaker_and_unflagged_utterance():
         q[4, 1, :] = 0.0
     m, logp, params, want = _run_model(cfg, [9, 6], 32, edit)
     assert abs_err(logp, want) < 1e-4
-    assert rel_err(m.rnn_parties.weight_ih_l0.grad, params["rnn_parties.weight_ih_l0"].grad) < 5e-4
+    assert rel_err(m.rnn_parties.weight_ih_l0.grad, params["rnn_parties.weight_ih_l0"].grad) < 1e-4
 
 
 @pytest.mark.parametrize("modals", ["av", "al", "vl"])
@@ -79,7 +79,7 @@ def test_two_modality_graph_module(modals, modal_weight):
     (want * w).sum().backward()
     assert abs_err(out, want) < 5e-5
     for k in modals:
-        assert rel_err(dev[k].grad, cpu[k].grad) < 2e-4, k
+        assert rel_err(dev[k].grad, cpu[k].grad) < 1e-4, k
 
 
 def test_speaker_and_modality_embeddings_enabled():
@@ -120,6 +120,7 @@ def test_random_ragged_batches_against_oracle(seed):
     m, logp, params, want = _run_model(cfg, lengths, 950 + seed)
     assert abs_err(logp, want) < 1e-4
     checked = 0
+    unstable = []
     ref64 = {}
 
     def grads_fp64():
@@ -147,10 +148,17 @@ def test_random_ragged_batches_against_oracle(seed):
         assert g_ref is not None, k
         if float(g_ref.abs().max()) < 1e-6:
             assert float(p.grad.abs().max()) < 1e-4, k
-        elif rel_err(p.grad, g_ref) >= 1e-3:
-            assert rel_err(p.grad.double().cpu(), grads_fp64()[k]) < 1e-3, k
+        elif rel_err(p.grad, g_ref) >= 1e-4:                      # gradients to 1e-4 relative
+            # second opinion in float64 at the SAME tolerance; only when the fp32 and fp64 oracles themselves disagree
+            # (a pre-activation within rounding of a ReLU kink: the gradient is discontinuous there) is the case
+            # recorded as unstable instead of failed
+            g64 = grads_fp64()[k]
+            if rel_err(p.grad.double().cpu(), g64) >= 1e-4:
+                assert rel_err(g_ref.double(), g64) >= 1e-4, "%s: device gradient off by %.3g" % (k, rel_err(p.grad, g_ref))
+                unstable.append(k)
         checked += 1
     assert checked >= 40
+    assert len(unstable) <= 2, unstable
 
 
 @pytest.mark.parametrize("weights", ["1-2-0.5", "0-0-0", "0-4-0"])
@@ -179,4 +187,4 @@ def test_other_speaker_weight_settings(weights):
         if gr is None or float(gr.abs().max()) == 0.0:
             assert g is None or float(g.abs().max()) == 0.0, k
         else:
-            assert rel_err(g, gr) < 5e-4, k
+            assert rel_err(g, gr) < 1e-4, k

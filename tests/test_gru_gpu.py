@@ -4,6 +4,7 @@ import pytest
 import torch
 
 import mmdfn_oracle as O
+import mmdfn_vectorised as V
 from mm_dfn_amd import gru as fused
 from mm_dfn_amd import synthetic
 from util import rel_err, abs_err
@@ -58,8 +59,8 @@ def test_matches_torch_gru_module_eval():
 @pytest.mark.parametrize("w", [[3.0, 0.0, 1.0], [1.0, 2.0, 0.5], [0.0, 0.0, 2.0]])
 @pytest.mark.parametrize("P,lengths", [(2, [15, 9, 1, 6]), (9, [12, 12, 3]), (3, [1]), (2, [110, 64, 80])])
 def test_party_gather_combine_kernels_match_index_composition(P, lengths, w):
-    """K3/K4 kernels vs the torch index-op composition (itself checked against the oracle on CPU in
-    tests/test_host_logic.py), forward and backward, including a non-one-hot qmask row."""
+    """K3/K4 kernels vs the torch index-op composition of oracle/mmdfn_vectorised.py (itself checked against the oracle
+    on CPU in tests/test_host_logic.py), forward and backward, including a non-one-hot qmask row."""
     from mm_dfn_amd import ops
     from mm_dfn_amd.dialogue_model import _flat_index
     cfg = dict(B=len(lengths), L=max(lengths), P=P, C=6, nlayers=2, D_t=100, D_a=32, D_v=64)
@@ -76,10 +77,10 @@ def test_party_gather_combine_kernels_match_index_composition(P, lengths, w):
     Wg = torch.from_numpy(rs.randn(3, sum(lengths), 200).astype(np.float32)).to(DEV)
     # reference composition (torch index ops)
     Xr = [x.clone().requires_grad_(True) for x in Xs]
-    plan = m._party_plan(q)
-    Sr = m._party_gather(Xr, plan)
+    plan = V.party_plan(q)
+    Sr = V.party_gather(torch.stack(Xr, 0), plan)
     Er = torch.tanh(Sr * 0.7 + 0.1)      # stand-in for the party GRU (any differentiable row-wise map)
-    Ur = m._party_scatter(Er, plan, 3)
+    Ur = V.party_scatter(Er, plan, 3)
     outr = torch.stack([Xr[i] + w[i] * Ur[i] for i in range(3)], 0).reshape(3, L * B, 200).index_select(1, idx)
     (outr * Wg).sum().backward()
     # kernels

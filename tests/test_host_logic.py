@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import mmdfn_oracle as O
+import mmdfn_vectorised as V
 from mm_dfn_amd import synthetic, train
 from mm_dfn_amd.dialogue_model import DialogueGNNModel
 from mm_dfn_amd.layout import BlockTileAdjacency, DialogueLayout, pair_list
@@ -53,17 +54,17 @@ def test_block_tile_dense_roundtrip():
 
 @pytest.mark.parametrize("P,lengths", [(2, [15, 9, 1, 6]), (9, [12, 12, 3]), (3, [1])])
 def test_party_gather_scatter_match_oracle(P, lengths):
-    """The device-side gather/scatter plan of the speaker-party encoder == the reference's per-(b,p) loops.
-    The GRU itself is applied by the TEST (torch CPU) -- the product has no CPU path."""
+    """The cumulative-sum gather/scatter plan (oracle/mmdfn_vectorised.py: the index-op composition the K3/K4 kernels
+    are checked against on the GPU) == the reference's per-(b,p) loops.  The GRU is applied by the TEST (torch CPU)."""
     cfg = dict(B=len(lengths), L=max(lengths), P=P, C=6, nlayers=2, D_t=100, D_a=32, D_v=64)
     m = synthetic.build_model(**cfg).eval()
     m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 3))
     b = synthetic.make_batch(4, lengths=lengths, **cfg)
     X = [torch.randn(max(lengths), len(lengths), 200) for _ in range(3)]
     with torch.no_grad():
-        plan = m._party_plan(b["qmask"])
-        S = m._party_gather(X, plan)
-        got = m._party_scatter(m.rnn_parties(S)[0], plan, 3)
+        plan = V.party_plan(b["qmask"])
+        S = V.party_gather(torch.stack(X, 0), plan)
+        got = V.party_scatter(m.rnn_parties(S)[0], plan, 3)
         for i in range(3):
             want = O.party_encode(X[i], b["qmask"], dict(m.state_dict()), engine="aten")
             assert (got[i] - want).abs().max() < 1e-5
@@ -89,8 +90,8 @@ def test_party_plan_non_one_hot_last_speaker_wins():
     q[2, 0, :] = 1.0
     X = torch.randn(6, 1, 200)
     with torch.no_grad():
-        plan = m._party_plan(q)
-        got = m._party_scatter(m.rnn_parties(m._party_gather([X], plan))[0], plan, 1)[0]
+        plan = V.party_plan(q)
+        got = V.party_scatter(m.rnn_parties(V.party_gather(X.unsqueeze(0), plan))[0], plan, 1)[0]
         # literal restatement of the reference loops
         U_ = X.transpose(0, 1)
         q_ = q.transpose(0, 1)

@@ -47,7 +47,7 @@ def test_end_to_end_against_reference_golden(name):
         want = g["gd/" + k]
         assert grads[k] is not None, k
         got = _digest(grads[k])
-        assert abs(got[1] - want[1]) / (want[1] + 1e-12) < 5e-4, k
+        assert abs(got[1] - want[1]) / (want[1] + 1e-12) < 2e-4, k
     for k, gr in grads.items():
         if k not in live:
             assert gr is None or float(gr.abs().max()) == 0.0, k
@@ -181,9 +181,27 @@ def test_mfn_fusion_variant_against_reference_golden():
     with torch.no_grad():
         logp = run(m, b)
     assert np.abs(logp.cpu().numpy() - g["e2e_mfn_log_prob"]).max() < 1e-4
-    m.train()
-    run(m, b).sum().backward()
+    # gradients through the memory fusion on the device: the module against the reference's own gradients (G8) ...
+    from mm_dfn_amd import MFN
+    rs = np.random.RandomState(700)
+    mfn = MFN()
+    mfn.load_state_dict(synthetic.seeded_state_dict(mfn.state_dict(), 700))
+    mfn = mfn.to(DEV).eval()
+    x = torch.from_numpy(rs.randn(9, 2, 900).astype(np.float32)).to(DEV).requires_grad_(True)
+    R = torch.from_numpy(rs.randn(9, 2, 400).astype(np.float32)).to(DEV)
+    y = mfn(x)
+    (y * R).sum().backward()
+    assert np.abs(y.detach().cpu().numpy() - g["mfn_y"]).max() < 1e-5
+    assert rel_err(x.grad, torch.from_numpy(g["mfn_dx"])) < 1e-4
+    assert rel_err(mfn.gamma1_fc1.weight.grad, torch.from_numpy(g["mfn_dW"])) < 1e-4
+    # ... and gradients reach every stage of the 'mfn' model (re-pad -> MFN -> strip -> head) on the device
+    m.eval()                                                 # dropouts inactive, gradients still flow
+    logp = run(m, b)
+    W = torch.from_numpy(np.random.RandomState(704).randn(*logp.shape).astype(np.float32)).to(DEV)
+    m.zero_grad(set_to_none=True)
+    (logp * W).sum().backward()
     assert m.mfn.gamma1_fc1.weight.grad is not None and torch.isfinite(m.mfn.gamma1_fc1.weight.grad).all()
+    assert float(m.mfn.lstm_l.weight_hh.grad.abs().max()) > 0 and float(m.linear_l.weight.grad.abs().max()) > 0
 
 
 def test_fused_flat_adam_matches_torch_adam_and_reference_trace():
@@ -253,7 +271,7 @@ def test_deepgcn_sibling_against_reference_golden_and_oracle():
     named = dict(m.named_parameters())
     for k in ("linear_l.weight", "lstm_l.weight_hh_l0", "graph_net_a.rnn.weight_hh_l0", "graph_net_l.convs.1.weight",
               "graph_net_v.fcs.0.bias", "smax_fc.weight"):
-        assert rel_err(named[k].grad, params[k].grad) < 5e-4, k
+        assert rel_err(named[k].grad, params[k].grad) < 1e-4, k
 
 
 @pytest.mark.parametrize("gamma,use_alpha,size_average", [(0.0, False, True), (0.5, False, True), (1.0, True, True),
