@@ -10,8 +10,6 @@ import torch
 
 from . import build as _build
 
-_lib = None
-
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -51,33 +49,47 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+_libs = {}
+_tuning = os.environ.get("MMDFN_TUNING_LIB", "0") == "1"
+
+
+def set_tuning(flag):
+    """Select the -DMMDFN_TUNING build (lib/libmmdfn_hip_tuning.so) for subsequent calls; returns the previous setting.
+    Only tools/ and the variant-forcing kernel tests do this (also: MMDFN_TUNING_LIB=1 in the environment).  It is the
+    one library that honours the MMDFN_* ablation / tiling switches; the production library has none compiled in."""
+    global _tuning
+    prev, _tuning = _tuning, bool(flag)
+    return prev
+
+
 def lib():
     """Load (once) and return the shared library; raises if unavailable."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = _build.LIBPATH
-    if _build.is_stale():
-        # missing or older than the sources: rebuild in place when a compiler is at hand (the GPU box has hipcc)
+    handle = _libs.get(_tuning)
+    if handle is not None:
+        return handle
+    tuning = _tuning
+    path = _build.TUNING_LIBPATH if tuning else _build.LIBPATH
+    if _build.is_stale(tuning):
+        # missing or built from other sources (digest stamp): rebuild in place when a compiler is at hand (the GPU box
+        # has hipcc).  A library that does not match the sources is never loaded.
         try:
-            _build.build(verbose=False)
+            _build.build(verbose=False, tuning=tuning)
         except Exception as e:
-            if not os.path.exists(path):
-                raise HipLibraryError(
-                    "libmmdfn_hip.so not built (%s missing) and could not be built (%s): run `python -m "
-                    "mm_dfn_amd.build` (needs hipcc); the MI355X path has no CPU fallback" % (path, e)) from e
+            raise HipLibraryError(
+                "%s is missing or stale (source digest mismatch) and could not be rebuilt (%s): run `python -m "
+                "mm_dfn_amd.build` (needs hipcc); the MI355X path has no CPU fallback" % (path, e)) from e
     handle = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(handle, name)
         except AttributeError as e:
-            raise HipLibraryError("libmmdfn_hip.so lacks symbol %s (stale build?)" % name) from e
+            raise HipLibraryError("%s lacks symbol %s (stale build?)" % (os.path.basename(path), name)) from e
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int64 if name.endswith("_workspace") else ctypes.c_int
     if handle.mmdfn_abi_version() != ABI_VERSION:
-        raise HipLibraryError("libmmdfn_hip.so ABI version mismatch")
-    _lib = handle
-    return _lib
+        raise HipLibraryError("%s ABI version mismatch" % os.path.basename(path))
+    _libs[tuning] = handle
+    return handle
 
 
 def ptr(t):

@@ -14,6 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmmdfn_hip.so")
+# the same sources with -DMMDFN_TUNING: ablation / tiling overrides read from the environment (tools/ only; the
+# production library above has none of them compiled in)
+TUNING_LIBPATH = os.path.join(LIBDIR, "libmmdfn_hip_tuning.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 ARCH = "gfx950"
 
@@ -40,49 +43,61 @@ def hipcc():
     return exe
 
 
-def build(force=False, verbose=True):
-    """Compile every csrc/*.hip for gfx950 into lib/libmmdfn_hip.so (serialised across processes)."""
+def build(force=False, verbose=True, tuning=False):
+    """Compile every csrc/*.hip for gfx950 into lib/libmmdfn_hip.so (serialised across processes);
+    ``tuning=True`` builds lib/libmmdfn_hip_tuning.so (-DMMDFN_TUNING) instead."""
     import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
     with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)          # one builder at a time (data-parallel ranks share the tree)
         try:
-            return _build_locked(force, verbose)
+            return _build_locked(force, verbose, tuning)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(force, verbose):
-    stamp = os.path.join(LIBDIR, "libmmdfn_hip.sha256")
+def _paths(tuning):
+    lib = TUNING_LIBPATH if tuning else LIBPATH
+    return lib, lib[:-3] + ".sha256", ("tuning_" if tuning else "")
+
+
+def _build_locked(force, verbose, tuning):
+    lib, stamp, prefix = _paths(tuning)
     digest = _digest()
-    if not force and os.path.exists(LIBPATH) and os.path.exists(stamp):
+    if not force and os.path.exists(lib) and os.path.exists(stamp):
         with open(stamp) as fh:
             if fh.read().strip() == digest:
-                return LIBPATH
+                return lib
     objs = []
+    jobs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(LIBDIR, prefix + os.path.basename(src)[:-4] + ".o")
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-c", src, "-o", obj]
+        if tuning:
+            cmd.insert(1, "-DMMDFN_TUNING")
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        jobs.append((cmd, subprocess.Popen(cmd)))            # the translation units are independent: compile in parallel
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIBPATH] + objs
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     with open(stamp, "w") as fh:
         fh.write(digest)
-    return LIBPATH
+    return lib
 
 
-def is_stale():
-    stamp = os.path.join(LIBDIR, "libmmdfn_hip.sha256")
-    if not (os.path.exists(LIBPATH) and os.path.exists(stamp)):
+def is_stale(tuning=False):
+    lib, stamp, _ = _paths(tuning)
+    if not (os.path.exists(lib) and os.path.exists(stamp)):
         return True
     with open(stamp) as fh:
         return fh.read().strip() != _digest()
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv))

@@ -21,8 +21,11 @@ __global__ __launch_bounds__(FL_NT) void focal_loss_fwd_kernel(const float* __re
     float acc = 0.f;
     for (int64_t i = threadIdx.x; i < N; i += FL_NT) {
         int64_t t = target[i];
-        t = t < 0 ? 0 : (t >= C ? C - 1 : t);          // out-of-range labels are the caller's bug; stay in bounds
-        const float lp = logp[i * C + t];
+        // an out-of-range label raises in the reference (gather, loss.py:23).  A kernel cannot raise without a host
+        // sync, so it poisons the loss instead: NaN loss and NaN gradients stop a run as surely, nothing is read out of bounds
+        const bool bad = t < 0 || t >= C;
+        t = bad ? 0 : t;
+        const float lp = bad ? __builtin_nanf("") : logp[i * C + t];
         const float pt = expf(lp);
         float wgt = (gamma == 0.f) ? 1.f : powf(fmaxf(1.f - pt, 0.f), gamma);
         if (alpha != nullptr) wgt *= alpha[t];
@@ -47,9 +50,8 @@ __global__ __launch_bounds__(256) void focal_loss_bwd_kernel(const float* __rest
     if (idx >= N * C) return;
     const int64_t i = idx / C;
     const int c = (int)(idx - i * C);
-    int64_t t = target[i];
-    t = t < 0 ? 0 : (t >= C ? C - 1 : t);
-    dlogp[idx] = (c == t) ? coef[i] * dloss[0] : 0.f;
+    const int64_t t = target[i];
+    dlogp[idx] = (c == t || t < 0 || t >= C) ? coef[i] * dloss[0] : 0.f;   // bad label: coef is NaN, the whole row is poisoned
 }
 
 }  // namespace

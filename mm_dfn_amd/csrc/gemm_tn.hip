@@ -197,10 +197,12 @@ __global__ void gemm_tn_grouped_reduce_kernel(const TnGroups gq) {
 }  // namespace
 
 extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) {
-    if (const char* e = getenv("MMDFN_TN_SPLITS")) {   // tuning aid (tools/bench_gemm_tn.py)
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_TN_SPLITS")) {   // tools/bench_gemm_tn.py
         const int v = atoi(e);
         if (v > 0) return v;
     }
+#endif
     // measured on MI355X (tools/bench_gemm_tn.py): ~330-660 rows per split is the sweet spot for every hot-path
     // shape (R = 1.7k .. 10.5k, outputs 100x200 .. 600x200); more splits only inflate the slab reduction
     (void)M;

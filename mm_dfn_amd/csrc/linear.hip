@@ -137,7 +137,8 @@ extern "C" int mmdfn_linear(const float* X, const float* W, const float* bias, f
                             int ldy, int act, int accumulate, void* stream) {
     if (R <= 0 || K < 4 || N <= 0 || (K & 3) || (ldx & 3) || ldx < K || ldy < N) return -1;
     hipStream_t s = (hipStream_t)stream;
-    const char* e = getenv("MMDFN_LIN_CFG");  // tuning aid; unset in production
+#ifdef MMDFN_TUNING
+    const char* e = getenv("MMDFN_LIN_CFG");  // tools/bench_linear.py
     const int ov = e ? atoi(e) : -1;
     if (ov == 0) return launch<2, 4, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
     if (ov == 1) return launch<1, 7, 4, 1>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
@@ -150,6 +151,9 @@ extern "C" int mmdfn_linear(const float* X, const float* W, const float* bias, f
         const int rc = mmdfn_launch_linear_split(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
         if (rc != -2) return rc;
     }
+#else
+    constexpr int ov = -1;
+#endif
     if (ov != 8) {
         // many 128 x 128 output tiles: the bf16-piece kernel (fp32-level error) outruns the exact-f32 MFMA path
         // 1.5-2x (tools/bench_linear.py: 10560 x 200 -> 600: 54 -> 33 us; 98304 x 200 -> 100: 79 -> 51 us);

@@ -157,9 +157,15 @@ template <int NWR, int NWC, int NCTW, int BKT, int RPW>
 __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_v2_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
-    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl) {
+    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl_arg) {
     // RPW = 16-row tiles per wave: every B fragment read from LDS feeds RPW MFMAs, and the H rows are
     // staged once per 16*RPW*NWR output rows (L2 -> LDS traffic scales with 1 / (RPW*NWR)).
+#ifndef MMDFN_TUNING
+    constexpr int abl = 0;                            // production build: no ablation paths
+    (void)abl_arg;
+#else
+    const int abl = abl_arg;
+#endif
     constexpr int NT = 64 * NWR * NWC;
     constexpr int WROWS = 16 * RPW;                   // rows per wave
     constexpr int BM = WROWS * NWR;
@@ -361,10 +367,16 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
     }
 }
 
+// Ablation / tuning switches exist only in the -DMMDFN_TUNING build (lib/libmmdfn_hip_tuning.so, used by tools/):
+// the production library reads no environment variable and the ablation tests fold away at compile time.
+#ifdef MMDFN_TUNING
 int ablation() {
-    const char* e = getenv("MMDFN_PROP_ABL");  // ablation aid for profiling; unset in production
+    const char* e = getenv("MMDFN_PROP_ABL");
     return e ? atoi(e) : 0;
 }
+#else
+constexpr int ablation() { return 0; }
+#endif
 
 template <int NWR, int NWC, int NCTW, int BKT, int RPW>
 int launch_v2(const float* tiles, const float* cross, const float* H, float* out, const int32_t* dia_len,
@@ -382,10 +394,14 @@ int launch_v2(const float* tiles, const float* cross, const float* H, float* out
     return 0;
 }
 
+#ifdef MMDFN_TUNING
 int tuning_override() {
-    const char* e = getenv("MMDFN_PROP_CFG");  // tuning aid (tools/tune_propagate.py); unset in production
+    const char* e = getenv("MMDFN_PROP_CFG");  // tools/tune_propagate.py
     return e ? atoi(e) : -1;
 }
+#else
+constexpr int tuning_override() { return -1; }
+#endif
 
 template <int NW, int NCT>
 int launch(const float* tiles, const float* cross, const float* H, float* out, const int32_t* dia_len,

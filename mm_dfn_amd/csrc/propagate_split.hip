@@ -50,7 +50,13 @@ template <int ABLC>
 __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
-    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl) {
+    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl_arg) {
+#ifndef MMDFN_TUNING
+    constexpr int abl = 0;                 // production build: no ablation paths
+    (void)abl_arg;
+#else
+    const int abl = abl_arg;
+#endif
     constexpr int NCT = 4;                 // 32-column MFMA tiles
     constexpr int WROWS = 32;              // tile rows per wave
     constexpr int BM = 4 * WROWS;          // 128 tile rows per workgroup
@@ -216,10 +222,14 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     }
 }
 
+#ifdef MMDFN_TUNING
 int split_ablation() {
     const char* e = getenv("MMDFN_PROP_ABL");
     return e ? atoi(e) : 0;
 }
+#else
+constexpr int split_ablation() { return 0; }
+#endif
 
 }  // namespace
 
@@ -232,14 +242,17 @@ int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const f
     const int ncb = (d + 127) / 128;
     const int lds_bytes = 2 * 3 * 128 * SROW * 4;   // 61440 B (>= the 64 x 136 float epilogue staging)
     dim3 grid(((B + 7) / 8) * 8 * M * max_rb * ncb);
-    const char* ac = getenv("MMDFN_SPLIT_ABLC");  // profiling aid: compile-time ablations (1: no cutting, 2: no MFMA)
-    const int ablc = ac ? atoi(ac) : 0;
 #define SPLIT_LAUNCH(A)                                                                                          \
     hipLaunchKernelGGL((propagate_split_kernel<A>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
                        row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation())
+#ifdef MMDFN_TUNING
+    const char* ac = getenv("MMDFN_SPLIT_ABLC");  // compile-time ablations (1: no cutting, 2: no MFMA)
+    const int ablc = ac ? atoi(ac) : 0;
     if (ablc == 1) SPLIT_LAUNCH(1);
     else if (ablc == 2) SPLIT_LAUNCH(2);
-    else SPLIT_LAUNCH(0);
+    else
+#endif
+    SPLIT_LAUNCH(0);
 #undef SPLIT_LAUNCH
     MMDFN_CHECK_LAUNCH();
     return 0;

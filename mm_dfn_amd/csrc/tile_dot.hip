@@ -355,7 +355,11 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
                           hipStream_t s) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 3) || max_len <= 0) return -1;
     if (ldx < K || ldy < K || (ldx & 3) || (ldy & 3)) return -1;
-    const char* sp = getenv("MMDFN_TILEDOT_SPLIT");   // tuning aid: 1 = always the bf16-piece kernel, 0 = never
+#ifdef MMDFN_TUNING
+    const char* sp = getenv("MMDFN_TILEDOT_SPLIT");   // 1 = always the bf16-piece kernel, 0 = never
+#else
+    constexpr const char* sp = nullptr;
+#endif
     const int mrb = (max_len + 127) / 128;
     // (K > 512 has no f32-MFMA instantiation: the register-resident A strip would not fit; the piece kernel walks K)
     const bool want_split = (K > 512) || (sp ? (sp[0] == '1') : (max_len >= 128 && (long)B * M * mrb * mrb >= 48));
@@ -365,7 +369,11 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
                                                    max_len, accumulate, s);
         if (rc != -2) return rc;
     }
+#ifdef MMDFN_TUNING
     const char* e = getenv("MMDFN_TILEDOT_V1");   // A/B aid: the first-generation kernel
+#else
+    constexpr const char* e = nullptr;
+#endif
     if (e == nullptr || e[0] == '0') {
         if (K <= 112) return launch_v2<7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
         if (K <= 208) return launch_v2<13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);

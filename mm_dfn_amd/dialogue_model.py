@@ -24,22 +24,18 @@ from . import gru as fused_gru
 from . import ops
 from .fusion import MFN, MMGatedAttention
 from .graph_conv import GCNII
+from .layout import PinnedLRU
 from .mm_gcn import MM_GCN
 
-_FLAT_CACHE = {}
+_FLAT_CACHE = PinnedLRU(64)
 
 
 def _flat_index(lengths, L, B, device):
     """Row ids t*B+b of the (L*B) padded grid in dialogue-major order (simple_batch_graphify)."""
-    key = (tuple(lengths), L, B, str(device))
-    idx = _FLAT_CACHE.get(key)
-    if idx is None:
-        if len(_FLAT_CACHE) > 64:
-            _FLAT_CACHE.clear()
+    def make():
         parts = [np.arange(int(n), dtype=np.int64) * B + j for j, n in enumerate(lengths)]
-        idx = torch.from_numpy(np.concatenate(parts)).to(device)
-        _FLAT_CACHE[key] = idx
-    return idx
+        return torch.from_numpy(np.concatenate(parts)).to(device)
+    return _FLAT_CACHE.get((tuple(lengths), L, B, str(device)), make)
 
 
 class _Scalar(nn.Module):

@@ -63,8 +63,20 @@ class GradientBucket:
         self.params = None
 
     def flatten(self):
+        live = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
         if self.params is None:
-            self.params = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+            self.params = live
+            self._ids = [id(p) for p in live]
+        elif [id(p) for p in live] != self._ids:
+            # the bucket layout is frozen at the first step (flat optimizer state and all-reduce offsets depend on
+            # it); a parameter that starts / stops receiving a gradient later would silently never be reduced or
+            # updated -- or crash in the pack.  The reference's Adam skips grad-less parameters step by step
+            # (run_train_erc.py:512), so a changing live set needs a new bucket (and optimizer state), not a patch.
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            now, was = set(id(p) for p in live), set(self._ids)
+            raise RuntimeError("GradientBucket: the set of parameters receiving gradients changed since the first step "
+                               "(new: %s; missing: %s)" % (sorted(names[i] for i in now - was),
+                                                           sorted(names[i] for i in was - now)))
         grads = [p.grad.reshape(-1) for p in self.params]
         if self.flat is None:
             self.flat = torch.cat(grads)

@@ -9,6 +9,7 @@ all-reduce / optimizer step can follow each replay.
 import torch
 
 from . import ops
+from .layout import recording
 
 
 class CapturedStep:
@@ -32,14 +33,26 @@ class CapturedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
-        # thread_local: a communication-library watchdog thread polling its own events must not invalidate the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss = step_fn()
-            ops.join_weight_grads()          # side-stream branches rejoin the captured graph here
-            if bucket is not None:
-                bucket.flatten()
+        from . import dialogue_model, layout
+        # the graph bakes raw pointers of the cached index tensors (dialogue layout, pad-strip index): keep every
+        # cache entry used during the capture alive for as long as this object lives, whatever the caches evict
+        with recording(layout._LAYOUT_CACHE, dialogue_model._FLAT_CACHE) as used:
+            # thread_local: a communication-library watchdog thread polling its own events must not invalidate the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = step_fn()
+                ops.join_weight_grads()          # side-stream branches rejoin the captured graph here
+                if bucket is not None:
+                    bucket.flatten()
+        self._pinned = list(used)
         self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        # the parameter storages are baked in as well: a later re-pointing of p.data (FlatAdam._materialise, .to(),
+        # load_state_dict(assign=True)) would make the graph update stale memory -- checked on every replay
+        self._param_ptrs = [(p, p.data_ptr()) for p in model.parameters()]
 
     def replay(self):
+        for p, ptr in self._param_ptrs:
+            if p.data_ptr() != ptr:
+                raise RuntimeError("CapturedStep: a parameter's storage moved after the capture (optimizer "
+                                   "materialisation / .to() / load_state_dict(assign=True)); capture again")
         self.graph.replay()
         return self.loss

@@ -5,11 +5,65 @@ The reference stores the graph as one dense (M*N x M*N) fp32 matrix
 dense L_i x L_i tile plus M(M-1) cross-modal diagonals.  ``BlockTileAdjacency``
 keeps exactly that content (layout documented in include/mmdfn_hip.h).
 """
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
-_LAYOUT_CACHE = {}
-_LAYOUT_CACHE_MAX = 64
+
+class PinnedLRU:
+    """Small LRU of host-built device index tensors keyed by batch signature.
+
+    Entries are evicted one at a time (least recently used first), never wholesale.  A hipGraph bakes the raw device
+    pointers of the entries used while it was captured but holds no Python reference to them, so ``recording()``
+    collects every entry handed out during a capture and the graph's owner (graphs.CapturedStep) keeps that list
+    alive: an evicted entry that a captured step still replays against stays allocated."""
+
+    def __init__(self, maxsize=64):
+        self.maxsize = maxsize
+        self.data = OrderedDict()
+        self._recorders = []
+
+    def get(self, key, make):
+        val = self.data.get(key)
+        if val is None:
+            val = make()
+            self.data[key] = val
+            while len(self.data) > self.maxsize:
+                self.data.popitem(last=False)
+        else:
+            self.data.move_to_end(key)
+        for rec in self._recorders:
+            rec.append(val)
+        return val
+
+    def clear(self):
+        self.data.clear()
+
+    def __len__(self):
+        return len(self.data)
+
+
+class recording:
+    """``with recording(cache_a, cache_b) as used:`` -- every entry the caches hand out inside the block is appended to
+    ``used`` (what a captured step must keep alive)."""
+
+    def __init__(self, *caches):
+        self.caches = caches
+        self.used = []
+
+    def __enter__(self):
+        for c in self.caches:
+            c._recorders.append(self.used)
+        return self.used
+
+    def __exit__(self, *exc):
+        for c in self.caches:
+            c._recorders.remove(self.used)
+        return False
+
+
+_LAYOUT_CACHE = PinnedLRU(64)
 
 
 def pair_list(M):
@@ -49,13 +103,7 @@ class DialogueLayout:
     @staticmethod
     def get(lengths, M, device):
         key = (tuple(int(x) for x in lengths), int(M), str(device))
-        lay = _LAYOUT_CACHE.get(key)
-        if lay is None:
-            if len(_LAYOUT_CACHE) >= _LAYOUT_CACHE_MAX:
-                _LAYOUT_CACHE.clear()
-            lay = DialogueLayout(lengths, M, device)
-            _LAYOUT_CACHE[key] = lay
-        return lay
+        return _LAYOUT_CACHE.get(key, lambda: DialogueLayout(lengths, M, device))
 
     # algorithmic bytes / flops of one propagate call
     def propagate_bytes(self, d):

@@ -50,6 +50,9 @@ class FocalLoss(nn.Module):
             input = input.view(input.size(0), input.size(1), -1).transpose(1, 2).contiguous().view(-1, input.size(1))
         if input.is_cuda and input.dtype == torch.float32 and input.dim() == 2 and target.dtype == torch.int64:
             alpha = self.alpha
+            if alpha is not None and alpha.numel() < input.shape[1]:
+                # the reference's alpha.gather(0, target) raises for such labels (loss.py:29); never read past the table
+                raise IndexError("FocalLoss: alpha has %d entries for %d classes" % (alpha.numel(), input.shape[1]))
             if alpha is not None and (alpha.device != input.device or alpha.dtype != input.dtype):
                 alpha = self.alpha = alpha.to(device=input.device, dtype=input.dtype)
             return _FocalLossHip.apply(input, target, alpha, self.gamma, self.size_average)

@@ -19,6 +19,9 @@ class FlatAdam:
         self.bucket = bucket if bucket is not None else GradientBucket(model, average=True)
         self.t = 0
         self.flat_p = self.m = self.v = None
+        # torch.optim-style handle for LR schedulers: ``step`` reads lr / weight_decay from here
+        self.param_groups = [dict(params=[p for p in model.parameters() if p.requires_grad], lr=self.lr,
+                                  betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)]
 
     def zero_grad(self, set_to_none=True):
         self.model.zero_grad(set_to_none=True)
@@ -45,7 +48,46 @@ class FlatAdam:
         if self.flat_p is None:
             self._materialise()
         self.t += 1
+        grp = self.param_groups[0]
         rc = _hip.lib().mmdfn_adam_step(_hip.ptr(self.flat_p), _hip.ptr(g), _hip.ptr(self.m), _hip.ptr(self.v),
-                                        g.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                        self.t, _hip.stream())
+                                        g.numel(), float(grp["lr"]), self.betas[0], self.betas[1], self.eps,
+                                        float(grp["weight_decay"]), self.t, _hip.stream())
         _hip.check(rc, "mmdfn_adam_step")
+
+    # ---- checkpointing: per-parameter moments under the parameter NAMES (layout-independent, loads into a bucket
+    # whose flat order differs), plus the step count and the hyper-parameters
+    def state_dict(self):
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        state = {}
+        if self.flat_p is not None:
+            off = 0
+            for p in self.bucket.params:
+                n = p.numel()
+                state[names[id(p)]] = dict(exp_avg=self.m[off:off + n].view_as(p).clone(),
+                                           exp_avg_sq=self.v[off:off + n].view_as(p).clone())
+                off += n
+        grp = self.param_groups[0]
+        return dict(step=self.t, lr=float(grp["lr"]), betas=self.betas, eps=self.eps,
+                    weight_decay=float(grp["weight_decay"]), state=state)
+
+    def load_state_dict(self, sd):
+        """Needs the bucket layout, i.e. call after one backward pass (or pass a bucket that has been flattened)."""
+        self.t = int(sd["step"])
+        self.betas, self.eps = (float(sd["betas"][0]), float(sd["betas"][1])), float(sd["eps"])
+        self.param_groups[0]["lr"] = self.lr = float(sd["lr"])
+        self.param_groups[0]["weight_decay"] = self.weight_decay = float(sd["weight_decay"])
+        if not sd["state"]:
+            return
+        if self.bucket.params is None:
+            raise RuntimeError("FlatAdam.load_state_dict: run one backward pass first (the flat layout is the set of "
+                               "parameters that receive gradients)")
+        if self.flat_p is None:
+            self._materialise()
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        off = 0
+        for p in self.bucket.params:
+            n = p.numel()
+            st = sd["state"][names[id(p)]]
+            self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            off += n

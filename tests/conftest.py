@@ -51,3 +51,14 @@ def pytest_sessionstart(session):
     # the CPU oracle is many small torch ops: a few threads beat the 256-thread default of the GPU box
     import torch
     torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+@pytest.fixture
+def kernel_variants(monkeypatch):
+    """For tests that force a specific kernel variant through the MMDFN_* switches: those exist only in the
+    -DMMDFN_TUNING build (lib/libmmdfn_hip_tuning.so), which is selected for the duration of the test; yields
+    ``monkeypatch`` for the setenv / delenv calls."""
+    from mm_dfn_amd import _hip
+    prev = _hip.set_tuning(True)
+    yield monkeypatch
+    _hip.set_tuning(prev)

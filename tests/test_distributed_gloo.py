@@ -83,3 +83,23 @@ def test_shard_dialogues_balanced_and_complete():
     assert sorted(sum(parts, [])) == list(range(8))
     loads = [sum(lengths[i] ** 2 for i in p) for p in parts]
     assert max(loads) / min(loads) < 1.6
+
+
+def test_bucket_rejects_a_changing_live_parameter_set():
+    """A parameter that starts receiving a gradient after the bucket layout was frozen must not be silently skipped."""
+    torch.manual_seed(0)
+    model = Tiny()
+    x = torch.randn(5, 8)
+    bucket = distributed.GradientBucket(model)
+    model(x).sum().backward()
+    bucket.flatten()
+    n0 = bucket.flat.numel()
+    model.zero_grad(set_to_none=True)
+    (model(x).sum() + model.dead(torch.randn(2, 3)).sum()).backward()     # 'dead' comes alive
+    with pytest.raises(RuntimeError, match="dead"):
+        bucket.flatten()
+    assert bucket.flat.numel() == n0
+    model.zero_grad(set_to_none=True)
+    model.a(x).sum().backward()                                            # 'b' gets no gradient this time
+    with pytest.raises(RuntimeError, match="missing"):
+        bucket.flatten()

@@ -57,7 +57,7 @@ SPLIT_CASES = [
 
 
 @pytest.mark.parametrize("lengths,M,d", SPLIT_CASES)
-def test_propagate_bf16_piece_kernel(lengths, M, d, monkeypatch):
+def test_propagate_bf16_piece_kernel(lengths, M, d, kernel_variants):
     """The large-launch variant (three exact bf16 pieces per operand, six MFMA products) forced on every
     shape: same fp32-level tolerance as the f32-MFMA kernel, ragged chunk tails, and tile padding columns
     poisoned with NaN (they are not data and must never reach a product)."""
@@ -70,11 +70,11 @@ def test_propagate_bf16_piece_kernel(lengths, M, d, monkeypatch):
             tiles[base: base + M * L * ld].view(M * L, ld)[:, L:] = float("nan")
     rs = np.random.RandomState(7)
     H = torch.from_numpy(rs.randn(M * sum(lengths), d).astype(np.float32))
-    monkeypatch.setenv("MMDFN_PROP_CFG", "8")
+    kernel_variants.setenv("MMDFN_PROP_CFG", "8")
     out = ops.propagate_raw(tiles, adj.cross, H.to(DEV), lay)
     want = dense.double() @ H.double()
     assert rel_err(out, want) < 1e-5
-    monkeypatch.setenv("MMDFN_PROP_CFG", "9")
+    kernel_variants.setenv("MMDFN_PROP_CFG", "9")
     ref = ops.propagate_raw(tiles, adj.cross, H.to(DEV), lay)
     # both kernels sit at fp32 rounding level against the fp64 product
     e_split = float((out.double().cpu() - want).abs().max())
@@ -82,10 +82,10 @@ def test_propagate_bf16_piece_kernel(lengths, M, d, monkeypatch):
     assert e_split <= 4 * e_f32 + 1e-7
 
 
-def test_propagate_bf16_piece_kernel_is_the_large_launch_default(monkeypatch):
+def test_propagate_bf16_piece_kernel_is_the_large_launch_default(kernel_variants):
     """At the long-dialogue stress shape (L=512, M=6) the dispatcher picks the bf16-piece kernel; results agree
     with the f32-MFMA kernel to fp32 rounding."""
-    monkeypatch.delenv("MMDFN_PROP_CFG", raising=False)
+    kernel_variants.delenv("MMDFN_PROP_CFG", raising=False)
     lengths = [512] * 11 + [300]
     M, d = 6, 100
     rs = np.random.RandomState(8)
@@ -93,7 +93,7 @@ def test_propagate_bf16_piece_kernel_is_the_large_launch_default(monkeypatch):
     adj = ops.build_adjacency(torch.from_numpy(rs.randn(M, N, 200).astype(np.float32)).to(DEV), lengths)
     H = torch.from_numpy(rs.randn(M * N, d).astype(np.float32)).to(DEV)
     out = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
-    monkeypatch.setenv("MMDFN_PROP_CFG", "9")
+    kernel_variants.setenv("MMDFN_PROP_CFG", "9")
     ref = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
     assert float((out - ref).abs().max()) < 2e-6
     assert float((out - ref).abs().max()) > 0.0   # it really was a different kernel
@@ -339,10 +339,10 @@ def test_gemm_tn_grouped_with_row_shifts():
 
 @pytest.mark.parametrize("R,K,N", [(300, 200, 600), (129, 100, 36), (1000, 36, 130), (257, 512, 200), (64, 8, 4),
                                    (2000, 44, 256)])
-def test_linear_bf16_piece_kernel(R, K, N, monkeypatch):
+def test_linear_bf16_piece_kernel(R, K, N, kernel_variants):
     """The many-row projection kernel (three exact bf16 pieces per operand, csrc/linear_split.hip) forced on small
     and ragged shapes: K tails (K % 32 != 0), row / column tails, strided input and output, bias, ReLU, accumulate."""
-    monkeypatch.setenv("MMDFN_LIN_CFG", "7")
+    kernel_variants.setenv("MMDFN_LIN_CFG", "7")
     rs = np.random.RandomState(31)
     xw = torch.from_numpy(rs.randn(R, K + 12).astype(np.float32)).to(DEV)
     x = xw[:, 4:4 + K]                                   # row stride K + 12, 16-byte aligned start
@@ -360,16 +360,16 @@ def test_linear_bf16_piece_kernel(R, K, N, monkeypatch):
     assert float((out.double() - (want - b.double() + 3.0)).abs().max()) / scale < 2e-6
     assert float(wide[:, N:].min()) == 3.0
     # same answer as the exact-f32 MFMA kernel to fp32 rounding
-    monkeypatch.setenv("MMDFN_LIN_CFG", "8")
+    kernel_variants.setenv("MMDFN_LIN_CFG", "8")
     y32 = ops.linear_raw(x, w, b, 0)
     assert float((y32 - ops.linear_raw(x, w, b, 0)).abs().max()) == 0.0
-    monkeypatch.setenv("MMDFN_LIN_CFG", "7")
+    kernel_variants.setenv("MMDFN_LIN_CFG", "7")
     assert float((ops.linear_raw(x, w, b, 0) - y32).abs().max()) / scale < 2e-6
 
 
 @pytest.mark.parametrize("lengths,M,d", [([5], 3, 100), ([130, 40, 129], 3, 100), ([257, 31], 2, 200), ([300], 6, 36),
                                          ([128, 128], 1, 100)])
-def test_tile_outer_bf16_piece_kernel(lengths, M, d, monkeypatch):
+def test_tile_outer_bf16_piece_kernel(lengths, M, d, kernel_variants):
     """K6' (dA = dOut . H^T on the tile pattern) on the bf16-piece path, forced on small and ragged tiles: against a
     float64 product per tile, zero row padding, accumulate mode, and the f32-MFMA kernel."""
     rs = np.random.RandomState(41)
@@ -377,9 +377,9 @@ def test_tile_outer_bf16_piece_kernel(lengths, M, d, monkeypatch):
     N = sum(lengths)
     wide = torch.from_numpy(rs.randn(M * N, 2 * d + 4).astype(np.float32)).to(DEV)
     X, Y = wide[:, :d], wide[:, d + 4:2 * d + 4]          # row-strided views
-    monkeypatch.setenv("MMDFN_TILEDOT_SPLIT", "1")
+    kernel_variants.setenv("MMDFN_TILEDOT_SPLIT", "1")
     dt, dc = ops.tile_outer_raw(X, Y, lay)
-    monkeypatch.setenv("MMDFN_TILEDOT_SPLIT", "0")
+    kernel_variants.setenv("MMDFN_TILEDOT_SPLIT", "0")
     dt0, dc0 = ops.tile_outer_raw(X, Y, lay)
     assert dc.numel() == 0 or abs_err(dc, dc0) == 0.0
     Xc, Yc = X.double().cpu(), Y.double().cpu()
@@ -395,7 +395,7 @@ def test_tile_outer_bf16_piece_kernel(lengths, M, d, monkeypatch):
         start += L
     assert float((dt - dt0).abs().max()) / float(dt0.abs().max()) < 2e-6
     # accumulate into existing gradients
-    monkeypatch.setenv("MMDFN_TILEDOT_SPLIT", "1")
+    kernel_variants.setenv("MMDFN_TILEDOT_SPLIT", "1")
     acc_t, acc_c = dt0.clone(), dc0.clone()
     ops.tile_outer_raw(X, Y, lay, dtiles=acc_t, dcross=acc_c)
     assert float((acc_t - 2 * dt0).abs().max()) / float(dt0.abs().max()) < 4e-6

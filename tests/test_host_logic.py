@@ -152,3 +152,43 @@ def test_mfn_and_gated_attention_modules_against_reference_golden():
     with torch.no_grad():
         assert np.abs(ga(a, v, l, ['a', 'v', 'l']).numpy() - g["gated_avl"]).max() < 1e-6
         assert np.abs(ga(a, [], l, ['a', 'l']).numpy() - g["gated_al"]).max() < 1e-6
+
+
+def test_pinned_lru_evicts_one_at_a_time_and_records_capture_users():
+    from mm_dfn_amd.layout import PinnedLRU, recording
+    c = PinnedLRU(3)
+    made = []
+    mk = lambda k: (lambda: made.append(k) or ("val", k))
+    with recording(c) as used:
+        a = c.get("a", mk("a"))
+        c.get("b", mk("b"))
+    assert used == [("val", "a"), ("val", "b")]
+    c.get("c", mk("c"))
+    c.get("a", mk("a"))                   # hit: refreshes 'a'
+    c.get("d", mk("d"))                   # evicts 'b' only (least recently used)
+    assert list(c.data) == ["c", "a", "d"] and made == ["a", "b", "c", "d"]
+    assert c.get("a", mk("a")) is a
+    c.get("b", mk("b"))                   # 'b' is rebuilt, 'c' goes
+    assert made[-1] == "b" and "c" not in c.data and len(c) == 3
+    # many signatures later the objects recorded during the "capture" are still the caller's to keep alive
+    for i in range(10):
+        c.get(i, mk(i))
+    assert used[0] is a and "a" not in c.data
+
+
+def test_dialogue_layout_cache_is_lru():
+    from mm_dfn_amd import layout
+    layout._LAYOUT_CACHE.clear()
+    first = DialogueLayout.get([3, 2], 3, "cpu")
+    for n in range(70):
+        DialogueLayout.get([n + 1], 3, "cpu")
+        assert DialogueLayout.get([3, 2], 3, "cpu") is first      # kept by use, not wiped with the rest
+    assert len(layout._LAYOUT_CACHE) <= 64
+
+
+def test_focal_loss_alpha_table_must_cover_the_classes():
+    from mm_dfn_amd import FocalLoss
+    f = FocalLoss(gamma=1.0, alpha=0.25)                     # scalar alpha -> 2-entry table (loss.py:9)
+    assert f.alpha.numel() == 2
+    lp = torch.log_softmax(torch.randn(4, 2), 1)
+    assert torch.isfinite(f(lp, torch.tensor([0, 1, 1, 0])))

@@ -68,3 +68,84 @@ def test_load_reference_weights_roundtrip(tmp_path):
     T.load_reference_weights(m2, path)
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_focal_loss_on_device_rejects_bad_alpha_and_poisons_bad_labels():
+    lp = torch.log_softmax(torch.randn(5, 6, device="cuda"), 1).requires_grad_(True)
+    with pytest.raises(IndexError):
+        FocalLoss(gamma=1.0, alpha=0.25)(lp, torch.zeros(5, dtype=torch.int64, device="cuda"))   # 2-entry table, 6 classes
+    tgt = torch.tensor([0, 5, 6, 1, 2], device="cuda")                                           # 6 is out of range
+    loss = FocalLoss(gamma=0.5)(lp, tgt)
+    assert torch.isnan(loss)                  # the reference raises in gather (loss.py:23); a kernel poisons instead
+    loss.backward()
+    assert torch.isnan(lp.grad[2]).all() and torch.isfinite(lp.grad[[0, 1, 3, 4]]).all()
+
+
+def test_flat_adam_state_dict_roundtrip_and_lr_schedule():
+    from mm_dfn_amd.optim import FlatAdam
+    b = synthetic.make_batch(3, lengths=[9, 4], B=2, L=9, **CFG)
+    loss_f = FocalLoss(gamma=0.5)
+
+    def step(m, opt):
+        opt.zero_grad()
+        lp = m(b["textf"].cuda(), b["qmask"].cuda(), b["umask"].cuda(), b["lengths"], b["acouf"].cuda(), b["visuf"].cuda())[0]
+        loss_f(lp, T.flatten_labels(b["label"].cuda(), b["lengths"])).backward()
+        opt.step()
+
+    m1, m2 = _model(11), _model(11)
+    o1 = FlatAdam(m1, lr=1e-3, weight_decay=1e-4)
+    for _ in range(2):
+        step(m1, o1)
+    sd_opt, sd_model = o1.state_dict(), {k: v.clone() for k, v in m1.state_dict().items()}
+    assert sd_opt["step"] == 2 and "smax_fc.weight" in sd_opt["state"] and "gatedatt.transform_l.weight" not in sd_opt["state"]
+    o1.param_groups[0]["lr"] = 5e-4                        # what an LR scheduler does
+    step(m1, o1)
+    # resume: fresh model + optimizer, weights and moments restored, same third step
+    m2.load_state_dict(sd_model)
+    o2 = FlatAdam(m2, lr=123.0)
+    m2.zero_grad(set_to_none=True)
+    lp = m2(b["textf"].cuda(), b["qmask"].cuda(), b["umask"].cuda(), b["lengths"], b["acouf"].cuda(), b["visuf"].cuda())[0]
+    loss_f(lp, T.flatten_labels(b["label"].cuda(), b["lengths"])).backward()
+    o2.bucket.flatten()                                     # fixes the flat layout
+    o2.load_state_dict(sd_opt)
+    assert o2.param_groups[0]["lr"] == 1e-3
+    o2.param_groups[0]["lr"] = 5e-4
+    step(m2, o2)
+    for (k, a), (_, c) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert float((a - c).abs().max()) < 1e-7, k
+
+
+def test_captured_step_pins_cached_index_tensors_and_detects_moved_parameters():
+    from mm_dfn_amd import layout, dialogue_model
+    from mm_dfn_amd.graphs import CapturedStep
+    from mm_dfn_amd.optim import FlatAdam
+    m = _model(13).train()
+    cfg = dict(B=2, L=9, **CFG)
+    b = synthetic.make_batch(3, lengths=[9, 4], device="cuda", **cfg)
+    label = T.flatten_labels(b["label"], b["lengths"])
+    loss_f = FocalLoss(gamma=0.5)
+
+    def fwd_bwd():
+        lp = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+        loss = loss_f(lp, label)
+        loss.backward()
+        return loss
+
+    cap = CapturedStep(m, fwd_bwd, warmup=1)
+    want = float(cap.replay())
+    g0 = m.smax_fc.weight.grad.clone()
+    assert any(isinstance(x, layout.DialogueLayout) for x in cap._pinned) and any(torch.is_tensor(x) for x in cap._pinned)
+    # flood both caches with other batch signatures: the captured step's index tensors are evicted from the caches ...
+    for n in range(80):
+        layout.DialogueLayout.get([n + 1, 2], 3, "cuda")
+        dialogue_model._flat_index([n + 1, 2], n + 1, 2, torch.device("cuda"))
+    junk = [torch.full((4096,), -7, dtype=torch.int64, device="cuda") for _ in range(64)]   # ... and memory is re-used
+    assert all(x not in layout._LAYOUT_CACHE.data.values() for x in cap._pinned if isinstance(x, layout.DialogueLayout))
+    assert float(cap.replay()) == want and torch.equal(m.smax_fc.weight.grad, g0)
+    del junk
+    # re-pointing the parameter storages after the capture is caught instead of silently training stale memory
+    opt = FlatAdam(m, lr=1e-3)
+    opt.bucket.flatten()
+    opt._materialise()
+    with pytest.raises(RuntimeError, match="storage moved"):
+        cap.replay()

@@ -1,6 +1,7 @@
 """Ablation of the propagate kernel phases (MMDFN_PROP_ABL bits: 1 no cross-terms, 2 no MFMA, 4 no H staging loads,
 8 no tile-strip loads).  Prints HIP-event times; workloads large enough that host launch overhead is hidden."""
 import os, sys
+os.environ["MMDFN_TUNING_LIB"] = "1"   # the MMDFN_* switches below exist only in the -DMMDFN_TUNING build
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mm_dfn_amd import ops

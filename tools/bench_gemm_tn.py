@@ -1,5 +1,6 @@
 """Split-K weight-gradient kernel (gemm_tn) vs torch (A.t() @ B + A.sum(0)) on the hot-path shapes."""
 import os, sys
+os.environ["MMDFN_TUNING_LIB"] = "1"   # the MMDFN_* switches below exist only in the -DMMDFN_TUNING build
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mm_dfn_amd import ops, _hip

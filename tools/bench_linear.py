@@ -1,5 +1,6 @@
 """MFMA linear kernel vs torch F.linear (hipBLASLt) on the hot-path shapes; graph-captured timing."""
 import os, sys
+os.environ["MMDFN_TUNING_LIB"] = "1"   # the MMDFN_* switches below exist only in the -DMMDFN_TUNING build
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mm_dfn_amd import ops

@@ -1,6 +1,8 @@
 """Accuracy + timing of the bf16-piece propagate (MMDFN_PROP_CFG=8) against the exact-f32 kernels and an
 fp64 dense product.  Run under tools/prof_stats.sh for kernel durations."""
 import os
+
+os.environ["MMDFN_TUNING_LIB"] = "1"   # the MMDFN_* switches below exist only in the -DMMDFN_TUNING build
 import sys
 
 import numpy as np

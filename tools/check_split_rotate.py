@@ -1,6 +1,8 @@
 """cfg5 propagate timing with a ROTATING set of output buffers (each launch writes a fresh 39 MB buffer, as a real
 layer stack does) vs one reused buffer: separates Infinity-Cache residency from kernel quality."""
 import os
+
+os.environ["MMDFN_TUNING_LIB"] = "1"   # the MMDFN_* switches below exist only in the -DMMDFN_TUNING build
 import sys
 import numpy as np
 import torch

@@ -2,6 +2,8 @@
 each launched several times -- results must be bit-identical across repeats (no LDS / pipeline race) and agree with
 the exact-f32 MFMA kernels / an fp64 product to fp32 rounding.  python tools/stress_split.py [n_cases] [seed]"""
 import os
+
+os.environ["MMDFN_TUNING_LIB"] = "1"   # the MMDFN_* switches below exist only in the -DMMDFN_TUNING build
 import sys
 
 import numpy as np

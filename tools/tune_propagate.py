@@ -1,6 +1,8 @@
 """Sweep the propagate v2 tilings (MMDFN_PROP_CFG override) on one workload; run under rocprofv3
 --kernel-trace --stats to get true per-kernel durations (kernel names carry the template args)."""
 import os
+
+os.environ["MMDFN_TUNING_LIB"] = "1"   # the MMDFN_* switches below exist only in the -DMMDFN_TUNING build
 import sys
 
 import numpy as np
