@@ -1,24 +1,30 @@
 """bench.py -- utterances/sec (fwd + loss + bwd) of the MM-DFN hot path on N MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--ragged]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = zero_grad -> DialogueGNNModel forward -> FocalLoss -> backward (+ the data-parallel
-gradient all-reduce when N > 1) on one synthetic IEMOCAP-shaped batch already resident in HBM.
-Weak scaling: every rank processes its own batch of the configured size (dialogues are independent;
-the only collective is the flat-bucket gradient all-reduce over RCCL).
+With --gpus N > 1 and no torch.distributed environment the script re-launches ITSELF under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` (one rank per GPU over RCCL);
+started by such a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  It refuses to
+report a world size other than the one asked for.
+
+One "step" = zero_grad -> DialogueGNNModel forward -> FocalLoss -> backward (+ the data-parallel gradient all-reduce
+when N > 1) on one synthetic IEMOCAP-shaped batch already resident in HBM.  Weak scaling: every rank processes its own
+batch of the configured size (dialogues are independent; the only collective is the flat-bucket gradient all-reduce).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline":     live HIP-event timing of the dominant graph kernel (K6 propagate) vs the HBM roofline
-  "cpu_baseline": the CPU oracle (port of the reference algorithm) timed on this host, N=1 only.
+  "roofline":      live HIP-event timing of the north-star kernel (K6 scatter-propagate) vs the HBM roofline at the
+                   bench workload; "roofline_cfg5*": the same kernel family at BASELINE config 5, where one launch moves
+                   282 MB (the >= 40 % target is a cfg5 property), buffers rotated so nothing is served by the MALL
+  "dominant":      what actually bounds the step at this workload (per-kernel shares from the committed rocprof stats)
+  "cpu_baseline":  the CPU oracle (port of the reference's op structure) and, next to it, the vectorised CPU
+                   restatement, timed on this host on the same batch, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,11 +41,17 @@ def parse():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs (cfg2 ragged, cfg3, cfg4 shard)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs (cfg2 ragged, cfg3, cfg4 shard, cfg5, streamed)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the K6 roofline legs (profiling runs of the step alone)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per cpu_baseline mode")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
-    ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use GPU 0")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use GPU 0 (needs --backend gloo)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel machinery (process group, flat bucket, all-reduce) even at N = 1")
+    ap.add_argument("--eager-allreduce", action="store_true",
+                    help="keep the gradient all-reduce outside the captured step (default: captured with it, eager on failure)")
     ap.add_argument("--deferred-wgrad", action="store_true",
                     help="queue weight-gradient kernels and issue them on a side stream in batches (overlapping the GRU backward)")
     ap.add_argument("--async-wgrad", action="store_true",
@@ -47,30 +59,54 @@ def parse():
     return ap.parse_args()
 
 
-def measured_traffic(key):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_propagate_traffic.json): the counters need
-    their own rocprofv3 --pmc runs (FETCH_SIZE / WRITE_SIZE do not fit one pass), so they are not re-collected here."""
+def self_launch(a):
+    """--gpus N > 1 without a launcher: become `torch.distributed.run` with N ranks on this node."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: needed by RCCL across processes here
+    os.execv(sys.executable, cmd)
+
+
+def profile_json(name):
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_propagate_traffic.json")) as f:
-            return json.load(f)[key]["traffic_bytes"]
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
     except Exception:
         return None
 
 
-def time_propagate(adj_builder, lay_d, iters=200, warm_replays=10, timed_replays=3):
-    """Average duration (ms) of one K6 propagate launch: `iters` back-to-back launches captured in a hipGraph
-    (so the host is out of the picture) and bracketed by HIP events on the replay stream."""
+def measured_traffic(key):
+    """HBM bytes per launch from the committed PMC passes: the counters need their own rocprofv3 --pmc runs
+    (FETCH_SIZE / WRITE_SIZE do not fit one pass), so they are not re-collected here."""
+    for name in ("r02_propagate_traffic.json", "r01_propagate_traffic.json"):
+        d = profile_json(name)
+        if d and key in d:
+            return d[key]["traffic_bytes"], "profiles/" + name
+    return None, None
+
+
+def time_propagate(make_set, nsets, iters, warm_replays=10, timed_replays=3):
+    """Average duration (ms) of one K6 propagate launch.  ``nsets`` independent (adjacency, H, out) buffer sets are
+    rotated launch by launch, sized so that together they exceed the 256 MB Infinity Cache: no launch finds its
+    operands in the MALL.  `iters` back-to-back launches are captured in a hipGraph (the host is out of the picture)
+    and bracketed by HIP events on the replay stream."""
+    import torch
     from mm_dfn_amd import ops
-    adj, H = adj_builder()
-    for _ in range(5):
-        ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    sets = [make_set(i) for i in range(nsets)]
+    outs = [torch.empty_like(H) for _, H in sets]
+    for (adj, H), out in zip(sets, outs):
+        ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout, out=out)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(iters):
-            out = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+        for i in range(iters):
+            adj, H = sets[i % nsets]
+            ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout, out=outs[i % nsets])
     # sustained-load warm-up: the first few milliseconds after an idle period run at a lower engine clock
-    # (measured: the same launch takes 103 us in the first 100 launches and 91 us afterwards)
     for _ in range(warm_replays):
         g.replay()
     torch.cuda.synchronize()
@@ -85,9 +121,26 @@ def time_propagate(adj_builder, lay_d, iters=200, warm_replays=10, timed_replays
     return e0.elapsed_time(e1) / (iters * timed_replays)
 
 
+def timed_replays(cap, steps, warmup, post=None):
+    import torch
+    for _ in range(warmup):
+        cap.replay()
+        if post:
+            post()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cap.replay()
+        if post:
+            post()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
 def quick_leg(cfgname, ragged, dropout, steps=12, warmup=4):
     """One more workload through the same captured step (SURVEY 8d asks for cfg2 ragged, cfg3 and the cfg4 shard
     next to the headline): returns {utterances_per_s, ms_per_step, ...}.  Single GPU, fewer steps, not the headline."""
+    import torch
     from mm_dfn_amd import FocalLoss, synthetic, train
     from mm_dfn_amd.graphs import CapturedStep
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -106,15 +159,7 @@ def quick_leg(cfgname, ragged, dropout, steps=12, warmup=4):
         loss.backward()
         return loss
 
-    cap = CapturedStep(model, fwd_bwd, warmup=2)
-    for _ in range(warmup):
-        cap.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        cap.replay()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = timed_replays(CapturedStep(model, fwd_bwd, warmup=2), steps, warmup)
     n = sum(lengths)
     return {"workload": "%s%s: B=%d, L<=%d, P=%d, %d GCN layers, dims %d/%d/%d" % (
                 cfgname, " ragged" if ragged else "", cfg["B"], cfg["L"], cfg["P"], cfg["nlayers"], cfg["D_t"], cfg["D_a"],
@@ -123,61 +168,147 @@ def quick_leg(cfgname, ragged, dropout, steps=12, warmup=4):
             "utterances_per_s": n / dt, "steps": steps}
 
 
-def cpu_baseline(cfg, batch, state, threads, budget_s=20.0):
-    """Times the oracle (reference op structure: dense adjacency, looped party GRUs, aten GRU) on the host."""
+def cfg5_leg(name, dropout, steps=6, warmup=2):
+    """BASELINE config 5 through the module stack (mm_dfn_amd.MultiStreamGraphModel: six 512-d streams, L = 512,
+    8 GCN layers, d = 100): fwd + FocalLoss + bwd of the whole model as one captured step."""
+    import torch
+    from mm_dfn_amd import FocalLoss, synthetic, train
+    from mm_dfn_amd.graphs import CapturedStep
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(synthetic.STREAM_CONFIGS[name])
+    model = synthetic.build_stream_model(dropout=dropout, **cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
+    model = model.to(dev).train()
+    batch = synthetic.make_stream_batch(2021, device=dev, **cfg)
+    lengths = batch["lengths"]
+    label = train.flatten_labels(batch["label"], lengths)
+    loss_f = FocalLoss(gamma=0.5)
+
+    def fwd_bwd():
+        loss = loss_f(model(batch["streams"], batch["qmask"], batch["umask"], lengths)[0], label)
+        loss.backward()
+        return loss
+
+    dt = timed_replays(CapturedStep(model, fwd_bwd, warmup=1), steps, warmup)
+    n = sum(lengths)
+    return {"workload": "%s: B=%d dialogues, L=%d, M=%d streams x %d-d, %d GCN layers, d=100 (MultiStreamGraphModel: "
+                        "projections + graph stack + head + loss)" % (name, cfg["B"], cfg["L"], len(cfg["D_streams"]),
+                                                                      cfg["D_streams"][0], cfg["nlayers"]),
+            "utterances": n, "ms_per_step": dt * 1e3, "utterances_per_s": n / dt, "steps": steps}
+
+
+def streamed_leg(cfgname, dropout, nbatches=32, passes=2):
+    """The drop-in pass loop (train.train_or_eval_graph_model incl. torch Adam) over `nbatches` DIFFERENT ragged
+    batches streamed from pinned host memory: eager launches vs the shape-keyed captured-step cache (second pass of
+    the cache = all replays, which is every epoch after the first in a real run: the reference re-seeds per pass)."""
+    import torch
+    from mm_dfn_amd import FocalLoss, synthetic, train
+    from mm_dfn_amd import data as D
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(synthetic.CONFIGS[cfgname])
+    batches = []
+    for i in range(nbatches):
+        b = synthetic.make_batch(3000 + i, ragged=True, **cfg)
+        batches.append([b["textf"].pin_memory(), b["visuf"].pin_memory(), b["acouf"].pin_memory(), b["qmask"].pin_memory(),
+                        b["umask"].pin_memory(), b["label"].pin_memory(), ["b%d" % i]])
+    n_utt = sum(int(b[4].sum()) for b in batches)
+    loss_f = FocalLoss(gamma=0.5)
+    res = {}
+    for mode in ("eager", "captured"):
+        model = synthetic.build_model(dropout=dropout, **cfg)
+        model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
+        model = model.to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=1e-4)
+        cache = train.StepGraphCache(model, loss_f, max_entries=nbatches + 4) if mode == "captured" else None
+        times = []
+        for _ in range(passes + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            train.train_or_eval_graph_model(model, loss_f, D.DevicePrefetcher(batches, device=dev), 0, True, opt, False,
+                                            graph_cache=cache)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        res[mode] = {"first_pass_s": times[0], "steady_pass_s": min(times[1:]),
+                     "utterances_per_s": n_utt / min(times[1:]), "ms_per_step": min(times[1:]) / nbatches * 1e3}
+        del model, opt, cache
+    return {"workload": "%s ragged, %d different batches streamed through train_or_eval_graph_model (fwd + loss + bwd + "
+                        "torch Adam step, metrics, pinned-host prefetch)" % (cfgname, nbatches),
+            "utterances_per_pass": n_utt, **res}
+
+
+def cpu_baseline(cfg, batch, state, threads, dropout, budget_s):
+    """Times the two CPU restatements on the host, SAME batch and dropout as the GPU step, fwd + loss + bwd:
+    ``port`` = oracle/mmdfn_oracle.py (the reference's op structure: dense adjacency, per-speaker GRU passes, dense
+    A.H) and ``vectorised`` = oracle/mmdfn_vectorised.py (block tiles, batched party GRU)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mmdfn_oracle as O
+    import mmdfn_vectorised as V
     # torch's default (all hardware threads) oversubscribes badly on a 256-thread host for these small
     # ops; 16 intra-op threads was the fastest setting measured (8/16/32/64 tried), override with --cpu-threads
     torch.set_num_threads(threads if threads > 0 else min(16, os.cpu_count() or 1))
     used = torch.get_num_threads()
-    # bounded sample: the first `nb` dialogues of the batch (reference CPU throughput peaks near B=16)
-    nb = min(len(batch["lengths"]), 8)
-    lens = batch["lengths"][:nb]
-    L = max(lens)
-    sl = lambda t: t[:L, :nb].contiguous()
+    lens = batch["lengths"]
     params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state.items()}
-    ocfg = O.default_cfg(cfg["nlayers"], dropout=0.0)
-    label = O.flatten_labels(batch["label"][:nb, :L].cpu(), lens)
-    args = (sl(batch["textf"].cpu()), sl(batch["qmask"].cpu()), batch["umask"][:nb, :L].cpu(), lens,
-            sl(batch["acouf"].cpu()), sl(batch["visuf"].cpu()))
+    ocfg = O.default_cfg(cfg["nlayers"], dropout=dropout)
+    label = O.flatten_labels(batch["label"].cpu(), lens)
+    args = (batch["textf"].cpu(), batch["qmask"].cpu(), batch["umask"].cpu(), lens, batch["acouf"].cpu(),
+            batch["visuf"].cpu())
 
-    def step():
-        for p in params.values():
-            p.grad = None
-        logp = O.forward(params, *args, ocfg, training=True, engine="aten")
-        O.focal_loss(logp, label, 0.5).backward()
+    def run(fwd):
+        def step():
+            for p in params.values():
+                p.grad = None
+            O.focal_loss(fwd(), label, 0.5).backward()
+        step()  # warm-up
+        t0 = time.time()
+        n = 0
+        while True:
+            step()
+            n += 1
+            if time.time() - t0 > budget_s or n >= 20:
+                break
+        return (time.time() - t0) / n, n
 
-    step()  # warm-up
-    t0 = time.time()
-    n = 0
-    while True:
-        step()
-        n += 1
-        if time.time() - t0 > budget_s or n >= 20:
-            break
-    dt = (time.time() - t0) / n
-    return {"value": sum(lens) / dt, "unit": "utterances/s", "cores": used, "kind": "port",
-            "sample": "%d dialogues (L<=%d, N=%d utt) of the bench batch, %d fwd+bwd steps, oracle/mmdfn_oracle.py "
-                      "(dense adjacency, per-speaker GRU passes, aten GRU), %.2f s/step" % (nb, L, sum(lens), n, dt)}
+    dt_p, n_p = run(lambda: O.forward(params, *args, ocfg, training=True, engine="aten"))
+    dt_v, n_v = run(lambda: V.forward(params, *args, ocfg, training=True))
+    sample = "the full bench batch (%d dialogues, N=%d utt), dropout %.2f, fwd+loss+bwd" % (len(lens), sum(lens), dropout)
+    port = {"value": sum(lens) / dt_p, "unit": "utterances/s", "cores": used, "kind": "port",
+            "sample": "%s, %d steps of oracle/mmdfn_oracle.py (dense adjacency, per-speaker GRU passes, aten GRU), "
+                      "%.2f s/step" % (sample, n_p, dt_p)}
+    port["vectorised"] = {"value": sum(lens) / dt_v, "unit": "utterances/s", "cores": used, "kind": "port",
+                          "sample": "%s, %d steps of oracle/mmdfn_vectorised.py (block-tile adjacency, batched party "
+                                    "GRU; SURVEY 8d's conservative comparison), %.3f s/step" % (sample, n_v, dt_v)}
+    ref = profile_json("r01_reference_cpu_build_container.json")
+    if ref:
+        port["reference_on_build_container"] = ref
+    return port
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if world != a.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: refusing to report a world size that was not asked for" % (world, a.gpus))
     if a.share_gpu:
         local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but only %d visible devices" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from mm_dfn_amd import FocalLoss, synthetic, train, ops, distributed
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # eager + captured steps share parameters
 
-    if world > 1:
+    use_dp = world > 1 or a.force_dp
+    if use_dp:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         distributed.init(backend=a.backend)
 
     cfg = dict(synthetic.CONFIGS[a.config])
@@ -190,8 +321,8 @@ def main():
     label = train.flatten_labels(batch["label"], lengths)
     loss_f = FocalLoss(gamma=0.5)
     # sum-reduce with the 1/world factor folded into the loss scale below: no separate averaging kernel after the all-reduce
-    dp = distributed.GradientBucket(model, average=False) if world > 1 else None
-    total_utt = distributed.all_reduce_scalar(n_utt) if world > 1 else n_utt
+    dp = distributed.GradientBucket(model, average=False) if use_dp else None
+    total_utt = distributed.all_reduce_scalar(n_utt) if use_dp else n_utt
 
     scale = (n_utt / total_utt) if dp is not None else 1.0   # local mean -> this rank's share of the GLOBAL mean
 
@@ -215,35 +346,52 @@ def main():
 
     step = eager_step
     launch_mode = "eager"
+    allreduce_mode = None if dp is None else "eager after the step"
     if not a.no_graph:
         from mm_dfn_amd.graphs import CapturedStep
-        try:
-            captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
+        captured = None
+        if dp is not None and not a.eager_allreduce:
+            # the all-reduce as a node of the captured step: no host launch between backward and the collective
+            try:
+                captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp, reduce_in_graph=True)
+                allreduce_mode = "captured in the step's hipGraph"
+                step = captured.replay
+            except Exception as exc:
+                print("[bench] capturing the all-reduce failed (%s: %s); all-reduce stays eager" % (type(exc).__name__, exc),
+                      file=sys.stderr)
+                torch.cuda.synchronize()
+                captured = None
+                dp = distributed.GradientBucket(model, average=False)
+        if captured is None:
+            try:
+                captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
 
-            def step():
-                loss = captured.replay()
-                if dp is not None:
-                    dp.reduce_flat()
-                return loss
+                def step():
+                    loss = captured.replay()
+                    if dp is not None:
+                        dp.reduce_flat()
+                    return loss
+            except Exception as exc:  # capture is an optimisation; never lose the measurement over it
+                print("[bench] hipGraph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
+                torch.cuda.synchronize()
+                captured = None
+                step = eager_step
+        if captured is not None:
             launch_mode = "hipGraph replay of the whole step"
-        except Exception as exc:  # capture is an optimisation; never lose the measurement over it
-            print("[bench] hipGraph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
-            torch.cuda.synchronize()
-            step = eager_step
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if use_dp:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dp:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -251,7 +399,7 @@ def main():
     # ---- the same step followed by the fused Adam update (one extra launch), reported next to the headline.
     # Parameters and gradients are flat buffers here, so the step is re-captured against the flat storage.
     adam_ms = None
-    if world == 1 and not a.no_graph and launch_mode != "eager":
+    if not use_dp and not a.no_graph and launch_mode != "eager":
         try:
             from mm_dfn_amd.graphs import CapturedStep
             from mm_dfn_amd.optim import FlatAdam
@@ -261,113 +409,129 @@ def main():
             opt.bucket.flatten()
             opt._materialise()
             cap2 = CapturedStep(model, fwd_bwd, warmup=2, bucket=opt.bucket)
-            for _ in range(3):
-                cap2.replay()
-                opt.step(grads_already_flat=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(a.steps):
-                cap2.replay()
-                opt.step(grads_already_flat=True)
-            torch.cuda.synchronize()
-            adam_ms = (time.perf_counter() - t1) / a.steps * 1e3
+            adam_ms = timed_replays(cap2, a.steps, 3, post=lambda: opt.step(grads_already_flat=True)) * 1e3
         except Exception as exc:
             print("[bench] fused-Adam leg skipped: %s" % exc, file=sys.stderr)
 
     if rank == 0:
-        # ---- roofline of the dominant graph kernel at this workload (K6 propagate forward, d = 100)
-        feats = torch.randn(3, n_utt, 200, device=dev)
-        d = 100
-
-        def mk():
-            adj = ops.build_adjacency(feats, lengths)
-            return adj, torch.randn(3 * n_utt, d, device=dev)
-
-        ms = time_propagate(mk, d)
-        lay = ops.DialogueLayout.get(lengths, 3, dev)
-        alg_bytes = lay.propagate_bytes(d)
-        achieved = alg_bytes / (ms * 1e-3) / 1e9
         out = {
             "metric": "utterances/sec (fwd+bwd), IEMOCAP-shaped batch", "value": total_utt * a.steps / dt,
             "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "launch": launch_mode,
+            "dtype": "f32",
+            "dtype_note": "fp32 in, fp32 out, fp32 accumulation everywhere.  Launches with many rows (the party-GRU input "
+                          "projection at cfg2; K6 / K6' / projections at cfg5) carry the fp32 product on bf16 MFMAs through "
+                          "three exact bf16 pieces per operand (six piece products): error vs fp64 at fp32 rounding level "
+                          "(<= 4x the exact-f32 MFMA kernel's, tests/test_graph_kernels_gpu.py), not a reduced-precision mode",
+            "data": "synthetic", "launch": launch_mode, "allreduce": allreduce_mode,
             "config": {"workload": "%s: B=%d dialogues/GPU, L=%s, dims %d/%d/%d, %d GCN layers, P=%d, dropout %.2f"
                                    % (a.config, cfg["B"], "ragged<=%d" % cfg["L"] if a.ragged else cfg["L"], cfg["D_t"],
                                       cfg["D_a"], cfg["D_v"], cfg["nlayers"], cfg["P"], a.dropout),
                        "utterances_per_gpu": n_utt, "parallelism": "dp%d" % world},
             "with_fused_adam_step": None if adam_ms is None else {"ms_per_step": adam_ms,
                                                                    "value": total_utt / (adam_ms * 1e-3)},
-            "roofline": {"bound": "hbm", "kernel": "propagate_v2_kernel<2,4,2,16,1> (K6 fwd, d=100, exact-f32 MFMA)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3,
-                         "traffic": measured_traffic("cfg2") if (a.config == "cfg2" and not a.ragged) else None,
-                         "traffic_source": "profiles/r01_propagate_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                                           "separate passes)"},
         }
-        # the same kernel on BASELINE config 5 (L=512, M=6, d=100, 32 dialogues), where one launch moves 282 MB and
-        # the launch-latency floor no longer hides the kernel (the >=40 % HBM target is a cfg5 property)
-        try:
-            l5 = [512] * 32
-            f5 = torch.randn(6, sum(l5), 200, device=dev)
+        if dp is not None and dp.flat is not None:
+            out["gradient_bucket"] = {"floats": dp.flat.numel(), "bytes": dp.flat.numel() * 4, "backend": a.backend}
+        if not a.no_roofline:
+            roofline_legs(out, a, dev, n_utt, lengths)
+        out["dominant"] = profile_json("r02_step_breakdown_%s.json" % a.config)
+        if world == 1 and not a.no_extra and not use_dp:
+            out["other_workloads"] = []
+            legs = [lambda c=c, r=r: quick_leg(c, r, a.dropout) for c, r in
+                    (("cfg2", True), ("cfg3", True), ("cfg4", False), ("cfg4", True))]
+            legs += [lambda: cfg5_leg("cfg5", a.dropout), lambda: cfg5_leg("cfg5_b32", a.dropout, steps=4, warmup=1),
+                     lambda: streamed_leg("cfg2", a.dropout)]
+            for leg in legs:
+                try:
+                    out["other_workloads"].append(leg())
+                except Exception as exc:
+                    print("[bench] extra workload skipped: %s: %s" % (type(exc).__name__, exc), file=sys.stderr)
+                torch.cuda.empty_cache()
+        if world == 1 and not a.no_cpu_baseline and not use_dp:
+            out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads, a.dropout, a.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if use_dp:
+        torch.distributed.destroy_process_group()
 
-            def mk5():
-                adj = ops.build_adjacency(f5, l5)
-                return adj, torch.randn(6 * sum(l5), d, device=dev)
 
-            ms5 = time_propagate(mk5, d, iters=20, warm_replays=15, timed_replays=5)
-            lay5 = ops.DialogueLayout.get(l5, 6, dev)
-            b5 = lay5.propagate_bytes(d)
-            out["roofline_cfg5"] = {"workload": "cfg5: B=32, L=512, M=6, d=100", "bound": "hbm",
-                                    "kernel": "propagate_split_kernel (K6 fwd, bf16-piece MFMA, fp32-level error)",
-                                    "traffic": measured_traffic("cfg5_b32"),
-                                    "achieved": b5 / (ms5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b5,
-                                    "avg_launch_us": ms5 * 1e3,
-                                    "useful_tflops": lay5.propagate_flops(d) / (ms5 * 1e-3) / 1e12}
-            # K6 backward at the same workload, reported separately: dH = A^T dO (the forward kernel, A is
-            # symmetric) + dA = dO . H^T on the tile pattern (tile_dot + cross_dot); bytes_bwd = 8 nnz + 16 M N d
-            adj5, H5 = mk5()
-            dO5 = torch.randn_like(H5)
-            for _ in range(3):
+def roofline_legs(out, a, dev, n_utt, lengths):
+    import torch
+    from mm_dfn_amd import ops
+    d = 100
+    # ---- the north-star kernel (K6 scatter-propagate forward, d = 100) at the bench workload.  At cfg2 it is ~2 % of
+    # the step and launch-latency bound (6.6 MB per launch); the bandwidth result is the cfg5 leg below.
+    def mk(i):
+        g = torch.Generator(device=dev).manual_seed(100 + i)
+        adj = ops.build_adjacency(torch.randn(3, n_utt, 200, device=dev, generator=g), lengths)
+        return adj, torch.randn(3 * n_utt, d, device=dev, generator=g)
+
+    ms = time_propagate(mk, nsets=48, iters=192)
+    lay = ops.DialogueLayout.get(lengths, 3, dev)
+    alg_bytes = lay.propagate_bytes(d)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    traffic, src = measured_traffic("cfg2") if (a.config == "cfg2" and not a.ragged) else (None, None)
+    out["roofline"] = {"bound": "hbm", "kernel": "propagate_v2_kernel<2,4,2,16,1> (K6 fwd, d=100, exact-f32 MFMA)",
+                       "role": "north-star target kernel (BASELINE.json: 'GCN scatter-propagate'); NOT the dominant cost of "
+                               "this workload, see 'dominant'; its HBM-roofline figure of merit is 'roofline_cfg5'",
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3, "traffic": traffic,
+                       "traffic_source": None if src is None else src + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                       "buffers": "48 rotating (adjacency, H, out) sets = %.0f MB > 256 MB MALL" % (48 * (alg_bytes / 1e6))}
+    # the same kernel on BASELINE config 5 (L=512, M=6, d=100, 32 dialogues), where one launch moves 282 MB and
+    # the launch-latency floor no longer hides the kernel (the >=40 % HBM target is a cfg5 property)
+    try:
+        l5 = [512] * 32
+
+        def mk5(i):
+            g = torch.Generator(device=dev).manual_seed(500 + i)
+            adj = ops.build_adjacency(torch.randn(6, sum(l5), 200, device=dev, generator=g), l5)
+            return adj, torch.randn(6 * sum(l5), d, device=dev, generator=g)
+
+        ms5 = time_propagate(mk5, nsets=3, iters=21, warm_replays=15, timed_replays=5)
+        lay5 = ops.DialogueLayout.get(l5, 6, dev)
+        b5 = lay5.propagate_bytes(d)
+        t5, src5 = measured_traffic("cfg5_b32")
+        out["roofline_cfg5"] = {"workload": "cfg5: B=32, L=512, M=6, d=100", "bound": "hbm",
+                                "kernel": "propagate_split_kernel (K6 fwd, bf16-piece MFMA, fp32-level error)",
+                                "traffic": t5, "traffic_source": src5,
+                                "achieved": b5 / (ms5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b5,
+                                "avg_launch_us": ms5 * 1e3,
+                                "buffers": "3 rotating (adjacency, H, out) sets = %.0f MB > 256 MB MALL" % (3 * b5 / 1e6),
+                                "useful_tflops": lay5.propagate_flops(d) / (ms5 * 1e-3) / 1e12}
+        # K6 backward at the same workload, reported separately: dH = A^T dO (the forward kernel, A is
+        # symmetric) + dA = dO . H^T on the tile pattern (tile_dot + cross_dot); bytes_bwd = 8 nnz + 16 M N d
+        adj5, H5 = mk5(0)
+        dO5 = torch.randn_like(H5)
+        for _ in range(3):
+            ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
+            ops.tile_outer_raw(dO5, H5, adj5.layout)
+        torch.cuda.synchronize()
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb):
+            for _ in range(10):
                 ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
                 ops.tile_outer_raw(dO5, H5, adj5.layout)
-            torch.cuda.synchronize()
-            gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb):
-                for _ in range(10):
-                    ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
-                    ops.tile_outer_raw(dO5, H5, adj5.layout)
-            for _ in range(10):
-                gb.replay()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                gb.replay()
-            e1.record()
-            e1.synchronize()
-            msb = e0.elapsed_time(e1) / 50
-            bb = 8 * lay5.nnz + 16 * 6 * sum(l5) * d
-            out["roofline_cfg5_bwd"] = {"workload": "cfg5 backward of one K6 call: dH (propagate) + dA (tile_dot + cross_dot)",
-                                        "bound": "hbm", "achieved": bb / (msb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "algorithmic_bytes": bb, "avg_us": msb * 1e3}
-            del f5, adj5, H5, dO5, gb
-        except Exception as exc:
-            print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
-        if world == 1 and not a.no_extra:
-            out["other_workloads"] = []
-            for cname, rag in (("cfg2", True), ("cfg3", True), ("cfg4", False), ("cfg4", True)):
-                try:
-                    out["other_workloads"].append(quick_leg(cname, rag, a.dropout))
-                except Exception as exc:
-                    print("[bench] extra workload %s skipped: %s" % (cname, exc), file=sys.stderr)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        for _ in range(10):
+            gb.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            gb.replay()
+        e1.record()
+        e1.synchronize()
+        msb = e0.elapsed_time(e1) / 50
+        bb = 8 * lay5.nnz + 16 * 6 * sum(l5) * d
+        out["roofline_cfg5_bwd"] = {"workload": "cfg5 backward of one K6 call: dH (propagate) + dA (tile_dot + cross_dot)",
+                                    "bound": "hbm", "achieved": bb / (msb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "algorithmic_bytes": bb, "avg_us": msb * 1e3}
+        del adj5, H5, dO5, gb
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -168,6 +168,10 @@ def get_MELD_loaders(data_path=None, batch_size=32, valid_rate=0.1, num_workers=
                     pin_memory, bucketed)
 
 
+class DeviceBatch(list):
+    """The reference's batch list with the host-side dialogue lengths attached (``.lengths``)."""
+
+
 class DevicePrefetcher:
     """Wraps a loader: batch k+1 is staged in pinned host memory and copied to HBM on a side stream while batch k
     computes; the consumer stream waits on the copy's event only.  Yields the reference's batch list with the six
@@ -183,6 +187,10 @@ class DevicePrefetcher:
 
     def _stage(self, batch, stream):
         tensors, rest = batch[:6], batch[6:]
+        # dialogue lengths from the HOST copy of umask (run_train_erc.py:194 reads them back from the device with B
+        # syncs): they key the trainer's captured-step cache without a device round trip
+        um = tensors[4]
+        lengths = ((um == 1).to(torch.int64) * torch.arange(1, um.shape[1] + 1).unsqueeze(0)).max(1).values.tolist()
         with torch.cuda.stream(stream):
             dev = []
             for t in tensors:
@@ -190,7 +198,7 @@ class DevicePrefetcher:
                 dev.append(h.to(self.device, non_blocking=True))
             ev = torch.cuda.Event()
             ev.record(stream)
-        return dev, rest, ev
+        return dev, list(rest), ev, lengths
 
     def __iter__(self):
         stream = torch.cuda.Stream(device=self.device)
@@ -202,7 +210,7 @@ class DevicePrefetcher:
         except StopIteration:
             pass
         while queue:
-            dev, rest, ev = queue.pop(0)
+            dev, rest, ev, lengths = queue.pop(0)
             torch.cuda.current_stream(self.device).wait_event(ev)
             for t in dev:
                 t.record_stream(torch.cuda.current_stream(self.device))
@@ -210,7 +218,9 @@ class DevicePrefetcher:
                 queue.append(self._stage(next(it), stream))
             except StopIteration:
                 pass
-            yield dev + list(rest)
+            out = DeviceBatch(dev + rest)
+            out.lengths = lengths
+            yield out
 
 
 def write_synthetic_pickle(path, dataset="IEMOCAP", n_train=24, n_test=8, max_len=40, min_len=3, D_t=100, D_a=100,

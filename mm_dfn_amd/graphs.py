@@ -13,22 +13,28 @@ from .layout import recording
 
 
 class CapturedStep:
-    def __init__(self, model, step_fn, warmup=3, bucket=None):
+    def __init__(self, model, step_fn, warmup=3, bucket=None, reduce_in_graph=False):
         """step_fn() must run forward + backward on STATIC input tensors and return the loss tensor.
         The step is captured with every ``.grad`` set to None, so autograd simply hands its gradient
         buffers over (no zero-fill, no accumulate kernels); with a ``bucket`` the captured graph ends with
-        the single multi-tensor pack into the flat all-reduce buffer."""
+        the single multi-tensor pack into the flat all-reduce buffer and, with ``reduce_in_graph``, the RCCL
+        all-reduce of that buffer as a graph node (no host launch between backward and the collective)."""
         self.model = model
         self.bucket = bucket
+
+        def tail():
+            ops.join_weight_grads()          # side-stream branches rejoin here
+            if bucket is not None:
+                bucket.flatten()
+                if reduce_in_graph:
+                    bucket.reduce_flat()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):
                 model.zero_grad(set_to_none=True)
                 step_fn()
-                ops.join_weight_grads()
-                if bucket is not None:
-                    bucket.flatten()
+                tail()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -40,9 +46,7 @@ class CapturedStep:
             # thread_local: a communication-library watchdog thread polling its own events must not invalidate the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = step_fn()
-                ops.join_weight_grads()          # side-stream branches rejoin the captured graph here
-                if bucket is not None:
-                    bucket.flatten()
+                tail()
         self._pinned = list(used)
         self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
         # the parameter storages are baked in as well: a later re-pointing of p.data (FlatAdam._materialise, .to(),

@@ -149,3 +149,95 @@ def test_captured_step_pins_cached_index_tensors_and_detects_moved_parameters():
     opt._materialise()
     with pytest.raises(RuntimeError, match="storage moved"):
         cap.replay()
+
+
+def test_pass_loop_with_captured_step_cache_equals_eager(tmp_path):
+    """train_or_eval_graph_model(graph_cache=StepGraphCache): ragged batches of changing signature, two epochs (the
+    second one is all replays), training trajectory and metrics identical to the eager loop (dropout 0)."""
+    p = D.write_synthetic_pickle(str(tmp_path / "f.pkl"), n_train=22, n_test=9, max_len=30, seed=8)
+    names = ['hap', 'sad', 'neu', 'ang', 'exc', 'fru']
+    loss_f = FocalLoss(gamma=0.5)
+    runs = []
+    for use_cache in (False, True):
+        m = _model(21)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr, _, te = D.get_IEMOCAP_loaders(p, batch_size=4, valid_rate=0.0)
+        cache = T.StepGraphCache(m, loss_f) if use_cache else None
+        hist = []
+        for e in range(2):
+            r_tr = T.train_or_eval_graph_model(m, loss_f, D.DevicePrefetcher(tr), e, True, opt, False, 'avl', names,
+                                               graph_cache=cache)
+            r_te = T.train_or_eval_graph_model(m, loss_f, D.DevicePrefetcher(te), e, False, None, False, 'avl', names,
+                                               graph_cache=cache)
+            hist.append((r_tr[2], r_tr[3], r_te[2], r_te[3], r_te[5].copy()))
+        runs.append((m, hist, cache))
+    (m0, h0, _), (m1, h1, cache) = runs
+    for a, b in zip(h0, h1):
+        assert abs(a[0] - b[0]) < 2e-4 and abs(a[2] - b[2]) < 2e-4 and a[1] == b[1] and a[3] == b[3]
+        assert (a[4] == b[4]).mean() > 0.99
+    for (k, x), (_, y) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert float((x - y).abs().max()) < 2e-5, k
+    n_tr, n_te = 6, 3                                   # ceil(22/4), ceil(9/4) batches per pass
+    assert cache.misses == n_tr + n_te                  # the per-pass reseed repeats the shuffle: epoch 2 only replays
+    assert cache.hits == n_tr + n_te
+
+
+def test_real_model_gradient_bucket_through_rccl_and_flat_adam():
+    """The data-parallel machinery on the real model and device tensors, world size 1 over RCCL (backend "nccl"):
+    captured step -> flat bucket pack -> all-reduce (also as a node of the captured graph) -> FlatAdam, against
+    the plain eager step with torch Adam."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from mm_dfn_amd import distributed
+    from mm_dfn_amd.graphs import CapturedStep
+    from mm_dfn_amd.optim import FlatAdam
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    distributed.init(backend="nccl")
+    try:
+        cfg = dict(B=3, L=12, **CFG)
+        b = synthetic.make_batch(31, lengths=[12, 5, 9], device="cuda", **cfg)
+        label = T.flatten_labels(b["label"], b["lengths"])
+        loss_f = FocalLoss(gamma=0.5)
+        m_ref, m_dp = _model(33).train(), _model(33).train()
+        o_ref = torch.optim.Adam(m_ref.parameters(), lr=1e-3, weight_decay=1e-4)
+
+        def fb(m):
+            lp = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+            loss = loss_f(lp, label)
+            loss.backward()
+            return loss
+
+        bucket = distributed.GradientBucket(m_dp, average=True)
+        m_dp.zero_grad(set_to_none=True)
+        fb(m_dp)
+        opt = FlatAdam(m_dp, lr=1e-3, weight_decay=1e-4, bucket=bucket)
+        bucket.flatten()
+        opt._materialise()
+        live = [p for p in m_dp.parameters() if p.grad is not None]
+        assert bucket.flat.numel() == sum(p.numel() for p in live) and len(live) == 48
+        try:
+            cap = CapturedStep(m_dp, lambda: fb(m_dp), warmup=1, bucket=bucket, reduce_in_graph=True)
+            in_graph = True
+        except Exception:                                   # a runtime without collective capture: eager all-reduce
+            torch.cuda.synchronize()
+            cap = CapturedStep(m_dp, lambda: fb(m_dp), warmup=1, bucket=bucket)
+            in_graph = False
+        for _ in range(3):
+            o_ref.zero_grad(set_to_none=True)
+            l_ref = fb(m_ref)
+            o_ref.step()
+            l_dp = cap.replay()
+            if not in_graph:
+                bucket.reduce_flat()
+            opt.step(grads_already_flat=True)
+            assert abs(float(l_ref) - float(l_dp)) < 1e-6
+        for (k, x), (_, y) in zip(m_ref.named_parameters(), m_dp.named_parameters()):
+            assert float((x - y).abs().max()) < 5e-6, k
+        assert dist.get_backend() == "nccl"
+    finally:
+        dist.destroy_process_group()
