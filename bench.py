@@ -52,10 +52,6 @@ def parse():
                     help="run the data-parallel machinery (process group, flat bucket, all-reduce) even at N = 1")
     ap.add_argument("--eager-allreduce", action="store_true",
                     help="keep the gradient all-reduce outside the captured step (default: captured with it, eager on failure)")
-    ap.add_argument("--deferred-wgrad", action="store_true",
-                    help="queue weight-gradient kernels and issue them on a side stream in batches (overlapping the GRU backward)")
-    ap.add_argument("--async-wgrad", action="store_true",
-                    help="enqueue weight-gradient kernels on a side stream (measured slower on MI355X: 2.16 vs 1.99 ms)")
     return ap.parse_args()
 
 
@@ -334,8 +330,6 @@ def main():
         loss.backward()
         return loss
 
-    ops.set_async_weight_grads("deferred" if a.deferred_wgrad else a.async_wgrad)
-
     def eager_step():
         model.zero_grad(set_to_none=True)
         loss = fwd_bwd()
@@ -350,7 +344,7 @@ def main():
     if not a.no_graph:
         from mm_dfn_amd.graphs import CapturedStep
         captured = None
-        if dp is not None and not a.eager_allreduce:
+        if dp is not None and not a.eager_allreduce and a.backend == "nccl":   # gloo collectives are host-driven: not capturable
             # the all-reduce as a node of the captured step: no host launch between backward and the collective
             try:
                 captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp, reduce_in_graph=True)

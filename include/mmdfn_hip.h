@@ -194,6 +194,12 @@ int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, cons
  * ------------------------------------------------------------------------- */
 int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N,
                  int ldx, int ldy, int act, int accumulate, void* stream);
+/* The same projection with the weight rows given as TWO blocks: output columns [0, N1) use W (N1, K) / bias,
+ * columns [N1, N) use W2 (N - N1, K) / bias2.  A bidirectional nn.GRU layer keeps one weight_ih / bias_ih
+ * parameter per direction (model.py:866,868); the hoisted input contraction of both directions runs as one
+ * launch on the parameters themselves, without a concatenated copy per step.  N1 == N: W2 / bias2 unused. */
+int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const float* bias, const float* bias2,
+                  float* Y, int R, int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Weight-gradient contraction (autograd of the dense layers on the path: dW = dY^T X, db = sum_r dY):
@@ -220,6 +226,25 @@ int64_t mmdfn_gemm_tn_grouped_workspace(int n, const int* R, const int* M, const
 int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, float* const* C, float* const* colsum,
                           const int* R, const int* M, const int* N, const int* lda, const int* ldb, const int* ldc,
                           const int* bshift, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Batch form: EVERY weight-gradient contraction of a training step in one launch pair (they feed nothing but the
+ * optimizer, so the host queues them during backward and issues them at its end; run_train_erc.py:208 autograd).
+ *   segment s (0 <= s < nseg):  A_s (R_s rows, stride lda_s), B_s (R_s rows, stride ldb_s), row shift bshift_s on B,
+ *                               contributes  sum_r A_s[r, :]^T B_s[r + bshift_s, :]  to output out[s];
+ *   output o (0 <= o < nout):   C_o (M_o x N_o, stride ldc_o) (+)= sum of its segments; colsum_o / colsum2_o (M_o
+ *                               floats or NULL; two destinations because b_ih and b_hh of the LSTM gate share one
+ *                               gradient) (+)= column sums of the segments' A;  accumulate_o != 0 adds to the
+ *                               existing contents.  Segments of one output are extra splits of one slab stack: the
+ *                               layer-shared LSTM gate (model_GCN.py:466) gets one segment per GCN layer and no
+ *                               gradient-accumulation kernel.
+ * nseg, nout <= 40.  All arrays are HOST arrays.  workspace: mmdfn_gemm_tn_batch_workspace(...) floats.
+ * ------------------------------------------------------------------------- */
+int64_t mmdfn_gemm_tn_batch_workspace(int nseg, const int* R, const int* out, int nout, const int* M, const int* N);
+int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                        const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                        float* const* colsum, float* const* colsum2, const int* M, const int* N, const int* ldc,
+                        const int* accumulate, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused Adam step over flat fp32 buffers (replaces torch.optim.Adam(lr, weight_decay=l2).step(),

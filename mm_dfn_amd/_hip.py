@@ -29,10 +29,13 @@ SIGNATURES = {
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_gcnii_combine_bwd": [_P, _P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_linear2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_gemm_tn_splits": [_I, _I, _I],
     "mmdfn_gemm_tn": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_gemm_tn_grouped_workspace": [_I, _P, _P, _P],
     "mmdfn_gemm_tn_grouped": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_gemm_tn_batch_workspace": [_I, _P, _P, _I, _P, _P],
+    "mmdfn_gemm_tn_batch": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_focal_loss_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "mmdfn_focal_loss_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "mmdfn_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
@@ -42,7 +45,7 @@ SIGNATURES = {
     "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):

@@ -194,6 +194,77 @@ __global__ void gemm_tn_grouped_reduce_kernel(const TnGroups gq) {
                         (blockIdx.x - gq.blk_prefix[p]) * (int64_t)blockDim.x + threadIdx.x, (int64_t)nblk * blockDim.x);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batch form: EVERY weight-gradient contraction of a training step in one launch pair.  A step has ~25 of them (dense
+// layers, GRU input / recurrent weights, LSTM gate, GCN layers), each far too small to fill the chip and none feeding
+// anything but the optimizer, so the host queues them during backward and issues them together at its end.
+//   segment s: (A_s, B_s, R_s rows, shift) contributes  A_s^T B_s  to output out[s]; segments of one output are extra
+//   splits of the same slab stack (the layer-shared LSTM gate gets one segment per GCN layer, the reduction sums them:
+//   no gradient-accumulation kernels).
+constexpr int TN_MAXSEG = 40;
+constexpr int TN_MAXOUT = 40;
+struct TnSegs {
+    const float* A[TN_MAXSEG];
+    const float* B[TN_MAXSEG];
+    float* part[TN_MAXSEG];
+    float* colpart[TN_MAXSEG];
+    int R[TN_MAXSEG], lda[TN_MAXSEG], ldb[TN_MAXSEG], bshift[TN_MAXSEG], rows_per_split[TN_MAXSEG], tiles[TN_MAXSEG];
+    int M[TN_MAXSEG], N[TN_MAXSEG];
+    int wg_prefix[TN_MAXSEG + 1];
+    int n;
+};
+struct TnOuts {
+    const float* part[TN_MAXOUT];
+    const float* colpart[TN_MAXOUT];
+    float* C[TN_MAXOUT];
+    float* colsum[TN_MAXOUT];
+    float* colsum2[TN_MAXOUT];    // optional second destination of the column sums (b_ih and b_hh share one gradient)
+    int M[TN_MAXOUT], N[TN_MAXOUT], ldc[TN_MAXOUT], splits[TN_MAXOUT], accumulate[TN_MAXOUT];
+    int blk_prefix[TN_MAXOUT + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(const TnSegs sq) {
+    int p = 0;
+    while (p + 1 < sq.n && (int)blockIdx.x >= sq.wg_prefix[p + 1]) ++p;
+    const int local = blockIdx.x - sq.wg_prefix[p];
+    const int split = local / sq.tiles[p];
+    const int tile = local - split * sq.tiles[p];
+    gemm_tn_body(sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p],
+                 sq.rows_per_split[p], sq.bshift[p], tile, split);
+}
+
+__global__ void gemm_tn_batch_reduce_kernel(const TnOuts oq) {
+    int p = 0;
+    while (p + 1 < oq.n && (int)blockIdx.x >= oq.blk_prefix[p + 1]) ++p;
+    const int nblk = oq.blk_prefix[p + 1] - oq.blk_prefix[p];
+    const int M = oq.M[p], N = oq.N[p], ldc = oq.ldc[p], splits = oq.splits[p];
+    const bool acc = oq.accumulate[p] != 0;
+    const float* part = oq.part[p];
+    const float* colpart = oq.colpart[p];
+    float* C = oq.C[p];
+    float* cs = oq.colsum[p];
+    float* cs2 = oq.colsum2[p];
+    const int64_t total = (int64_t)M * N;
+    const int64_t stride = (int64_t)nblk * blockDim.x;
+    for (int64_t idx = (blockIdx.x - oq.blk_prefix[p]) * (int64_t)blockDim.x + threadIdx.x; idx < total + M; idx += stride) {
+        if (idx < total) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += part[(int64_t)k * total + idx];
+            const int m = (int)(idx / N);
+            float* dst = C + (int64_t)m * ldc + (idx - (int64_t)m * N);
+            *dst = acc ? *dst + s : s;
+        } else if (cs != nullptr) {
+            const int m = (int)(idx - total);
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += colpart[(int64_t)k * M + m];
+            cs[m] = acc ? cs[m] + s : s;
+            if (cs2 != nullptr) cs2[m] = acc ? cs2[m] + s : s;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) {
@@ -204,12 +275,19 @@ extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) {
     }
 #endif
     // measured on MI355X (tools/bench_gemm_tn.py): ~330-660 rows per split is the sweet spot for every hot-path
-    // shape (R = 1.7k .. 10.5k, outputs 100x200 .. 600x200); more splits only inflate the slab reduction
-    (void)M;
-    (void)N;
+    // shape (R = 1.7k .. 10.5k, outputs 100x200 .. 600x200); more splits only inflate the slab reduction.  Long
+    // reductions (cfg5: R = 98 304 rows into a 100 x 200 output = 8 tiles) need far more than 16 splits to put a
+    // workgroup on every CU: ~512 rows per split, at most ~1536 workgroups per problem.
     int s = (R + 329) / 330;
     if (s < 8) s = 8;
-    if (s > 16) s = 16;
+    if (s > 16) {
+        const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+        int cap = 1536 / (tiles > 0 ? tiles : 1);
+        if (cap < 16) cap = 16;
+        s = (R + 511) / 512;
+        if (s > cap) s = cap;
+        if (s < 16) s = 16;
+    }
     const int max_s = (R + 2 * BR - 1) / (2 * BR);  // at least two staged chunks per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -284,6 +362,100 @@ extern "C" int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* 
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(gq.wg_prefix[n]), dim3(256), 0, s, gq);
     MMDFN_CHECK_LAUNCH();
     hipLaunchKernelGGL(gemm_tn_grouped_reduce_kernel, dim3(gq.blk_prefix[n]), dim3(256), 0, s, gq);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- batch form (see TnSegs / TnOuts above) ----------------------------------------------------------------------
+static int batch_eff_splits(int R, int M, int N, int* rps_out) {
+    const int splits = mmdfn_gemm_tn_splits(R, M, N);
+    const int rps = ((R + splits - 1) / splits + BR - 1) / BR * BR;
+    if (rps_out) *rps_out = rps;
+    return (R + rps - 1) / rps;
+}
+
+extern "C" int64_t mmdfn_gemm_tn_batch_workspace(int nseg, const int* R, const int* out, int nout, const int* M,
+                                                 const int* N) {
+    int64_t total = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int o = out[s];
+        if (o < 0 || o >= nout) return -1;
+        total += (int64_t)batch_eff_splits(R[s], M[o], N[o], nullptr) * ((int64_t)M[o] * N[o] + M[o]);
+    }
+    return total;
+}
+
+extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                                   const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                                   float* const* colsum, float* const* colsum2, const int* M, const int* N,
+                                   const int* ldc, const int* accumulate, float* workspace, void* stream) {
+    if (nseg < 1 || nseg > TN_MAXSEG || nout < 1 || nout > TN_MAXOUT) return -1;
+    TnSegs sq;
+    TnOuts oq;
+    // pass 1: splits per output (its segments stack their slabs)
+    int out_splits[TN_MAXOUT], seg_eff[TN_MAXSEG], seg_rps[TN_MAXSEG];
+    for (int o = 0; o < nout; ++o) {
+        out_splits[o] = 0;
+        if (M[o] <= 0 || N[o] <= 0 || (M[o] & 3) || (N[o] & 3) || ldc[o] < N[o]) return -1;
+    }
+    for (int s = 0; s < nseg; ++s) {
+        const int o = out[s];
+        if (o < 0 || o >= nout || R[s] <= 0 || (lda[s] & 3) || (ldb[s] & 3) || lda[s] < M[o] || ldb[s] < N[o]) return -1;
+        seg_eff[s] = batch_eff_splits(R[s], M[o], N[o], &seg_rps[s]);
+        out_splits[o] += seg_eff[s];
+    }
+    // workspace layout: per output [splits][M][N] then [splits][M]
+    float* ws = workspace;
+    float* part_base[TN_MAXOUT];
+    float* col_base[TN_MAXOUT];
+    oq.n = nout;
+    oq.blk_prefix[0] = 0;
+    for (int o = 0; o < nout; ++o) {
+        if (out_splits[o] == 0) return -1;   // an output nobody contributes to
+        part_base[o] = ws;
+        ws += (int64_t)out_splits[o] * M[o] * N[o];
+        col_base[o] = ws;
+        ws += (int64_t)out_splits[o] * M[o];
+        oq.part[o] = part_base[o];
+        oq.colpart[o] = col_base[o];
+        oq.C[o] = C[o];
+        oq.colsum[o] = colsum ? colsum[o] : nullptr;
+        oq.colsum2[o] = colsum2 ? colsum2[o] : nullptr;
+        oq.M[o] = M[o]; oq.N[o] = N[o]; oq.ldc[o] = ldc[o]; oq.splits[o] = out_splits[o];
+        oq.accumulate[o] = accumulate ? accumulate[o] : 0;
+        int nblk = (int)(((int64_t)M[o] * N[o] + M[o] + 255) / 256);
+        if (nblk > 256) nblk = 256;
+        oq.blk_prefix[o + 1] = oq.blk_prefix[o] + nblk;
+    }
+    for (int o = nout; o < TN_MAXOUT; ++o) {
+        oq.part[o] = oq.colpart[o] = nullptr; oq.C[o] = oq.colsum[o] = oq.colsum2[o] = nullptr;
+        oq.M[o] = oq.N[o] = oq.ldc[o] = oq.splits[o] = oq.accumulate[o] = 0;
+        oq.blk_prefix[o + 1] = oq.blk_prefix[nout];
+    }
+    int used[TN_MAXOUT];
+    for (int o = 0; o < nout; ++o) used[o] = 0;
+    sq.n = nseg;
+    sq.wg_prefix[0] = 0;
+    for (int s = 0; s < nseg; ++s) {
+        const int o = out[s];
+        const int tiles = ((M[o] + TM - 1) / TM) * ((N[o] + TN - 1) / TN);
+        sq.A[s] = A[s]; sq.B[s] = B[s];
+        sq.part[s] = part_base[o] + (int64_t)used[o] * M[o] * N[o];
+        sq.colpart[s] = (oq.colsum[o] != nullptr) ? col_base[o] + (int64_t)used[o] * M[o] : nullptr;
+        used[o] += seg_eff[s];
+        sq.R[s] = R[s]; sq.lda[s] = lda[s]; sq.ldb[s] = ldb[s]; sq.bshift[s] = bshift ? bshift[s] : 0;
+        sq.rows_per_split[s] = seg_rps[s]; sq.tiles[s] = tiles; sq.M[s] = M[o]; sq.N[s] = N[o];
+        sq.wg_prefix[s + 1] = sq.wg_prefix[s] + tiles * seg_eff[s];
+    }
+    for (int s = nseg; s < TN_MAXSEG; ++s) {
+        sq.A[s] = sq.B[s] = nullptr; sq.part[s] = sq.colpart[s] = nullptr;
+        sq.R[s] = sq.lda[s] = sq.ldb[s] = sq.bshift[s] = sq.rows_per_split[s] = sq.tiles[s] = sq.M[s] = sq.N[s] = 0;
+        sq.wg_prefix[s + 1] = sq.wg_prefix[nseg];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
+    MMDFN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[nout]), dim3(256), 0, st, oq);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -18,9 +18,12 @@ namespace {
 
 template <int RT, int CT, int WR, int WC>
 __global__ __launch_bounds__(64 * WR * WC) void linear_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                             const float* __restrict__ bias, float* __restrict__ Y,
-                                                             int R, int K, int N, int ldx, int ldy, int act,
-                                                             int accumulate) {
+                                                             const float* __restrict__ W2, int N1,
+                                                             const float* __restrict__ bias, const float* __restrict__ bias2,
+                                                             float* __restrict__ Y, int R, int K, int N, int ldx, int ldy,
+                                                             int act, int accumulate) {
+    // output columns [0, N1) use rows of W / bias, columns [N1, N) rows of W2 / bias2 (the two directions of a
+    // bidirectional GRU layer keep their own weight_ih parameters: no concatenated copy per step); N1 = N: one block
     constexpr int BM = 16 * RT * WR;
     constexpr int BN = 16 * CT * WC;
     const int nbn = (N + BN - 1) / BN;
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(64 * WR * WC) void linear_kernel(const float* __res
     for (int ct = 0; ct < CT; ++ct) {
         const int c = col0 + 16 * ct + fi;
         wok[ct] = c < N;
-        wp[ct] = W + (int64_t)(c < N ? c : N - 1) * K;
+        const int cc = c < N ? c : N - 1;
+        wp[ct] = (cc < N1) ? W + (int64_t)cc * K : W2 + (int64_t)(cc - N1) * K;
     }
 
     f32x4 acc[RT][CT];
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(64 * WR * WC) void linear_kernel(const float* __res
     for (int ct = 0; ct < CT; ++ct) {
         const int c = col0 + 16 * ct + fi;
         if (c >= N) continue;
-        const float bb = bias ? bias[c] : 0.f;
+        const float bb = bias ? (c < N1 ? bias[c] : bias2[c - N1]) : 0.f;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -121,34 +125,36 @@ __global__ __launch_bounds__(64 * WR * WC) void linear_kernel(const float* __res
 }
 
 template <int RT, int CT, int WR, int WC>
-int launch(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N, int ldx, int ldy, int act,
-           int accumulate, hipStream_t s) {
+int launch(const float* X, const float* W, const float* W2, int N1, const float* bias, const float* bias2, float* Y, int R,
+           int K, int N, int ldx, int ldy, int act, int accumulate, hipStream_t s) {
     const int BM = 16 * RT * WR, BN = 16 * CT * WC;
     dim3 grid(((R + BM - 1) / BM) * ((N + BN - 1) / BN));
-    hipLaunchKernelGGL((linear_kernel<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, s, X, W, bias, Y, R, K, N, ldx,
-                       ldy, act, accumulate);
+    hipLaunchKernelGGL((linear_kernel<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, s, X, W, W2, N1, bias, bias2, Y, R, K,
+                       N, ldx, ldy, act, accumulate);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
 
 }  // namespace
 
-extern "C" int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N, int ldx,
-                            int ldy, int act, int accumulate, void* stream) {
+extern "C" int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const float* bias,
+                             const float* bias2, float* Y, int R, int K, int N, int ldx, int ldy, int act, int accumulate,
+                             void* stream) {
     if (R <= 0 || K < 4 || N <= 0 || (K & 3) || (ldx & 3) || ldx < K || ldy < N) return -1;
+    if (N1 <= 0 || N1 > N || (N1 < N && W2 == nullptr) || (bias != nullptr && N1 < N && bias2 == nullptr)) return -1;
     hipStream_t s = (hipStream_t)stream;
 #ifdef MMDFN_TUNING
     const char* e = getenv("MMDFN_LIN_CFG");  // tools/bench_linear.py
     const int ov = e ? atoi(e) : -1;
-    if (ov == 0) return launch<2, 4, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
-    if (ov == 1) return launch<1, 7, 4, 1>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
-    if (ov == 2) return launch<1, 13, 4, 1>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
-    if (ov == 3) return launch<2, 4, 1, 4>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
-    if (ov == 4) return launch<4, 4, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
-    if (ov == 5) return launch<2, 2, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
-    if (ov == 6) return launch<1, 4, 4, 1>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 0) return launch<2, 4, 2, 2>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 1) return launch<1, 7, 4, 1>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 2) return launch<1, 13, 4, 1>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 3) return launch<2, 4, 1, 4>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 4) return launch<4, 4, 2, 2>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 5) return launch<2, 2, 2, 2>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    if (ov == 6) return launch<1, 4, 4, 1>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
     if (ov == 7) {
-        const int rc = mmdfn_launch_linear_split(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
+        const int rc = mmdfn_launch_linear_split(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
         if (rc != -2) return rc;
     }
 #else
@@ -160,11 +166,16 @@ extern "C" int mmdfn_linear(const float* X, const float* W, const float* bias, f
         // with fewer tiles its 4-wave 128 x 128 workgroups leave the chip idle
         const long tiles = (long)((R + 127) / 128) * ((N + 127) / 128);
         if (tiles >= 256 && K >= 32) {
-            const int rc = mmdfn_launch_linear_split(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
+            const int rc = mmdfn_launch_linear_split(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
             if (rc != -2) return rc;
         }
     }
     // measured (tools/bench_linear.py): the 64 x 64 workgroup tile (2 x 2 MFMA tiles per wave) wins on every
     // hot-path shape -- the kernel is latency-bound, so more, smaller workgroups beat bigger register tiles
-    return launch<2, 2, 2, 2>(X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate, s);
+    return launch<2, 2, 2, 2>(X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act, accumulate, s);
+}
+
+extern "C" int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N, int ldx,
+                            int ldy, int act, int accumulate, void* stream) {
+    return mmdfn_linear2(X, W, nullptr, N, bias, nullptr, Y, R, K, N, ldx, ldy, act, accumulate, stream);
 }

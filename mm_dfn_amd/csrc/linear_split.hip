@@ -33,8 +33,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 
 // One 128 x 128 output block:  Yb[r][c] = act( sum_k Xb[r][k] Wb[c][k] + bias[c] ) (+ Yb[r][c])  for r < Rv, c < Nstore;
 // columns Nv <= c < Nstore are written as exact zeros (row padding of the block-tile layout).
+// Block columns [0, n1) read rows of Wb / bias, columns [n1, Nv) rows (c - n1) of W2b / bias2 (n1 >= Nv: one block).
 __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, const float* __restrict__ Wb,
-                                                 const float* __restrict__ bias, float* __restrict__ Yb, int Rv, int Nv,
+                                                 const float* __restrict__ W2b, int n1,
+                                                 const float* __restrict__ bias, const float* __restrict__ bias2,
+                                                 float* __restrict__ Yb, int Rv, int Nv,
                                                  int Nstore, int K, int ldx, int ldw, int ldy, int act, int accumulate) {
     constexpr int NCT = 4;
     constexpr int ABLC = 0;
@@ -61,7 +64,8 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
     const bool bok = bcol < Nv;
     const int bkg = __builtin_amdgcn_readfirstlane(tid >> 7);
     const int blds = bcol * SROW + 4 * bkg;
-    const float* w_lane = Wb + (int64_t)(bok ? bcol : Nv - 1) * ldw + 4 * bkg;
+    const int bcolc = bok ? bcol : Nv - 1;
+    const float* w_lane = ((bcolc < n1) ? Wb + (int64_t)bcolc * ldw : W2b + (int64_t)(bcolc - n1) * ldw) + 4 * bkg;
 
     const int arow = wrow0 + l32;
     const float* a_lane = Xb + (int64_t)(arow < Rv ? arow : Rv - 1) * ldx + 4 * kg;
@@ -125,7 +129,8 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
                     float4 v = *reinterpret_cast<const float4*>(&Os[erow * LDO + c]);
                     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (c + e < Nv) ? o[e] + (bias ? bias[c + e] : 0.f) : 0.f;
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = (c + e < Nv) ? o[e] + (bias ? (c + e < n1 ? bias[c + e] : bias2[c + e - n1]) : 0.f) : 0.f;
                     if (accumulate) {
                         const float4 old = *reinterpret_cast<const float4*>(yrow + c);
                         o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
@@ -145,7 +150,7 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
     for (int ct = 0; ct < NCT; ++ct) {
         const int c = 32 * ct + l32;
         if (c >= Nstore) continue;
-        const float bb = (bias && c < Nv) ? bias[c] : 0.f;
+        const float bb = (bias && c < Nv) ? (c < n1 ? bias[c] : bias2[c - n1]) : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
@@ -161,9 +166,10 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
 }
 
 __global__ __launch_bounds__(256, 2) void linear_split_kernel(const float* __restrict__ X, const float* __restrict__ W,
-                                                              const float* __restrict__ bias, float* __restrict__ Y,
-                                                              int R, int K, int N, int ldx, int ldy, int act,
-                                                              int accumulate) {
+                                                              const float* __restrict__ W2, int N1,
+                                                              const float* __restrict__ bias, const float* __restrict__ bias2,
+                                                              float* __restrict__ Y, int R, int K, int N, int ldx, int ldy,
+                                                              int act, int accumulate) {
     // column blocks fastest: the column blocks of one X strip run back to back and share it through L2
     const int nbn = (N + 127) / 128;
     const int bm = blockIdx.x / nbn;
@@ -171,8 +177,18 @@ __global__ __launch_bounds__(256, 2) void linear_split_kernel(const float* __res
     const int r0 = bm * 128, c0 = bn * 128;
     const int Rv = (R - r0 < 128) ? R - r0 : 128;
     const int Nv = (N - c0 < 128) ? N - c0 : 128;
-    split_gemm_block(X + (int64_t)r0 * ldx, W + (int64_t)c0 * K, bias ? bias + c0 : nullptr, Y + (int64_t)r0 * ldy + c0, Rv,
-                     Nv, Nv, K, ldx, K, ldy, act, accumulate);
+    // the block's columns c0 .. c0+Nv-1 against the two weight blocks (rows [0, N1) of W, rows [0, N - N1) of W2)
+    const int n1 = N1 - c0;                                   // block-relative boundary (<= 0: all of it is W2)
+    const float* Wb = (n1 > 0) ? W + (int64_t)c0 * K : nullptr;
+    const float* W2b = (n1 > 0) ? W2 : W2 + (int64_t)(-n1) * K;
+    const float* bb = (bias && n1 > 0) ? bias + c0 : nullptr;
+    const float* bb2 = bias ? ((n1 > 0) ? bias2 : bias2 + (-n1)) : nullptr;
+    if (n1 <= 0)      // entirely in the second block: present it as a single block
+        split_gemm_block(X + (int64_t)r0 * ldx, W2b, nullptr, 1 << 30, bb2, nullptr, Y + (int64_t)r0 * ldy + c0, Rv, Nv, Nv, K,
+                         ldx, K, ldy, act, accumulate);
+    else
+        split_gemm_block(X + (int64_t)r0 * ldx, Wb, W2b, n1, bb, bb2, Y + (int64_t)r0 * ldy + c0, Rv, Nv, Nv, K, ldx, K, ldy,
+                         act, accumulate);
 }
 
 // K6' on the same path: dtiles_{i,m}[p, q] (+)= X[(m,p), :] . Y[(m,q), :]  (the adjacency gradient dA = dOut . H^T on the
@@ -205,18 +221,20 @@ __global__ __launch_bounds__(256, 2) void tile_dot_split_kernel(const float* __r
     const int Rv = (L - r0 < 128) ? L - r0 : 128;
     const int Nv = (L - c0 < 128) ? L - c0 : 128;
     const int Ns = (ld - c0 < 128) ? ld - c0 : 128;
-    split_gemm_block(Xm, Ym, nullptr, T, Rv, Nv, Ns, K, ldx, ldy, ld, 0, accumulate);
+    split_gemm_block(Xm, Ym, nullptr, 1 << 30, nullptr, nullptr, T, Rv, Nv, Ns, K, ldx, ldy, ld, 0, accumulate);
 }
 
 }  // namespace
 
 // -2: shape not covered (caller falls back to the f32-MFMA kernel)
-int mmdfn_launch_linear_split(const float* X, const float* W, const float* bias, float* Y, int R, int K, int N, int ldx,
-                              int ldy, int act, int accumulate, hipStream_t s) {
+int mmdfn_launch_linear_split(const float* X, const float* W, const float* W2, int N1, const float* bias,
+                              const float* bias2, float* Y, int R, int K, int N, int ldx, int ldy, int act, int accumulate,
+                              hipStream_t s) {
     if (K < 8 || (K & 3) || (ldx & 3)) return -2;
     const int lds_bytes = 2 * 3 * 128 * SROW * 4;
     dim3 grid(((R + 127) / 128) * ((N + 127) / 128));
-    hipLaunchKernelGGL(linear_split_kernel, grid, dim3(256), lds_bytes, s, X, W, bias, Y, R, K, N, ldx, ldy, act, accumulate);
+    hipLaunchKernelGGL(linear_split_kernel, grid, dim3(256), lds_bytes, s, X, W, W2, N1, bias, bias2, Y, R, K, N, ldx, ldy, act,
+                       accumulate);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

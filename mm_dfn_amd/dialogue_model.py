@@ -178,8 +178,8 @@ class DialogueGNNModel(nn.Module):
                 # Pays off once the party batch is large (measured: cfg4 2.27 -> 2.22 ms, cfg3 2.25 -> 2.19 ms; at
                 # cfg2's 7040 party rows the three extra small launches cost more than the halved GEMMs save)
                 w_ih, b_ih, _ = fused_gru._layer_params(self.rnn_parties, 0)
-                G = ops.linear(torch.stack(act, 0), w_ih, None)
-                gi_p, rank = ops.party_gather(G, qmask, bias=b_ih)
+                G = ops.linear2(torch.stack(act, 0), w_ih[0], w_ih[1], None, None)
+                gi_p, rank = ops.party_gather(G, qmask, bias=torch.cat(b_ih))
                 ctx, E = fused_gru.bigru2([Xl, None], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
                                           gi0=[None, gi_p])
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)

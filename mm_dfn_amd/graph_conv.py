@@ -110,7 +110,8 @@ class GCNII_lyc(nn.Module):
         h = c = None
         if self.reason_flag:
             w_ih, w_hh = self.rnn.weight_ih_l0, self.rnn.weight_hh_l0
-            bias = self.rnn.bias_ih_l0 + self.rnn.bias_hh_l0
+            b_ih, b_hh = self.rnn.bias_ih_l0, self.rnn.bias_hh_l0
+            bsum = (b_ih + b_hh).detach()      # the gate op routes the (shared) bias gradient to both parameters
         masks = None
         if self.inner_dropout and self.training and self.dropout > 0:
             # the keep-masks of all layers in one fill + one dropout launch (already scaled by 1/(1-p))
@@ -119,7 +120,7 @@ class GCNII_lyc(nn.Module):
         for i, con in enumerate(self.convs):
             q = cur
             if self.reason_flag:
-                G = ops.linear(q, w_ih, bias) if h is None else ops.gate_linear(q, h, w_ih, w_hh, bias)
+                G = ops.gate_linear(q, h, w_ih, w_hh, bsum, b_ih, b_hh)
                 h, c = ops.lstm_pointwise(G, c)
                 cur = h
             theta = math.log(self.lamda / (i + 1) + 1)

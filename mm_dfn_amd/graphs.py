@@ -21,6 +21,9 @@ class CapturedStep:
         all-reduce of that buffer as a graph node (no host launch between backward and the collective)."""
         self.model = model
         self.bucket = bucket
+        # the graph bakes the addresses of every tensor step_fn closes over (static inputs, index tensors, labels):
+        # holding the closure keeps them allocated for the lifetime of the graph
+        self._step_fn = step_fn
 
         def tail():
             ops.join_weight_grads()          # side-stream branches rejoin here

@@ -39,6 +39,7 @@ class _GruRecurrence(torch.autograd.Function):
                                           _hip.int_array(Ts), H, _hip.stream())
         _hip.check(rc, "mmdfn_gru_seq_fwd")
         ctx.n = n
+        ctx.refs = [args[5 * g + 1 + k] for g in range(n) for k in range(4)]   # the parameter objects (leaf test)
         ctx.save_for_backward(*ys, *gates, *whh)
         return tuple(ys)
 
@@ -52,35 +53,40 @@ class _GruRecurrence(torch.autograd.Function):
         dgh = [torch.empty_like(t) for t in dgi]
         rows = [y.shape[1] for y in ys]
         Ts = [y.shape[0] for y in ys]
-        ops.flush_weight_grads()      # queued weight gradients of later layers overlap this latency-bound recurrence
         rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
                                           _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
                                           _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
         _hip.check(rc, "mmdfn_gru_seq_bwd")
-        # recurrent-weight gradients of every group and direction in ONE grouped launch (2n problems):
+        # recurrent-weight gradients of every group and direction join the step's weight-gradient batch:
         #   dW_hh = sum_t dgh_t (x) h_{t-1}   forward: h_{t-1} = y[t-1] (row shift -R), reverse: y[t+1] (+R)
         #   db_hh = sum_t dgh_t                = the column sums of the same operand
-        problems, out = [], []
+        out = []
         for g in range(n):
             y, d = ys[g], dgh[g]
             T, R = y.shape[0], y.shape[1]
             d2, y2 = d.view(T * R, 6 * H), y.view(T * R, 2 * H)
-            dwf, dwr = (torch.empty(3 * H, H, dtype=torch.float32, device=y.device) for _ in range(2))
-            dbf, dbr = (torch.empty(3 * H, dtype=torch.float32, device=y.device) for _ in range(2))
-            problems.append(dict(A=d2[:, :3 * H], B=y2[:, :H], C=dwf, colsum=dbf, shift=-R))
-            problems.append(dict(A=d2[:, 3 * H:], B=y2[:, H:], C=dwr, colsum=dbr, shift=R))
-            out += [dgi[g], dwf, dwr, dbf, dbr]
-        def launch():
-            for i in range(0, len(problems), 8):
-                ops.gemm_tn_grouped(problems[i:i + 8])
-        ops._run_wgrad(launch, list(dgh) + list(ys) + [t for o in out for t in ([o] if torch.is_tensor(o) else [])])
+            wf, wr, bf, br = ctx.refs[4 * g: 4 * g + 4]
+            parts = ((d2[:, :3 * H], y2[:, :H], wf, bf, -R), (d2[:, 3 * H:], y2[:, H:], wr, br, R))
+            res = []
+            for A, B, w, b, shift in parts:
+                if ops._queueable(w, [b], 3 * H, H):
+                    ops.queue_wgrad(A, B, w, [b], shift)
+                    res.append((None, None))
+                else:
+                    dw = torch.empty(3 * H, H, dtype=torch.float32, device=y.device)
+                    db = torch.empty(3 * H, dtype=torch.float32, device=y.device)
+                    ops.gemm_tn_grouped([dict(A=A, B=B, C=dw, colsum=db, shift=shift)])
+                    res.append((dw, db))
+            out += [dgi[g], res[0][0], res[1][0], res[0][1], res[1][1]]
         return tuple(out)
 
 
 def _layer_params(gru, layer):
+    """((w_ih_fwd, w_ih_rev), (b_ih_fwd, b_ih_rev), [w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev]): the module's own
+    parameters, never concatenated."""
     sfx = "_l%d" % layer
-    w_ih = torch.cat([getattr(gru, "weight_ih" + sfx), getattr(gru, "weight_ih" + sfx + "_reverse")], 0)
-    b_ih = torch.cat([getattr(gru, "bias_ih" + sfx), getattr(gru, "bias_ih" + sfx + "_reverse")], 0)
+    w_ih = (getattr(gru, "weight_ih" + sfx), getattr(gru, "weight_ih" + sfx + "_reverse"))
+    b_ih = (getattr(gru, "bias_ih" + sfx), getattr(gru, "bias_ih" + sfx + "_reverse"))
     hh = [getattr(gru, "weight_hh" + sfx), getattr(gru, "weight_hh" + sfx + "_reverse"),
           getattr(gru, "bias_hh" + sfx), getattr(gru, "bias_hh" + sfx + "_reverse")]
     return w_ih, b_ih, hh
@@ -97,13 +103,11 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
     cur = list(xs)
     for layer in range(2):
         prm = [_layer_params(gru, layer) for gru in grus]
-        # hoisted input contractions (all t, both directions) of every group: one op, one weight-gradient launch
+        # hoisted input contractions (all t, both directions) of every group: one launch per group on the two
+        # directions' own weight_ih / bias_ih parameters
         pre = gi0 if (layer == 0 and gi0 is not None) else [None] * len(grus)
-        todo = [g for g in range(len(grus)) if pre[g] is None]
-        done = ops.linear_group([cur[g] for g in todo], [prm[g][0] for g in todo], [prm[g][1] for g in todo]) if todo else []
-        gis = list(pre)
-        for g, gi in zip(todo, done):
-            gis[g] = gi
+        gis = [pre[g] if pre[g] is not None else ops.linear2(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1])
+               for g in range(len(grus))]
         args = []
         for gi, p in zip(gis, prm):
             args += [gi] + p[2]

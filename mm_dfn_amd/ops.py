@@ -444,92 +444,138 @@ def gemm_tn_grouped(problems):
 
 
 # ---------------------------------------------------------------------------------------------------
-# Weight-gradient side stream.  dW / db of the dense layers feed nothing else in the backward pass, so when
-# enabled they are enqueued on a second HIP stream (forked from / joined to the main stream with events; under
-# hipGraph capture these become parallel graph branches) and overlap the serial dX chain.  Whoever consumes
-# .grad (optimizer step, gradient all-reduce) must call join_weight_grads() first; mm_dfn_amd.train and
-# mm_dfn_amd.graphs.CapturedStep do.  Off by default: on MI355X at IEMOCAP sizes the fork/join cost outweighs
-# the overlap (cfg2 step 2.16 ms with the side stream vs 1.99 ms without, bench.py --async-wgrad).
+# Weight-gradient queue.  dW / db of the dense layers, the GRU weights, the LSTM gate and the GCN layers feed
+# nothing else in the backward pass and each is far too small to fill the chip (cfg2: ~25 contractions of
+# 1.7k-7k rows into 100x200 .. 600x200 outputs, ten launch pairs and 300 us per step when issued one by one).
+# During backward they are only QUEUED; an autograd end-of-backward callback issues all of them as ONE launch pair
+# (csrc/gemm_tn.hip, batch form) that writes straight into the parameters' .grad -- no autograd accumulation
+# kernels, and the contributions of a parameter used several times (the layer-shared LSTM gate) are summed inside
+# the slab reduction.  Conditions: the weight (and bias) are leaf parameters; anything else takes the in-line path
+# and returns its gradient to autograd as usual.  torch.autograd.grad() callers never get leaf parameters here.
 # ---------------------------------------------------------------------------------------------------
-_WG = {"enabled": False, "stream": None, "dirty": False, "pending": []}
+_WGQ = {"segs": [], "outs": {}, "armed": False}
+_WG_MAX = 40        # TN_MAXSEG / TN_MAXOUT of csrc/gemm_tn.hip
 
 
-def set_async_weight_grads(flag):
-    """False: weight-gradient kernels run in line.  True: each one is forked onto the side stream as it is issued.
-    "deferred": they are queued and issued on the side stream in batches -- right before each GRU backward
-    recurrence (a long, latency-bound launch that leaves most of the chip idle) and at join_weight_grads() -- so a
-    step has two or three fork points instead of ten."""
-    _WG["enabled"] = flag if flag == "deferred" else bool(flag)
+def _leaf(p):
+    return p is not None and p.is_leaf and p.requires_grad
 
 
-def async_weight_grads_enabled():
-    return _WG["enabled"]
+def _queueable(weight, biases, M, N):
+    return _leaf(weight) and all(_leaf(b) for b in biases) and gemm_tn_supported(M, N) and len(biases) <= 2
 
 
-def _wgrad_stream():
-    if _WG["stream"] is None:
-        _WG["stream"] = torch.cuda.Stream()
-    return _WG["stream"]
+def queue_wgrad(A, B, weight, biases=(), shift=0):
+    """weight.grad (M, N) += sum_r A[r]^T B[r + shift];  b.grad (M) += column sums of A for every b in ``biases``.
+    Only valid inside a backward pass (the flush is an end-of-backward callback)."""
+    A = _strided_rows(A)
+    B = _strided_rows(B)
+    key = id(weight)
+    out = _WGQ["outs"].get(key)
+    if out is None:
+        out = dict(weight=weight, biases=[], M=A.shape[1], N=B.shape[1], segs=[])
+        _WGQ["outs"][key] = out
+    for b in biases:
+        if all(b is not x for x in out["biases"]):
+            out["biases"].append(b)
+    if len(out["biases"]) > 2 or (A.shape[1], B.shape[1]) != (out["M"], out["N"]) or tuple(weight.shape) != (out["M"], out["N"]):
+        raise RuntimeError("queue_wgrad: inconsistent contributions to one parameter")
+    out["segs"].append((A, B, int(shift)))
+    if not _WGQ["armed"]:
+        _WGQ["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_queued_wgrads)
 
 
-def _run_wgrad(fn, tensors):
-    """Run (or queue) a weight-gradient launch closure; ``tensors`` are the main-stream buffers it reads / writes."""
-    if _WG["enabled"] == "deferred":
-        _WG["pending"].append((fn, tensors))
+def flush_queued_wgrads():
+    """Issue every queued weight-gradient contraction (one launch pair per <= 40 segments) into the .grad fields."""
+    outs = list(_WGQ["outs"].values())
+    _WGQ["outs"], _WGQ["armed"] = {}, False
+    if not outs:
         return
-    with _wgrad_scope(*tensors):
-        fn()
+    dev = outs[0]["weight"].device
+    # gradient destinations: fresh buffers handed to .grad (the usual case: backward runs with .grad = None), or the
+    # existing .grad accumulated in place
+    work = []                                   # (out, C, colsum targets, accumulate, segment slice)
+    for o in outs:
+        w = o["weight"]
+        have = [w.grad is not None] + [b.grad is not None for b in o["biases"]]
+        acc = any(have)
+        if w.grad is None:
+            w.grad = (torch.zeros if acc else torch.empty)(o["M"], o["N"], dtype=torch.float32, device=dev)
+        elif not w.grad.is_contiguous():
+            w.grad = w.grad.contiguous()
+        cs = []
+        for b in o["biases"]:
+            if b.grad is None:
+                b.grad = (torch.zeros if acc else torch.empty)(o["M"], dtype=torch.float32, device=dev)
+            cs.append(b.grad)
+        segs = o["segs"]
+        for i in range(0, len(segs), _WG_MAX):          # a parameter with > 40 contributions: later pieces accumulate
+            work.append((o, w.grad, cs, 1 if (acc or i > 0) else 0, segs[i:i + _WG_MAX]))
+    batch, nseg = [], 0
+    for item in work:
+        if batch and (nseg + len(item[4]) > _WG_MAX or len(batch) >= _WG_MAX):
+            _launch_wgrad_batch(batch)
+            batch, nseg = [], 0
+        batch.append(item)
+        nseg += len(item[4])
+    if batch:
+        _launch_wgrad_batch(batch)
 
 
-def flush_weight_grads():
-    """Issue every queued weight-gradient launch on the side stream behind the current stream's work so far."""
-    if not _WG["pending"]:
-        return
-    pending, _WG["pending"] = _WG["pending"], []
-    side = _wgrad_stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for fn, tensors in pending:
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(side)
-            fn()
-    _WG["dirty"] = True
+def _launch_wgrad_batch(batch):
+    lib = _hip.lib()
+    ia = _hip.int_array
+    A, B, R, lda, ldb, sh, oi = [], [], [], [], [], [], []
+    C, cs1, cs2, M, N, ldc, acc = [], [], [], [], [], [], []
+    for k, (o, Ct, cs, a, segs) in enumerate(batch):
+        C.append(Ct)
+        cs1.append(cs[0] if len(cs) > 0 else None)
+        cs2.append(cs[1] if len(cs) > 1 else None)
+        M.append(o["M"]); N.append(o["N"]); ldc.append(Ct.stride(0)); acc.append(a)
+        for (At, Bt, s_) in segs:
+            A.append(At); B.append(Bt); R.append(At.shape[0]); lda.append(At.stride(0)); ldb.append(Bt.stride(0))
+            sh.append(s_); oi.append(k)
+    _hip.require_cuda(*A, *B)
+    _hip.require_f32(*A, *B, *C)
+    nws = lib.mmdfn_gemm_tn_batch_workspace(len(A), ia(R), ia(oi), len(C), ia(M), ia(N))
+    if nws < 0:
+        raise _hip.HipLibraryError("mmdfn_gemm_tn_batch_workspace rejected the batch")
+    ws = torch.empty(int(nws), dtype=torch.float32, device=A[0].device)
+    pa = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+    rc = lib.mmdfn_gemm_tn_batch(len(A), pa(A), pa(B), ia(R), ia(lda), ia(ldb), ia(sh), ia(oi), len(C), pa(C), pa(cs1),
+                                 pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), _hip.stream())
+    _hip.check(rc, "mmdfn_gemm_tn_batch")
 
 
 def join_weight_grads():
-    """Make the current stream wait for every weight-gradient kernel launched on the side stream."""
-    flush_weight_grads()
-    if _WG["dirty"]:
-        torch.cuda.current_stream().wait_stream(_WG["stream"])
-        _WG["dirty"] = False
+    """Kept for callers of earlier versions: the queue is flushed by the end-of-backward callback; this only covers a
+    backward driven outside the autograd engine."""
+    if _WGQ["outs"] and not _WGQ["armed"]:
+        flush_queued_wgrads()
 
 
-class _wgrad_scope:
-    """``with _wgrad_scope(t1, t2, ...):`` runs the block on the side stream (if enabled) behind the main
-    stream's work so far; the listed tensors (main-stream allocations read by the block) are protected from
-    premature reuse by the caching allocator."""
+def set_async_weight_grads(flag):
+    """Removed option (side-stream weight gradients measured slower on MI355X, profiles/r01_propagate_tuning.md)."""
+    if flag:
+        raise NotImplementedError("side-stream weight gradients were removed: they are batched into one launch now")
 
-    def __init__(self, *tensors):
-        self.tensors = tensors
-        self.ctx = None
 
-    def __enter__(self):
-        if _WG["enabled"] is True:
-            side = _wgrad_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            for t in self.tensors:
-                if t is not None:
-                    t.record_stream(side)
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
-            _WG["dirty"] = True
-        return self
+def _wgrad_inline(dy2, x2, want_b):
+    """(dW = dy2^T x2, db = column sums of dy2 or None) computed now and returned to autograd."""
+    if gemm_tn_supported(dy2.shape[1], x2.shape[1]):
+        return gemm_tn(dy2, x2, want_colsum=want_b)
+    return torch.mm(dy2.t(), x2), (dy2.sum(0) if want_b else None)
 
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
+
+def _wgrad(dy2, x2, weight, bias):
+    """dW = dy2^T x2 (+ db = column sums of dy2): queued for the end-of-backward batch when the targets are leaf
+    parameters (returns (None, None): the batch writes .grad itself), computed in line otherwise."""
+    want_b = bias is not None
+    if _queueable(weight, [bias] if want_b else [], dy2.shape[1], x2.shape[1]):
+        queue_wgrad(dy2, x2, weight, [bias] if want_b else [])
+        return None, None
+    return _wgrad_inline(dy2, x2, want_b)
 
 
 class _Linear(torch.autograd.Function):
@@ -561,6 +607,7 @@ class _Linear(torch.autograd.Function):
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.has_base = base is not None
+        ctx.weight_ref, ctx.bias_ref = weight, bias        # the parameter objects themselves (leaf test in backward)
         ctx.save_for_backward(x2, weight, y if act else None)
         return y.view(*shp[:-1], N)
 
@@ -574,7 +621,7 @@ class _Linear(torch.autograd.Function):
         dy2 = dy2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            (dw, db), = _weight_grads([(dy2, x2, ctx.has_bias)])           # dW and db in one pass over dY
+            dw, db = _wgrad(dy2, x2, ctx.weight_ref, ctx.bias_ref)         # dW and db in one pass over dY
         if ctx.needs_input_grad[0]:
             if N % 4 == 0 and linear_preferred(dy2.shape[0], N, K):
                 dx = linear_raw(dy2, weight.t().contiguous(), None, 0)
@@ -590,6 +637,7 @@ class _MatmulKN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w):
+        ctx.weight_ref = w
         ctx.save_for_backward(x, w)
         return torch.mm(x, w)
 
@@ -599,7 +647,7 @@ class _MatmulKN(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[1]:
-            (dw, _), = _weight_grads([(x, dy, False)])                     # dW = x^T dy
+            dw, _ = _wgrad(x, dy, ctx.weight_ref, None)                    # dW = x^T dy
         if ctx.needs_input_grad[0]:
             dx = dy @ w.t()
         return dx, dw
@@ -621,33 +669,6 @@ def _linear_dx(dy2, weight):
     return dy2 @ weight
 
 
-def _weight_grads(jobs):
-    """jobs: list of (dy2 (R, N), x2 (R, K), want_bias) -> list of (dW (N, K), db or None); every job the split-K
-    kernel covers goes into ONE grouped launch pair (the problems are far too small to fill the chip one by one).
-    Outputs are allocated here and filled by a launch closure (run now, forked, or deferred: _run_wgrad)."""
-    res, probs, other = [], [], []
-    for dy2, x2, wb in jobs:
-        N, K = dy2.shape[1], x2.shape[1]
-        dw = torch.empty(N, K, dtype=torch.float32, device=dy2.device)
-        db = torch.empty(N, dtype=torch.float32, device=dy2.device) if wb else None
-        res.append((dw, db))
-        if gemm_tn_supported(N, K):
-            probs.append(dict(A=dy2, B=x2, C=dw, colsum=db))
-        else:
-            other.append((dy2, x2, dw, db))
-
-    def launch():
-        for i in range(0, len(probs), 8):
-            gemm_tn_grouped(probs[i:i + 8])
-        for dy2, x2, dw, db in other:
-            torch.mm(dy2.t(), x2, out=dw)
-            if db is not None:
-                torch.sum(dy2, 0, out=db)
-
-    _run_wgrad(launch, [t for j in jobs for t in j[:2]] + [t for r in res for t in r])
-    return res
-
-
 class _LinearGroup(torch.autograd.Function):
     """n independent projections y_g = act(x_g W_g^T + b_g) that become available together (the three modality
     projections model.py:1065,1094,1129; the hoisted input contractions of the context and the party GRU).  Forward
@@ -664,22 +685,22 @@ class _LinearGroup(torch.autograd.Function):
             ys.append(y.view(*x.shape[:-1], w.shape[0]))
         ctx.n, ctx.act = n, act
         ctx.has_bias = [b is not None for b in bs]
+        ctx.param_refs = list(zip(ws, bs))
         ctx.save_for_backward(*saved)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         n, sv = ctx.n, ctx.saved_tensors
-        dxs, jobs = [], []
+        dxs, wg = [], []
         for g in range(n):
             x2, w, y = sv[3 * g], sv[3 * g + 1], sv[3 * g + 2]
             dy2 = dys[g].reshape(-1, w.shape[0])
             if ctx.act:
                 dy2 = dy2 * (y > 0).to(dy2.dtype)
             dy2 = dy2.contiguous()
-            jobs.append((dy2, x2, ctx.has_bias[g]))
+            wg.append(_wgrad(dy2, x2, ctx.param_refs[g][0], ctx.param_refs[g][1]))
             dxs.append(_linear_dx(dy2, w).view(*dys[g].shape[:-1], w.shape[1]) if ctx.needs_input_grad[2 + g] else None)
-        wg = _weight_grads(jobs)
         return (None, None) + tuple(dxs) + tuple(r[0] for r in wg) + tuple(r[1] for r in wg)
 
 
@@ -692,32 +713,92 @@ def linear_group(xs, weights, biases, act=0):
 
 
 class _GateLinear(torch.autograd.Function):
-    """G = q W_ih^T + h W_hh^T + b: the pre-activation of the layer-shared LSTM cell (model_GCN.py:466, seq_len 1)
-    as one op; dW_ih, dW_hh and db come out of one grouped launch (they share the operand dG)."""
+    """G = q W_ih^T + h W_hh^T + (b_ih + b_hh): the pre-activation of the layer-shared LSTM cell (model_GCN.py:466,
+    seq_len 1) as one op; h may be None (first layer: zero state).  ``bsum`` is b_ih + b_hh computed once per forward
+    pass; the bias gradient goes to both parameters (they share it)."""
 
     @staticmethod
-    def forward(ctx, q, h, w_ih, w_hh, bias):
-        G = _linear_forward(q, w_ih, bias, 0)
-        if linear_supported(h, w_hh) and linear_preferred(h.shape[0], w_hh.shape[1], w_hh.shape[0]):
-            linear_raw(h, w_hh, None, 0, out=G, accumulate=True)
-        else:
-            G = torch.addmm(G, h, w_hh.t())
+    def forward(ctx, q, h, w_ih, w_hh, bsum, b_ih, b_hh):
+        G = _linear_forward(q, w_ih, bsum, 0)
+        if h is not None:
+            if linear_supported(h, w_hh) and linear_preferred(h.shape[0], w_hh.shape[1], w_hh.shape[0]):
+                linear_raw(h, w_hh, None, 0, out=G, accumulate=True)
+            else:
+                G = torch.addmm(G, h, w_hh.t())
+        ctx.has_h = h is not None
+        ctx.refs = (w_ih, w_hh, b_ih, b_hh)
         ctx.save_for_backward(q, h, w_ih, w_hh)
         return G
 
     @staticmethod
     def backward(ctx, dG):
         q, h, w_ih, w_hh = ctx.saved_tensors
+        p_ih, p_hh, b_ih, b_hh = ctx.refs
         dG = dG.contiguous()
         dq = _linear_dx(dG, w_ih) if ctx.needs_input_grad[0] else None
-        dh = _linear_dx(dG, w_hh) if ctx.needs_input_grad[1] else None
-        (dwi, db), (dwh, _) = _weight_grads([(dG, q, True), (dG, h, False)])
-        return dq, dh, dwi, dwh, db
+        dh = _linear_dx(dG, w_hh) if (ctx.has_h and ctx.needs_input_grad[1]) else None
+        dwi = dwh = dbs = dbi = dbh = None
+        M, N = dG.shape[1], q.shape[1]
+        if _queueable(p_ih, [b_ih, b_hh], M, N) and (not ctx.has_h or _queueable(p_hh, [], M, h.shape[1])):
+            queue_wgrad(dG, q, p_ih, [b_ih, b_hh])
+            if ctx.has_h:
+                queue_wgrad(dG, h, p_hh)
+        else:
+            dwi, dbi = _wgrad_inline(dG, q, True)
+            dbh = dbi
+            if ctx.has_h:
+                dwh, _ = _wgrad_inline(dG, h, False)
+        return dq, dh, dwi, dwh, dbs, dbi, dbh
 
 
-def gate_linear(q, h, w_ih, w_hh, bias):
+def gate_linear(q, h, w_ih, w_hh, bsum, b_ih, b_hh):
     _hip.require_cuda(q, h)
-    return _GateLinear.apply(q, h, w_ih, w_hh, bias)
+    return _GateLinear.apply(q, h, w_ih, w_hh, bsum, b_ih, b_hh)
+
+
+class _Linear2(torch.autograd.Function):
+    """y = x [W1; W2]^T + [b1; b2]: one projection whose weight rows live in two parameters (the two directions of a
+    bidirectional GRU layer, nn.GRU weight_ih_l*/ *_reverse) -- one launch on the parameters themselves instead of a
+    concatenated copy per step (csrc/linear.hip, mmdfn_linear2)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, b1, b2):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        _hip.require_cuda(x2, w1, w2)
+        _hip.require_f32(x2, w1, w2, b1, b2)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        R, K = x2.shape
+        n1, N = w1.shape[0], w1.shape[0] + w2.shape[0]
+        y = torch.empty(R, N, dtype=torch.float32, device=x2.device)
+        rc = _hip.lib().mmdfn_linear2(_hip.ptr(x2), _hip.ptr(w1c), _hip.ptr(w2c), n1, _hip.ptr(b1), _hip.ptr(b2), _hip.ptr(y),
+                                      R, K, N, x2.stride(0), N, 0, 0, _hip.stream())
+        _hip.check(rc, "mmdfn_linear2")
+        ctx.refs = (w1, w2, b1, b2)
+        ctx.save_for_backward(x2, w1c, w2c)
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2 = ctx.saved_tensors
+        p1, p2, b1, b2 = ctx.refs
+        n1 = w1.shape[0]
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        d1, d2 = dy2[:, :n1], dy2[:, n1:]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.addmm(d1 @ w1, d2, w2).view(*dy.shape[:-1], w1.shape[1])
+        dw1, db1 = _wgrad(d1, x2, p1, b1)
+        dw2, db2 = _wgrad(d2, x2, p2, b2)
+        return dx, dw1, dw2, db1, db2
+
+
+def linear2(x, w1, w2, b1, b2):
+    if w1.shape[1] % 4 or w1.shape[1] < 4:
+        raise ValueError("linear2: the contraction width must be a multiple of 4")
+    return _Linear2.apply(x, w1, w2, b1, b2)
 
 
 def matmul_kn(x, w):

@@ -88,7 +88,9 @@ class StepGraphCache:
             with torch.set_grad_enabled(bool(train_flag)):
                 cap = CapturedStep(model, fn, warmup=self.warmup)
             model.train(mode)
-            ent = dict(static=static, cap=cap, out=out, flat=flat)
+            # everything the graph reads that was allocated OUTSIDE the capture must live as long as the graph: the
+            # static inputs, the label gather index and the flattened labels (the closure itself is kept by cap)
+            ent = dict(static=static, cap=cap, out=out, flat=flat, pos=pos)
             self.entries[key] = ent
             while len(self.entries) > self.max_entries:
                 self.entries.popitem(last=False)

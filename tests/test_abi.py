@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(build.LIBPATH)
     for s in declared_symbols():
         assert hasattr(handle, s), "missing export %s" % s
-    assert handle.mmdfn_abi_version() == 3
+    from mm_dfn_amd import _hip
+    assert handle.mmdfn_abi_version() == _hip.ABI_VERSION
 
 
 def test_binding_table_matches_header():

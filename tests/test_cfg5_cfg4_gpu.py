@@ -97,31 +97,38 @@ def test_cfg5_adjacency_propagate_and_their_gradients_against_oracle_slice(B, j)
     # K5 forward: adjacency tiles and cross-modal diagonals of dialogue j
     base = int(lay.tile_base_host[j])
     t_d = adj.tiles[base: base + M * L * L]
-    assert rel_err(t_d, t_o.detach()) < 2e-5
-    assert rel_err(adj.cross[:, sl], c_o.detach()) < 2e-5
+    e = rel_err(t_d, t_o.detach())
+    assert e < 2e-5, "adjacency tiles rel err %.3g" % e
+    e = rel_err(adj.cross[:, sl], c_o.detach())
+    assert e < 2e-5, "cross-modal diagonals rel err %.3g" % e
 
     # K6 forward through the autograd op (the bf16-piece kernel at this size)
     out = ops.propagate(adj, H)
     got_j = torch.cat([out[m_ * N + j * L: m_ * N + (j + 1) * L] for m_ in range(M)], 0)
-    assert rel_err(got_j, out_o.detach()) < 1e-5
+    e = rel_err(got_j, out_o.detach())
+    assert e < 1e-5, "propagate rel err %.3g" % e
 
     # K6 backward: dH = A^T dO, dA = dO H^T on the tile pattern, then K5 backward down to the features
     out.backward(dO_cpu.to(DEV))
     out_o.backward(dOj)
     dH_j = torch.cat([H.grad[m_ * N + j * L: m_ * N + (j + 1) * L] for m_ in range(M)], 0)
-    assert rel_err(dH_j, Hj.grad) < 1e-5
+    e = rel_err(dH_j, Hj.grad)
+    assert e < 1e-5, "dH rel err %.3g" % e
     want_df = torch.stack([f.grad for f in fj], 0)
-    assert rel_err(feats.grad[:, sl], want_df) < 1e-4
+    e = rel_err(feats.grad[:, sl], want_df)
+    assert e < 1e-4, "dfeats (through K6', K5 backward) rel err %.3g" % e
 
     # tile_outer alone (dtiles / dcross of dialogue j) against the dense outer product on the pattern
     dt, dc = ops.tile_outer_raw(dO_cpu.to(DEV), H_cpu.to(DEV), lay)
     G = dOj @ Hj.detach().t()                                  # (ML, ML): dense dL/dA of dialogue j
     want_t = torch.cat([G[m_ * L:(m_ + 1) * L, m_ * L:(m_ + 1) * L].reshape(-1) for m_ in range(M)])
-    assert rel_err(dt[base: base + M * L * L], want_t) < 1e-5
+    e = rel_err(dt[base: base + M * L * L], want_t)
+    assert e < 1e-5, "tile_outer tiles rel err %.3g" % e
     ar = torch.arange(L)
     for k, (m_, n_) in enumerate(pair_list(M)):
         want_c = G[m_ * L + ar, n_ * L + ar] + G[n_ * L + ar, m_ * L + ar]
-        assert rel_err(dc[k, sl], want_c) < 1e-5, (m_, n_)
+        e = rel_err(dc[k, sl], want_c)
+        assert e < 1e-5, "tile_outer cross (%d,%d) rel err %.3g" % (m_, n_, e)
 
 
 def test_cfg5_whole_batch_properties():

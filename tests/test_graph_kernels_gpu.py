@@ -399,3 +399,70 @@ def test_tile_outer_bf16_piece_kernel(lengths, M, d, kernel_variants):
     acc_t, acc_c = dt0.clone(), dc0.clone()
     ops.tile_outer_raw(X, Y, lay, dtiles=acc_t, dcross=acc_c)
     assert float((acc_t - 2 * dt0).abs().max()) / float(dt0.abs().max()) < 4e-6
+
+
+def test_weight_gradient_batch_kernel():
+    """mmdfn_gemm_tn_batch: every weight-gradient contraction of a step in one launch pair -- several segments per
+    output (summed in the slab reduction), row shifts, strided operand views, two bias destinations, accumulate."""
+    rs = np.random.RandomState(71)
+    t = lambda *shape: torch.from_numpy(rs.randn(*shape).astype(np.float32)).to(DEV)
+    H = 100
+    # output 0: a GRU recurrent weight (300 x 100) from one shifted segment with column sums
+    T, R = 9, 8
+    dgh, y = t(T * R, 6 * H), t(T * R, 2 * H)
+    # output 1: the layer-shared LSTM gate (400 x 100): three segments of different row counts, two bias targets
+    dG = [t(n, 4 * H) for n in (333, 64, 1500)]
+    q = [t(n, H) for n in (333, 64, 1500)]
+    # output 2: a wide projection (200 x 512) accumulated into an existing gradient
+    dy, x = t(777, 200), t(777, 512)
+    w = [torch.empty(3 * H, H, device=DEV), torch.empty(4 * H, H, device=DEV), t(200, 512)]
+    b = [torch.empty(3 * H, device=DEV), torch.empty(4 * H, device=DEV), torch.empty(4 * H, device=DEV), t(200)]
+    old_w2, old_b3 = w[2].clone(), b[3].clone()
+    o0 = dict(M=3 * H, N=H)
+    o1 = dict(M=4 * H, N=H)
+    o2 = dict(M=200, N=512)
+    batch = [(o0, w[0], [b[0]], 0, [(dgh[:, 3 * H:], y[:, H:], R)]),
+             (o1, w[1], [b[1], b[2]], 0, [(dG[i], q[i], 0) for i in range(3)]),
+             (o2, w[2], [b[3]], 1, [(dy, x, 0)])]
+    ops._launch_wgrad_batch(batch)
+    A, B = dgh[:, 3 * H:].double().cpu(), y[:, H:].double().cpu()
+    want0 = A[:-R].t() @ B[R:]                                # row r of A pairs with row r + R of B
+    assert rel_err(w[0], want0) < 1e-5
+    assert rel_err(b[0], A.sum(0)) < 1e-5
+    want1 = sum(g.double().cpu().t() @ v.double().cpu() for g, v in zip(dG, q))
+    assert rel_err(w[1], want1) < 1e-5
+    wb = sum(g.double().cpu().sum(0) for g in dG)
+    assert rel_err(b[1], wb) < 1e-5 and torch.equal(b[1], b[2])
+    assert rel_err(w[2], old_w2.double().cpu() + dy.double().cpu().t() @ x.double().cpu()) < 1e-5
+    assert rel_err(b[3], old_b3.double().cpu() + dy.double().cpu().sum(0)) < 1e-5
+    # a negative shift (forward GRU direction: h_{t-1}) and a long reduction (many splits)
+    Rl = 40000
+    a2, b2 = t(Rl, 100), t(Rl, 200)
+    out = torch.empty(100, 200, device=DEV)
+    ops._launch_wgrad_batch([(dict(M=100, N=200), out, [], 0, [(a2, b2, -16)])])
+    assert rel_err(out, a2[16:].double().cpu().t() @ b2[:-16].double().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("R,K,n1,n2", [(300, 200, 300, 300), (7040, 200, 300, 300), (129, 36, 4, 100), (2000, 100, 260, 52)])
+def test_two_block_projection(R, K, n1, n2):
+    """mmdfn_linear2: output columns from two weight / bias parameters (the directions of a bidirectional GRU layer),
+    forward vs torch, gradients of x / both weights / both biases vs autograd on the concatenated form."""
+    rs = np.random.RandomState(72)
+    mk = lambda *s: torch.from_numpy(rs.randn(*s).astype(np.float32)).to(DEV)
+    x = mk(R, K).requires_grad_(True)
+    w1, w2 = torch.nn.Parameter(mk(n1, K)), torch.nn.Parameter(mk(n2, K))
+    b1, b2 = torch.nn.Parameter(mk(n1)), torch.nn.Parameter(mk(n2))
+    W = mk(R, n1 + n2)
+    y = ops.linear2(x, w1, w2, b1, b2)
+    (y * W).sum().backward()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    pr = [p.detach().double().cpu().requires_grad_(True) for p in (w1, w2, b1, b2)]
+    yr = xr @ torch.cat([pr[0], pr[1]], 0).t() + torch.cat([pr[2], pr[3]], 0)
+    (yr * W.double().cpu()).sum().backward()
+    assert rel_err(y, yr) < 2e-6
+    assert rel_err(x.grad, xr.grad) < 1e-5
+    for p, r in zip((w1, w2, b1, b2), pr):
+        assert p.grad is not None and rel_err(p.grad, r.grad) < 1e-5
+    # no biases (the project-then-gather path adds the bias after the gather)
+    y0 = ops.linear2(x.detach(), w1, w2, None, None)
+    assert rel_err(y0, yr - torch.cat([pr[2], pr[3]], 0)) < 2e-6
