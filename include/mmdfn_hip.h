@@ -228,6 +228,42 @@ int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, f
                           const int* bshift, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Fused stages of the GCNII "dynamic fusion" stack (GCNII_lyc.forward model_GCN.py:444-488, GraphConvolution.forward
+ * :176-189): each is ONE launch whose dense contraction runs as exact-f32 MFMA with the pointwise work in its
+ * prologue / epilogue (csrc/gcn_stack.hip).  R rows (= M * N graph nodes), H = hidden width (<= 128, multiple of 4),
+ * F = input width (<= 256, multiple of 4); every mask is a float keep-mask already scaled by 1/(1-p), NULL = ones.
+ *
+ * input stage (model_GCN.py:453-456):  xd = x (.) mx (row stride ldxd);  h0 = relu(xd W0^T + b0);  cur0 = h0 (.) m0
+ *   bwd:  dpre = (dcur0 (.) m0 + dh0) (.) [h0 > 0]  (operand of dW0 / db0);  dx = (dpre W0 + dxd) (.) mx,
+ *         dxd = gradient reaching xd directly (row stride lddxd) or NULL.
+ * gate (K8, model_GCN.py:463-467, nn.LSTM seq_len 1, gate order i f g o, W_ih / W_hh (4H, H), bsum = b_ih + b_hh):
+ *   fwd:  (h_out, c_out) = LSTMCell(q, (h, c));  h = c = NULL is the zero state;  gates (R, 4H) = gate ACTIVATIONS.
+ *   bwd:  dh' = dh_a + dh_b (either NULL), dc_next (NULL = 0) -> dG (R, 4H) pre-activation gradients (operand of
+ *         dW_ih, dW_hh, db), dc_prev, dq = dG W_ih + dres (row stride lddres, NULL = 0), dh_prev = dG W_hh;  has_h = 0: the incoming
+ *         state was zero, dc_prev / dh_prev are not produced.
+ * layer (K7, model_GCN.py:178-186,469-472, W (2H, H) as stored by GraphConvolution):
+ *   fwd:  pre = theta [hi | h0] W + (1-theta)((1-alpha) hi + alpha h0);  out = relu(pre) (.) m + q (row stride ldo, q
+ *         NULL = 0);  gmask = m (.) [pre > 0].
+ *   bwd:  dP = theta dout (.) gmask (operand of dW = [hi | h0]^T dP; dout row stride lddo);
+ *         dhi = dP W[:H]^T + (1-theta)(1-alpha) gg,  dh0 (+)= dP W[H:]^T + (1-theta) alpha gg,  gg = dout (.) gmask;
+ *         acc_h0 != 0 accumulates into dh0 (h0 feeds every layer).
+ * ------------------------------------------------------------------------- */
+int mmdfn_gcn_input_fwd(const float* x, const float* mx, const float* W0, const float* b0, const float* m0, float* xd,
+                        float* h0, float* cur0, int R, int F, int H, int ldxd, void* stream);
+int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const float* dh0, const float* h0, const float* W0,
+                        const float* dxd, const float* mx, float* dpre, float* dx, int R, int F, int H, int lddxd,
+                        void* stream);
+int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                        const float* bsum, float* gates, float* h_out, float* c_out, int R, int H, void* stream);
+int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh_a, const float* dh_b,
+                        const float* dc_next, const float* Wih, const float* Whh, const float* dres, float* dG,
+                        float* dc_prev, float* dq, float* dh_prev, int R, int H, int has_h, int lddres, void* stream);
+int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const float* W, const float* q, const float* m, float* out,
+                          float* gmask, float theta, float alpha, int R, int H, int ldo, void* stream);
+int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
+                          float theta, float alpha, int R, int H, int lddo, int acc_h0, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Batch form: EVERY weight-gradient contraction of a training step in one launch pair (they feed nothing but the
  * optimizer, so the host queues them during backward and issues them at its end; run_train_erc.py:208 autograd).
  *   segment s (0 <= s < nseg):  A_s (R_s rows, stride lda_s), B_s (R_s rows, stride ldb_s), row shift bshift_s on B,

@@ -28,6 +28,12 @@ SIGNATURES = {
     "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_gcnii_combine_bwd": [_P, _P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
+    "mmdfn_gcn_input_fwd": [_P] * 8 + [_I] * 4 + [_P],
+    "mmdfn_gcn_input_bwd": [_P] * 9 + [_I] * 4 + [_P],
+    "mmdfn_lstm_gate_fwd": [_P] * 9 + [_I] * 2 + [_P],
+    "mmdfn_lstm_gate_bwd": [_P] * 13 + [_I] * 4 + [_P],
+    "mmdfn_gcnii_layer_fwd": [_P] * 7 + [_F, _F, _I, _I, _I, _P],
+    "mmdfn_gcnii_layer_bwd": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _P],
     "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_gemm_tn_splits": [_I, _I, _I],
@@ -45,7 +51,7 @@ SIGNATURES = {
     "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):

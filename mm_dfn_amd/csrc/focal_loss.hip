@@ -29,6 +29,7 @@ __global__ __launch_bounds__(FL_NT) void focal_loss_fwd_kernel(const float* __re
         const float pt = expf(lp);
         float wgt = (gamma == 0.f) ? 1.f : powf(fmaxf(1.f - pt, 0.f), gamma);
         if (alpha != nullptr) wgt *= alpha[t];
+        if (bad) wgt = __builtin_nanf("");               // (fmaxf / powf above swallow the NaN of lp)
         coef[i] = -wgt * scale;
         acc += -wgt * lp;
     }

@@ -1,0 +1,151 @@
+"""The GCNII "dynamic fusion" stack (reference GCNII_lyc.forward, model_GCN.py:444-488) as ONE autograd node.
+
+Forward = 1 + 3 launches per layer (input stage; per layer: LSTM gate K8, propagate K6, GCNII update K7), backward =
+1 + 5 per layer (K7', K6', the two tile-pattern kernels of dA, K8') -- every stage is a fused kernel of
+csrc/gcn_stack.hip / propagate.hip / tile_dot.hip.  Written as a single ``torch.autograd.Function`` with a
+hand-scheduled backward because the stack's dataflow has three fan-outs that autograd would serve with accumulation
+kernels: h0 feeds every layer (the kernels accumulate dh0 in place), the adjacency feeds every layer (tile_outer
+accumulates dA in place) and the LSTM cell is shared by all layers (its weight gradients are extra segments of one
+reduction in the end-of-backward batch, ops.queue_wgrad).  Parameters must be leaf tensors (their gradients are
+written to ``.grad`` by that batch); GCNII_lyc falls back to the op-by-op path otherwise, and for launches of more
+than ROW_LIMIT rows, where the unfused contractions run on the bf16-piece pipeline instead of 16-row exact-f32 blocks.
+"""
+import math
+
+import torch
+
+from . import _hip, ops
+
+ROW_LIMIT = 32768
+
+
+def eligible(x, nfeat, nhidden, nlayers, params):
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= ROW_LIMIT and nlayers >= 1
+            and nhidden % 4 == 0 and 4 <= nhidden <= 128 and nfeat % 4 == 0 and 4 <= nfeat <= 256
+            and (not torch.is_grad_enabled() or all(ops._leaf(p) for p in params)))
+
+
+class _GcnStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tiles, cross, masks, lay, symmetric, lamda, alpha, reason, use_residue, W0, b0, w_ih, w_hh, b_ih,
+                b_hh, *convW):
+        lib = _hip.lib()
+        P, st = _hip.ptr, _hip.stream()
+        x = x.contiguous()
+        R, F = x.shape
+        H = W0.shape[0]
+        nl = len(convW)
+        dev = x.device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        mx = m0 = None
+        ml = [None] * nl
+        if masks is not None:
+            mx = masks[:R * F].view(R, F)
+            m0 = masks[R * F:R * (F + H)].view(R, H)
+            ml = [masks[R * (F + H) + i * R * H: R * (F + H) + (i + 1) * R * H].view(R, H) for i in range(nl)]
+        out = new(R, F + H) if use_residue else new(R, H)
+        xd = out if use_residue else new(R, F)                 # x_d lives in the left F columns of the residue output
+        ldxd = F + H if use_residue else F
+        h0, cur = new(R, H), new(R, H)
+        _hip.check(lib.mmdfn_gcn_input_fwd(P(x), P(mx), P(W0), P(b0), P(m0), P(xd), P(h0), P(cur), R, F, H, ldxd, st),
+                   "mmdfn_gcn_input_fwd")
+        bsum = (b_ih + b_hh) if reason else None
+        h = c = None
+        layers = []
+        for i in range(nl):
+            q = cur
+            rec = dict(q=q, h_prev=h, c_prev=c)
+            if reason:
+                gates, h_new, c_new = new(R, 4 * H), new(R, H), new(R, H)
+                _hip.check(lib.mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(w_ih), P(w_hh), P(bsum), P(gates), P(h_new), P(c_new),
+                                                   R, H, st), "mmdfn_lstm_gate_fwd")
+                rec.update(gates=gates, c_new=c_new)
+                h, c = h_new, c_new
+                zin = h_new
+            else:
+                zin = q
+            hi = ops.propagate_raw(tiles, cross, zin, lay)
+            last = i == nl - 1
+            if last and use_residue:
+                dst, ldo = out[:, F:], F + H
+            elif last:
+                dst, ldo = out, H
+            else:
+                dst, ldo = new(R, H), H
+            gmask = new(R, H)
+            theta = math.log(lamda / (i + 1) + 1)
+            _hip.check(lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(convW[i]), P(q if reason else None), P(ml[i]), P(dst),
+                                                 P(gmask), theta, alpha, R, H, ldo, st), "mmdfn_gcnii_layer_fwd")
+            rec.update(zin=zin, hi=hi, gmask=gmask, theta=theta)
+            layers.append(rec)
+            cur = dst
+        ctx.layers = layers
+        # (xd is a detached alias: holding the output itself would tie this node and its output into a reference cycle)
+        ctx.misc = dict(lay=lay, symmetric=symmetric, alpha=alpha, reason=reason, use_residue=use_residue, R=R, F=F, H=H,
+                        mx=mx, m0=m0, xd=xd.detach(), h0=h0, tiles=tiles, cross=cross)
+        ctx.params = (W0, b0, w_ih, w_hh, b_ih, b_hh, convW)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _hip.lib()
+        P, st = _hip.ptr, _hip.stream()
+        m = ctx.misc
+        R, F, H = m["R"], m["F"], m["H"]
+        W0, b0, w_ih, w_hh, b_ih, b_hh, convW = ctx.params
+        lay, tiles, cross = m["lay"], m["tiles"], m["cross"]
+        dev = dout.device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        dout = dout.contiguous()
+        if m["use_residue"]:
+            dcur, lddo, dxd, lddxd = dout[:, F:], F + H, dout, F + H
+        else:
+            dcur, lddo, dxd, lddxd = dout, H, None, 0
+        want_adj = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dh0 = new(R, H)
+        acc_h0 = 0
+        dtiles = dcross = None
+        dh_carry = dc_carry = None
+        for i in reversed(range(len(ctx.layers))):
+            L = ctx.layers[i]
+            dP, dhi = new(R, H), new(R, H)
+            _hip.check(lib.mmdfn_gcnii_layer_bwd(P(dcur), P(L["gmask"]), P(convW[i]), P(dP), P(dhi), P(dh0), L["theta"],
+                                                 m["alpha"], R, H, lddo, acc_h0, st), "mmdfn_gcnii_layer_bwd")
+            acc_h0 = 1
+            # dW_i = [hi | h0]^T dP: two row ranges of the (2H, H) parameter, the concatenated operand never exists
+            ops.queue_wgrad(L["hi"], dP, convW[i], rows=(0, H))
+            ops.queue_wgrad(m["h0"], dP, convW[i], rows=(H, 2 * H))
+            dz = ops.propagate_raw(tiles, cross, dhi, lay, transpose=not m["symmetric"])
+            if want_adj:
+                dtiles, dcross = ops.tile_outer_raw(dhi, L["zin"], lay, dtiles, dcross)
+            if m["reason"]:
+                has_h = L["h_prev"] is not None
+                dG, dq = new(R, 4 * H), new(R, H)
+                dh_prev = new(R, H) if has_h else None
+                dc_prev = new(R, H) if has_h else None
+                _hip.check(lib.mmdfn_lstm_gate_bwd(P(L["gates"]), P(L["c_prev"]), P(L["c_new"]), P(dz), P(dh_carry),
+                                                   P(dc_carry), P(w_ih), P(w_hh), P(dcur), P(dG), P(dc_prev), P(dq),
+                                                   P(dh_prev), R, H, 1 if has_h else 0, lddo, st), "mmdfn_lstm_gate_bwd")
+                ops.queue_wgrad(dG, L["q"], w_ih, [b_ih, b_hh])
+                if has_h:
+                    ops.queue_wgrad(dG, L["h_prev"], w_hh)
+                dcur, lddo = dq, H
+                dh_carry, dc_carry = dh_prev, dc_prev
+            else:
+                dcur, lddo = dz, H
+        dpre, dx = new(R, H), new(R, F)
+        _hip.check(lib.mmdfn_gcn_input_bwd(P(dcur), P(m["m0"]), P(dh0), P(m["h0"]), P(W0), P(dxd), P(m["mx"]), P(dpre), P(dx), R,
+                                           F, H, lddxd, st), "mmdfn_gcn_input_bwd")
+        xd = m["xd"][:, :F] if m["use_residue"] else m["xd"]
+        ops.queue_wgrad(dpre, xd, W0, [b0] if b0 is not None else [])
+        return (dx, dtiles, dcross) + (None,) * (13 + len(convW))
+
+
+def gcn_stack(x, adj, masks, lamda, alpha, reason_flag, use_residue, W0, b0, lstm, convs):
+    """x (R, F) -> [x (.) m_x | cur] (R, F + H) (or cur alone without use_residue).  ``masks``: one flat fp32 tensor of
+    keep-masks scaled by 1/(1-p) for x, h0 and every layer (R F + R H + nl R H floats), or None (eval / p = 0)."""
+    w_ih = w_hh = b_ih = b_hh = None
+    if reason_flag:
+        w_ih, w_hh, b_ih, b_hh = lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0
+    return _GcnStack.apply(x, adj.tiles, adj.cross, masks, adj.layout, adj.symmetric, float(lamda), float(alpha),
+                           bool(reason_flag), bool(use_residue), W0, b0, w_ih, w_hh, b_ih, b_hh, *convs)

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
-from . import _hip, ops
+from . import _hip, gcn_stack, ops
 from .layout import BlockTileAdjacency
 
 
@@ -101,9 +101,34 @@ class GCNII_lyc(nn.Module):
             return None
         return F.dropout(torch.ones_like(like), self.dropout, True)
 
+    def _forward_stack(self, x, adj):
+        """Dialogue-graph sizes: the whole stack as one autograd node of fused kernels (gcn_stack.py)."""
+        R, nfeat = x.shape
+        H = con_width(self.convs)
+        masks = None
+        if self.training and self.dropout > 0:
+            # the keep-masks of x, h0 and every layer from one fill + one dropout launch (scaled by 1/(1-p))
+            masks = F.dropout(torch.ones(R * nfeat + (1 + len(self.convs)) * R * H, dtype=x.dtype, device=x.device),
+                              self.dropout, True)
+        cur = gcn_stack.gcn_stack(x, adj, masks, self.lamda, self.alpha, self.reason_flag, self.use_residue,
+                                  self.fcs[0].weight, self.fcs[0].bias, self.rnn, [c.weight for c in self.convs])
+        if not self.return_feature:
+            cur = F.log_softmax(self.fcs[-1](cur), dim=1)
+        return cur
+
+    def _stack_params(self):
+        ps = [self.fcs[0].weight, self.fcs[0].bias] + [c.weight for c in self.convs]
+        if self.reason_flag:
+            ps += [self.rnn.weight_ih_l0, self.rnn.weight_hh_l0, self.rnn.bias_ih_l0, self.rnn.bias_hh_l0]
+        return ps
+
     def _forward_fused(self, x, adj):
-        """MI355X path: per layer = gate GEMM(s) + fused LSTM-cell kernel + propagate (writes [A.x | h0] in
-        place) + support GEMM + fused GCNII update kernel."""
+        """MI355X path.  Dialogue-graph sizes: one fused autograd node (gcn_stack.py).  Long-dialogue batches (~10^5
+        rows) and non-leaf parameters: per layer = gate GEMM(s) + fused LSTM-cell kernel + propagate (writes
+        [A.x | h0] in place) + support GEMM + fused GCNII update kernel."""
+        if (self.inner_dropout and not self.final_dropout
+                and gcn_stack.eligible(x, x.shape[1], con_width(self.convs), len(self.convs), self._stack_params())):
+            return self._forward_stack(x, adj)
         x = F.dropout(x, self.dropout, training=self.training)
         h0 = ops.linear(x, self.fcs[0].weight, self.fcs[0].bias, act=1)      # Linear + ReLU fused
         cur = F.dropout(h0, self.dropout, training=self.training)

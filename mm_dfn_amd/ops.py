@@ -465,20 +465,24 @@ def _queueable(weight, biases, M, N):
     return _leaf(weight) and all(_leaf(b) for b in biases) and gemm_tn_supported(M, N) and len(biases) <= 2
 
 
-def queue_wgrad(A, B, weight, biases=(), shift=0):
+def queue_wgrad(A, B, weight, biases=(), shift=0, rows=None):
     """weight.grad (M, N) += sum_r A[r]^T B[r + shift];  b.grad (M) += column sums of A for every b in ``biases``.
+    ``rows = (r0, r1)``: the contraction fills rows r0..r1-1 of weight.grad only (GraphConvolution.weight takes its two
+    halves from hi^T dP and h0^T dP, the concatenated operand [hi | h0] never exists).
     Only valid inside a backward pass (the flush is an end-of-backward callback)."""
     A = _strided_rows(A)
     B = _strided_rows(B)
-    key = id(weight)
+    r0, r1 = rows if rows is not None else (0, weight.shape[0])
+    key = (id(weight), r0)
     out = _WGQ["outs"].get(key)
     if out is None:
-        out = dict(weight=weight, biases=[], M=A.shape[1], N=B.shape[1], segs=[])
+        out = dict(weight=weight, biases=[], M=A.shape[1], N=B.shape[1], segs=[], rows=(r0, r1))
         _WGQ["outs"][key] = out
     for b in biases:
         if all(b is not x for x in out["biases"]):
             out["biases"].append(b)
-    if len(out["biases"]) > 2 or (A.shape[1], B.shape[1]) != (out["M"], out["N"]) or tuple(weight.shape) != (out["M"], out["N"]):
+    if (len(out["biases"]) > 2 or (A.shape[1], B.shape[1]) != (out["M"], out["N"]) or out["rows"] != (r0, r1)
+            or r1 - r0 != out["M"] or weight.shape[1] != out["N"] or (rows is not None and biases)):
         raise RuntimeError("queue_wgrad: inconsistent contributions to one parameter")
     out["segs"].append((A, B, int(shift)))
     if not _WGQ["armed"]:
@@ -496,22 +500,31 @@ def flush_queued_wgrads():
     # gradient destinations: fresh buffers handed to .grad (the usual case: backward runs with .grad = None), or the
     # existing .grad accumulated in place
     work = []                                   # (out, C, colsum targets, accumulate, segment slice)
+    fresh = set()                               # gradients allocated by this flush (their row ranges are disjoint)
     for o in outs:
         w = o["weight"]
-        have = [w.grad is not None] + [b.grad is not None for b in o["biases"]]
+        have = [w.grad is not None and id(w) not in fresh] + [b.grad is not None for b in o["biases"]]
         acc = any(have)
+        full = o["rows"] == (0, w.shape[0])
         if w.grad is None:
-            w.grad = (torch.zeros if acc else torch.empty)(o["M"], o["N"], dtype=torch.float32, device=dev)
+            # a row-range contribution may be the only one of its parameter: rows nobody fills must be zero
+            w.grad = (torch.empty if (full and not acc) else torch.zeros)(tuple(w.shape), dtype=torch.float32, device=dev)
+            fresh.add(id(w))
         elif not w.grad.is_contiguous():
             w.grad = w.grad.contiguous()
+        C = w.grad if full else w.grad[o["rows"][0]:o["rows"][1]]
+        if id(w) in fresh and not full:
+            acc_here = 1                        # zero-initialised above: adding is the same as writing
+        else:
+            acc_here = 1 if acc else 0
         cs = []
         for b in o["biases"]:
             if b.grad is None:
-                b.grad = (torch.zeros if acc else torch.empty)(o["M"], dtype=torch.float32, device=dev)
+                b.grad = (torch.zeros if acc_here else torch.empty)(o["M"], dtype=torch.float32, device=dev)
             cs.append(b.grad)
         segs = o["segs"]
         for i in range(0, len(segs), _WG_MAX):          # a parameter with > 40 contributions: later pieces accumulate
-            work.append((o, w.grad, cs, 1 if (acc or i > 0) else 0, segs[i:i + _WG_MAX]))
+            work.append((o, C, cs, 1 if (acc_here or i > 0) else 0, segs[i:i + _WG_MAX]))
     batch, nseg = [], 0
     for item in work:
         if batch and (nseg + len(item[4]) > _WG_MAX or len(batch) >= _WG_MAX):

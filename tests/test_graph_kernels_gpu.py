@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import mmdfn_oracle as O
-from mm_dfn_amd import ops
+from mm_dfn_amd import GCNII_lyc, ops, synthetic
 from mm_dfn_amd.layout import BlockTileAdjacency, DialogueLayout, pair_list
 from util import abs_err, random_block_adjacency, rel_err
 
@@ -466,3 +466,193 @@ def test_two_block_projection(R, K, n1, n2):
     # no biases (the project-then-gather path adds the bias after the gather)
     y0 = ops.linear2(x.detach(), w1, w2, None, None)
     assert rel_err(y0, yr - torch.cat([pr[2], pr[3]], 0)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fused stages of the GCNII stack (csrc/gcn_stack.hip) against float64 restatements of model_GCN.py:453-472,176-189
+# ------------------------------------------------------------------------------------------------------------------
+def _rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.randn(*shape) * scale).astype(np.float32)).to(DEV)
+
+
+def _keep(rs, *shape, p=0.5):
+    return torch.from_numpy(((rs.uniform(size=shape) > p) / (1 - p)).astype(np.float32)).to(DEV)
+
+
+@pytest.mark.parametrize("R,F,H,masked,residue", [(37, 200, 100, True, True), (16, 52, 36, False, False), (1000, 200, 100, True, True),
+                                                   (5, 8, 4, True, False)])
+def test_gcn_input_stage_kernels(R, F, H, masked, residue):
+    from mm_dfn_amd import _hip
+    lib, P, st = _hip.lib(), _hip.ptr, _hip.stream
+    rs = np.random.RandomState(81)
+    x, W0, b0 = _rnd(rs, R, F), _rnd(rs, H, F, scale=0.1), _rnd(rs, H)
+    mx, m0 = (_keep(rs, R, F), _keep(rs, R, H)) if masked else (None, None)
+    ld = F + H if residue else F
+    xd_buf = torch.full((R, ld), 7.0, device=DEV)
+    h0, cur0 = torch.empty(R, H, device=DEV), torch.empty(R, H, device=DEV)
+    assert lib.mmdfn_gcn_input_fwd(P(x), P(mx), P(W0), P(b0), P(m0), P(xd_buf), P(h0), P(cur0), R, F, H, ld, st()) == 0
+    d = lambda t: None if t is None else t.double().cpu()
+    xd_w = d(x) * (d(mx) if masked else 1.0)
+    h0_w = torch.relu(xd_w @ d(W0).t() + d(b0))
+    cur_w = h0_w * (d(m0) if masked else 1.0)
+    assert rel_err(xd_buf[:, :F], xd_w) < 1e-6 and (not residue or float(xd_buf[:, F:].min()) == 7.0)
+    assert rel_err(h0, h0_w) < 2e-6 and rel_err(cur0, cur_w) < 2e-6
+    # backward
+    dcur0, dh0 = _rnd(rs, R, H), _rnd(rs, R, H)
+    dout = _rnd(rs, R, ld)
+    dpre, dx = torch.empty(R, H, device=DEV), torch.empty(R, F, device=DEV)
+    assert lib.mmdfn_gcn_input_bwd(P(dcur0), P(m0), P(dh0), P(h0), P(W0), P(dout) if residue else None, P(mx), P(dpre), P(dx),
+                                   R, F, H, ld, st()) == 0
+    dpre_w = (d(dcur0) * (d(m0) if masked else 1.0) + d(dh0)) * (h0_w > 0)
+    dx_w = (dpre_w @ d(W0) + (d(dout)[:, :F] if residue else 0.0)) * (d(mx) if masked else 1.0)
+    assert rel_err(dpre, dpre_w) < 1e-6 and rel_err(dx, dx_w) < 2e-6
+
+
+@pytest.mark.parametrize("R,H,first", [(37, 100, False), (37, 100, True), (600, 36, False), (3, 4, True), (2000, 128, False)])
+def test_lstm_gate_kernels(R, H, first):
+    from mm_dfn_amd import _hip
+    lib, P, st = _hip.lib(), _hip.ptr, _hip.stream
+    rs = np.random.RandomState(82)
+    q = _rnd(rs, R, H)
+    h, c = (None, None) if first else (_rnd(rs, R, H), _rnd(rs, R, H))
+    Wih, Whh, bsum = _rnd(rs, 4 * H, H, scale=0.2), _rnd(rs, 4 * H, H, scale=0.2), _rnd(rs, 4 * H)
+    gates, h_out, c_out = (torch.empty(R, n, device=DEV) for n in (4 * H, H, H))
+    assert lib.mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(Wih), P(Whh), P(bsum), P(gates), P(h_out), P(c_out), R, H, st()) == 0
+    d = lambda t: None if t is None else t.double().cpu()
+    qd = d(q).requires_grad_(True)
+    hd = None if first else d(h).requires_grad_(True)
+    cd = None if first else d(c).requires_grad_(True)
+    G = qd @ d(Wih).t() + d(bsum) + (0 if first else hd @ d(Whh).t())
+    i, f, g, o = (torch.sigmoid(G[:, :H]), torch.sigmoid(G[:, H:2 * H]), torch.tanh(G[:, 2 * H:3 * H]), torch.sigmoid(G[:, 3 * H:]))
+    c_w = i * g + (0 if first else f * cd)
+    h_w = o * torch.tanh(c_w)
+    assert rel_err(h_out, h_w) < 2e-6 and rel_err(c_out, c_w) < 2e-6
+    assert rel_err(gates, torch.cat([i, f, g, o], 1)) < 2e-6
+    # backward: upstream gradients on h' (two addends), on c', and the residual addend of dq
+    dh_a, dh_b, dc_n, dres_w = _rnd(rs, R, H), _rnd(rs, R, H), _rnd(rs, R, H), _rnd(rs, R, H + 12)
+    dres = dres_w[:, 4:4 + H]                                       # strided residual gradient
+    G.retain_grad()
+    (h_w * (d(dh_a) + d(dh_b))).sum().backward(retain_graph=True)
+    (c_w * d(dc_n)).sum().backward()
+    dG, dq = torch.empty(R, 4 * H, device=DEV), torch.empty(R, H, device=DEV)
+    dcp = None if first else torch.empty(R, H, device=DEV)
+    dhp = None if first else torch.empty(R, H, device=DEV)
+    assert lib.mmdfn_lstm_gate_bwd(P(gates), P(c), P(c_out), P(dh_a), P(dh_b), P(dc_n), P(Wih), P(Whh), P(dres), P(dG), P(dcp),
+                                   P(dq), P(dhp), R, H, 0 if first else 1, H + 12, st()) == 0
+    assert rel_err(dG, G.grad) < 5e-6
+    assert rel_err(dq, qd.grad + d(dres)) < 5e-6
+    if not first:
+        assert rel_err(dhp, hd.grad) < 5e-6 and rel_err(dcp, cd.grad) < 5e-6
+    # optional inputs absent
+    assert lib.mmdfn_lstm_gate_bwd(P(gates), P(c), P(c_out), P(dh_a), None, None, P(Wih), P(Whh), None, P(dG), P(dcp),
+                                   P(dq), P(dhp), R, H, 0 if first else 1, 0, st()) == 0
+    assert torch.isfinite(dq).all()
+
+
+@pytest.mark.parametrize("R,H,masked,has_q,ldo", [(37, 100, True, True, 300), (500, 100, False, False, 100), (9, 36, True, True, 36),
+                                                  (2100, 128, True, False, 128)])
+def test_gcnii_layer_kernels(R, H, masked, has_q, ldo):
+    from mm_dfn_amd import _hip
+    lib, P, st = _hip.lib(), _hip.ptr, _hip.stream
+    rs = np.random.RandomState(83)
+    hi, h0, W = _rnd(rs, R, H), _rnd(rs, R, H), _rnd(rs, 2 * H, H, scale=0.1)
+    q = _rnd(rs, R, H) if has_q else None
+    m = _keep(rs, R, H) if masked else None
+    theta, alpha = 0.405, 0.2
+    wide = torch.full((R, ldo), 3.0, device=DEV)
+    out = wide[:, ldo - H:]
+    gmask = torch.empty(R, H, device=DEV)
+    assert lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(W), P(q), P(m), P(out), P(gmask), theta, alpha, R, H, ldo, st()) == 0
+    d = lambda t: None if t is None else t.double().cpu()
+    hid, h0d = d(hi).requires_grad_(True), d(h0).requires_grad_(True)
+    pre = theta * (torch.cat([hid, h0d], 1) @ d(W)) + (1 - theta) * ((1 - alpha) * hid + alpha * h0d)
+    want = torch.relu(pre) * (d(m) if masked else 1.0) + (d(q) if has_q else 0.0)
+    assert rel_err(out, want) < 2e-6
+    assert ldo == H or float(wide[:, :ldo - H].min()) == 3.0
+    assert torch.equal(gmask.cpu() != 0, ((pre > 0) & ((d(m) != 0) if masked else torch.ones_like(pre, dtype=torch.bool))))
+    dwide = _rnd(rs, R, ldo)
+    dout = dwide[:, ldo - H:]
+    (want * d(dout)).sum().backward()
+    dP, dhi = torch.empty(R, H, device=DEV), torch.empty(R, H, device=DEV)
+    dh0 = _rnd(rs, R, H)
+    old = dh0.clone()
+    assert lib.mmdfn_gcnii_layer_bwd(P(dout), P(gmask), P(W), P(dP), P(dhi), P(dh0), theta, alpha, R, H, ldo, 1, st()) == 0
+    gg = d(dout) * (pre > 0) * (d(m) if masked else 1.0)
+    assert rel_err(dP, theta * gg) < 1e-6
+    assert rel_err(dhi, hid.grad) < 5e-6
+    assert rel_err(dh0, d(old) + h0d.grad) < 5e-6
+    assert lib.mmdfn_gcnii_layer_bwd(P(dout), P(gmask), P(W), P(dP), P(dhi), P(dh0), theta, alpha, R, H, ldo, 0, st()) == 0
+    assert rel_err(dh0, h0d.grad) < 5e-6
+
+
+@pytest.mark.parametrize("nl,reason,residue,p", [(2, True, True, 0.0), (3, True, True, 0.5), (2, False, True, 0.5), (4, True, False, 0.0),
+                                                 (1, True, True, 0.3)])
+def test_fused_stack_equals_op_by_op_path(nl, reason, residue, p):
+    """GCNII_lyc through the single-node fused stack vs the op-by-op HIP path (itself golden / oracle checked) on the
+    same keep-masks: output, input gradient, adjacency gradient (through the feature gradient) and every parameter."""
+    from mm_dfn_amd import gcn_stack
+    rs = np.random.RandomState(84)
+    lengths = [9, 4, 17]
+    N = sum(lengths)
+    feats0 = _rnd(rs, 3, N, 200)
+    Rw = _rnd(rs, 3 * N, 300 if residue else 100)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(5)
+        net = GCNII_lyc(nfeat=200, nlayers=nl, nhidden=100, nclass=6, dropout=p, lamda=0.5, alpha=0.2, variant=True,
+                        return_feature=True, use_residue=residue, reason_flag=reason)
+        net.load_state_dict(synthetic.seeded_state_dict(net.state_dict(), 85))
+        net = net.to(DEV).train()
+        feats = feats0.clone().requires_grad_(True)
+        adj = ops.build_adjacency(feats, lengths)
+        limit = gcn_stack.ROW_LIMIT
+        gcn_stack.ROW_LIMIT = limit if fused else 0
+        try:
+            torch.manual_seed(11)                       # same dropout stream ...
+            if p > 0 and not fused:
+                # ... but the two paths draw their masks in different shapes: replay the fused path's flat mask
+                R_, H_ = 3 * N, 100
+                flat = F_dropout_ones(R_ * 200 + (1 + nl) * R_ * H_, p)
+                y = _op_by_op_with_masks(net, adj, flat, R_, H_)
+            else:
+                y = net(adj.stacked_feats.reshape(3 * N, 200), lengths, None, adj)
+        finally:
+            gcn_stack.ROW_LIMIT = limit
+        (y * Rw).sum().backward()
+        res.append((y.detach(), feats.grad.clone(), {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}))
+    (y1, g1, p1), (y0, g0, p0) = res
+    assert rel_err(y1, y0) < 5e-6
+    assert rel_err(g1, g0) < 5e-5
+    assert sorted(p1) == sorted(p0)
+    for k in p0:
+        assert rel_err(p1[k], p0[k]) < 5e-5, k
+
+
+def F_dropout_ones(n, p):
+    return torch.nn.functional.dropout(torch.ones(n, device=DEV), p, True)
+
+
+def _op_by_op_with_masks(net, adj, flat, R, H):
+    """GCNII_lyc's op-by-op HIP path with externally supplied keep-masks (layout of gcn_stack.gcn_stack)."""
+    import math
+    F_ = 200
+    nl = len(net.convs)
+    mx = flat[:R * F_].view(R, F_)
+    m0 = flat[R * F_:R * (F_ + H)].view(R, H)
+    ml = [flat[R * (F_ + H) + i * R * H: R * (F_ + H) + (i + 1) * R * H].view(R, H) for i in range(nl)]
+    x = adj.stacked_feats.reshape(R, F_) * mx
+    h0 = ops.linear(x, net.fcs[0].weight, net.fcs[0].bias, act=1)
+    cur = h0 * m0
+    h = c = None
+    if net.reason_flag:
+        bsum = (net.rnn.bias_ih_l0 + net.rnn.bias_hh_l0).detach()
+    for i, con in enumerate(net.convs):
+        q = cur
+        if net.reason_flag:
+            G = ops.gate_linear(q, h, net.rnn.weight_ih_l0, net.rnn.weight_hh_l0, bsum, net.rnn.bias_ih_l0, net.rnn.bias_hh_l0)
+            h, c = ops.lstm_pointwise(G, c)
+            cur = h
+        S2 = ops.propagate_concat(adj, cur, h0)
+        Pm = ops.matmul_kn(S2, con.weight)
+        cur = ops.gcnii_combine(Pm, S2, q if net.reason_flag else None, ml[i], math.log(net.lamda / (i + 1) + 1), net.alpha)
+    return torch.cat([x, cur], -1) if net.use_residue else cur

@@ -235,7 +235,7 @@ def test_real_model_gradient_bucket_through_rccl_and_flat_adam():
             if not in_graph:
                 bucket.reduce_flat()
             opt.step(grads_already_flat=True)
-            assert abs(float(l_ref) - float(l_dp)) < 1e-6
+            assert abs(float(l_ref) - float(l_dp)) < 5e-6
         for (k, x), (_, y) in zip(m_ref.named_parameters(), m_dp.named_parameters()):
             assert float((x - y).abs().max()) < 5e-6, k
         assert dist.get_backend() == "nccl"
