@@ -230,8 +230,9 @@ int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, f
 /* ---------------------------------------------------------------------------
  * Fused stages of the GCNII "dynamic fusion" stack (GCNII_lyc.forward model_GCN.py:444-488, GraphConvolution.forward
  * :176-189): each is ONE launch whose dense contraction runs as exact-f32 MFMA with the pointwise work in its
- * prologue / epilogue (csrc/gcn_stack.hip).  R rows (= M * N graph nodes), H = hidden width (<= 128, multiple of 4),
- * F = input width (<= 256, multiple of 4); every mask is a float keep-mask already scaled by 1/(1-p), NULL = ones.
+ * prologue / epilogue (csrc/gcn_stack.hip).  R rows (= M * N graph nodes), H = hidden width (<= 112, multiple of 4),
+ * F = input width (<= 256, multiple of 4); every mask is a float keep-mask (0 / 1) multiplied by mscale = 1/(1-p) where
+ * it is used, NULL = ones.
  *
  * input stage (model_GCN.py:453-456):  xd = x (.) mx (row stride ldxd);  h0 = relu(xd W0^T + b0);  cur0 = h0 (.) m0
  *   bwd:  dpre = (dcur0 (.) m0 + dh0) (.) [h0 > 0]  (operand of dW0 / db0);  dx = (dpre W0 + dxd) (.) mx,
@@ -249,17 +250,17 @@ int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, f
  *         acc_h0 != 0 accumulates into dh0 (h0 feeds every layer).
  * ------------------------------------------------------------------------- */
 int mmdfn_gcn_input_fwd(const float* x, const float* mx, const float* W0, const float* b0, const float* m0, float* xd,
-                        float* h0, float* cur0, int R, int F, int H, int ldxd, void* stream);
+                        float* h0, float* cur0, int R, int F, int H, int ldxd, float mscale, void* stream);
 int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const float* dh0, const float* h0, const float* W0,
                         const float* dxd, const float* mx, float* dpre, float* dx, int R, int F, int H, int lddxd,
-                        void* stream);
+                        float mscale, void* stream);
 int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
                         const float* bsum, float* gates, float* h_out, float* c_out, int R, int H, void* stream);
 int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh_a, const float* dh_b,
                         const float* dc_next, const float* Wih, const float* Whh, const float* dres, float* dG,
                         float* dc_prev, float* dq, float* dh_prev, int R, int H, int has_h, int lddres, void* stream);
 int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const float* W, const float* q, const float* m, float* out,
-                          float* gmask, float theta, float alpha, int R, int H, int ldo, void* stream);
+                          float* gmask, float theta, float alpha, int R, int H, int ldo, float mscale, void* stream);
 int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
                           float theta, float alpha, int R, int H, int lddo, int acc_h0, void* stream);
 
@@ -289,6 +290,20 @@ int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float* const* B, 
  * ------------------------------------------------------------------------- */
 int mmdfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K9  classifier head (reference model.py:1328-1337: dropout_ -> ReLU -> smax_fc -> log_softmax) as one launch each way:
+ *   z = relu(F (.) mask * mscale);  logp = log_softmax(z W^T + b)       F: N rows of Wd floats (row stride ldf),
+ *   mask: (N, Wd) 0 / 1 keep flags or NULL, W: (C, Wd) nn.Linear layout, C <= 8 classes, Wd % 4 == 0.
+ *   bwd: dF (row stride lddf), dW (C, Wd), db (C) from dlogp; workspace: mmdfn_head_bwd_workspace(Wd, C) floats;
+ *   dW / db are reduced in a fixed order (bit-reproducible).
+ * ------------------------------------------------------------------------- */
+int mmdfn_head_fwd(const float* F, const float* mask, const float* W, const float* bias, float* logp, int64_t N, int Wd,
+                   int C, int ldf, float mscale, void* stream);
+int64_t mmdfn_head_bwd_workspace(int Wd, int C);
+int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
+                   float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, float mscale,
+                   void* stream);
 
 /* ---------------------------------------------------------------------------
  * K10  FocalLoss (reference loss.py:14-34) as one launch each way:

@@ -28,11 +28,11 @@ SIGNATURES = {
     "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_gcnii_combine_bwd": [_P, _P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
-    "mmdfn_gcn_input_fwd": [_P] * 8 + [_I] * 4 + [_P],
-    "mmdfn_gcn_input_bwd": [_P] * 9 + [_I] * 4 + [_P],
+    "mmdfn_gcn_input_fwd": [_P] * 8 + [_I] * 4 + [_F, _P],
+    "mmdfn_gcn_input_bwd": [_P] * 9 + [_I] * 4 + [_F, _P],
     "mmdfn_lstm_gate_fwd": [_P] * 9 + [_I] * 2 + [_P],
     "mmdfn_lstm_gate_bwd": [_P] * 13 + [_I] * 4 + [_P],
-    "mmdfn_gcnii_layer_fwd": [_P] * 7 + [_F, _F, _I, _I, _I, _P],
+    "mmdfn_gcnii_layer_fwd": [_P] * 7 + [_F, _F, _I, _I, _I, _F, _P],
     "mmdfn_gcnii_layer_bwd": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _P],
     "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -42,6 +42,9 @@ SIGNATURES = {
     "mmdfn_gemm_tn_grouped": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_gemm_tn_batch_workspace": [_I, _P, _P, _I, _P, _P],
     "mmdfn_gemm_tn_batch": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_head_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
+    "mmdfn_head_bwd_workspace": [_I, _I],
+    "mmdfn_head_bwd": [_P] * 9 + [_L, _I, _I, _I, _I, _F, _P],
     "mmdfn_focal_loss_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "mmdfn_focal_loss_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "mmdfn_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
@@ -51,7 +54,7 @@ SIGNATURES = {
     "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):

@@ -1,0 +1,220 @@
+// K9: classifier head  log_softmax( relu(dropout(F)) W^T + b )  as one launch each way.
+//
+// Replaces  dropout_ -> ReLU -> smax_fc -> log_softmax  (reference model.py:1328-1337) and its autograd (soft-max
+// backward, two GEMMs, a bias reduction, the ReLU and dropout masks: ten library launches).  NB the reference applies
+// the ReLU to the whole fused feature row, including the raw residual x.
+//   z = relu(F (.) m * mscale)            F: (N, W) rows (stride ldf), m: 0/1 keep-mask (N, W) or NULL, mscale = 1/(1-p)
+//   logit_c = z . W_c + b_c ;  logp = logit - logsumexp(logit)                                   C <= 8 classes
+// The weight (C x W, a few tens of KB) lives in LDS; one wave per row walks the row in 16-byte chunks, the C dot
+// products are reduced across the wave; C is far too small for the matrix cores to matter (2 N W C flop = 19 MFLOP at
+// cfg2) -- the kernel is a single pass over F at HBM / L2 speed.
+// Backward:  g = dlogp - exp(logp) * sum_c dlogp_c;   dF = (g W) (.) [z > 0] m mscale;   dW = g^T z;   db = sum_rows g.
+//   dW / db: every wave keeps its partial sums in registers over the rows it owns, waves of a workgroup meet in LDS,
+//   workgroups write partial slabs and a second tiny kernel sums them in a fixed order (bit-reproducible, no atomics).
+#include "mmdfn_internal.h"
+#include "../../include/mmdfn_hip.h"
+
+namespace {
+
+constexpr int HC_MAX = 8;        // classes (IEMOCAP 6, MELD 7); wider heads stay on the library path
+constexpr int HB_COLS = 1024;    // feature columns per backward column block (4 float4 per lane)
+constexpr int HB_GROUPS = 128;   // row groups (workgroups per column block) of the backward pass
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ Fm, const float* __restrict__ mask,
+                                                       const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                       float* __restrict__ logp, int64_t N, int W, int C, int ldf,
+                                                       float mscale) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];       // [C][W]
+    for (int i = threadIdx.x; i < C * W / 4; i += 256)
+        reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(Wt)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int W4 = W / 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+        float acc[HC_MAX];
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c) acc[c] = 0.f;
+        for (int j = lane; j < W4; j += 64) {
+            float4 z = *reinterpret_cast<const float4*>(Fm + row * ldf + 4 * j);
+            if (mask) {
+                const float4 m = *reinterpret_cast<const float4*>(mask + row * W + 4 * j);
+                z.x *= m.x * mscale; z.y *= m.y * mscale; z.z *= m.z * mscale; z.w *= m.w * mscale;
+            }
+            z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f);
+#pragma unroll
+            for (int c = 0; c < HC_MAX; ++c) {
+                if (c < C) {
+                    const float4 wv = *reinterpret_cast<const float4*>(sW + c * W + 4 * j);
+                    acc[c] += z.x * wv.x + z.y * wv.y + z.z * wv.z + z.w * wv.w;
+                }
+            }
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c) {
+            if (c < C) {
+                acc[c] = wave_sum(acc[c]) + bias[c];
+                mx = fmaxf(mx, acc[c]);
+            }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c)
+            if (c < C) se += expf(acc[c] - mx);
+        const float lse = mx + logf(se);
+        if (lane < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < HC_MAX; ++c)
+                if (c == lane) v = acc[c];
+            logp[row * C + lane] = v - lse;
+        }
+    }
+}
+
+// grid (HB_GROUPS, column blocks).  part: [groups][C][W] slabs of dW, bpart: [groups][C] slabs of db (column block 0).
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
+                                                       const float* __restrict__ Fm, const float* __restrict__ mask,
+                                                       const float* __restrict__ Wt, float* __restrict__ dF,
+                                                       float* __restrict__ part, float* __restrict__ bpart, int64_t N, int W,
+                                                       int C, int ldf, int lddf, float mscale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [C][cols] weight block, later the wave partials
+    const int col0 = blockIdx.y * HB_COLS;
+    const int cols = min(HB_COLS, W - col0);
+    const int cols4 = cols / 4;
+    for (int i = threadIdx.x; i < C * cols4; i += 256) {
+        const int c = i / cols4, j = i - c * cols4;
+        reinterpret_cast<float4*>(sm)[c * (HB_COLS / 4) + j] = *reinterpret_cast<const float4*>(Wt + (int64_t)c * W + col0 + 4 * j);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float4 dw[HC_MAX][HB_COLS / 256];
+    float db[HC_MAX];
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c) {
+        db[c] = 0.f;
+#pragma unroll
+        for (int s = 0; s < HB_COLS / 256; ++s) dw[c][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+        float g[HC_MAX];
+        float sd = 0.f;
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c) {
+            g[c] = (c < C) ? dlogp[row * C + c] : 0.f;
+            sd += g[c];
+        }
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c) {
+            if (c < C) {
+                g[c] -= expf(logp[row * C + c]) * sd;
+                db[c] += g[c];                        // (every lane holds the same value; lane 0 reports it)
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < HB_COLS / 256; ++s) {
+            const int j = lane + 64 * s;
+            if (j >= cols4) continue;
+            const int64_t o = row * ldf + col0 + 4 * j;
+            float4 z = *reinterpret_cast<const float4*>(Fm + o);
+            float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (mask) {
+                m = *reinterpret_cast<const float4*>(mask + row * W + col0 + 4 * j);
+                m.x *= mscale; m.y *= mscale; m.z *= mscale; m.w *= mscale;
+            }
+            z.x = fmaxf(z.x * m.x, 0.f); z.y = fmaxf(z.y * m.y, 0.f); z.z = fmaxf(z.z * m.z, 0.f); z.w = fmaxf(z.w * m.w, 0.f);
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < HC_MAX; ++c) {
+                if (c < C) {
+                    const float4 wv = reinterpret_cast<const float4*>(sm)[c * (HB_COLS / 4) + j];
+                    d.x += g[c] * wv.x; d.y += g[c] * wv.y; d.z += g[c] * wv.z; d.w += g[c] * wv.w;
+                    dw[c][s].x += g[c] * z.x; dw[c][s].y += g[c] * z.y; dw[c][s].z += g[c] * z.z; dw[c][s].w += g[c] * z.w;
+                }
+            }
+            d.x = z.x > 0.f ? d.x * m.x : 0.f; d.y = z.y > 0.f ? d.y * m.y : 0.f;
+            d.z = z.z > 0.f ? d.z * m.z : 0.f; d.w = z.w > 0.f ? d.w * m.w : 0.f;
+            *reinterpret_cast<float4*>(dF + row * lddf + col0 + 4 * j) = d;
+        }
+    }
+    // waves -> LDS -> one slab per workgroup (fixed order)
+    __syncthreads();                                     // the weight block is no longer needed
+    float4* sp = reinterpret_cast<float4*>(sm);          // [4 waves][C][HB_COLS / 4]
+#pragma unroll
+    for (int c = 0; c < HC_MAX; ++c) {
+        if (c < C) {
+#pragma unroll
+            for (int s = 0; s < HB_COLS / 256; ++s) sp[(w * C + c) * (HB_COLS / 4) + lane + 64 * s] = dw[c][s];
+        }
+    }
+    __shared__ float sdb[4][HC_MAX];
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c) sdb[w][c] = db[c];
+    }
+    __syncthreads();
+    float* pout = part + (int64_t)blockIdx.x * C * W;
+    for (int i = threadIdx.x; i < C * cols4; i += 256) {
+        const int c = i / cols4, j = i - c * cols4;
+        float4 s = sp[(0 * C + c) * (HB_COLS / 4) + j];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const float4 v = sp[(ww * C + c) * (HB_COLS / 4) + j];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(pout + (int64_t)c * W + col0 + 4 * j) = s;
+    }
+    if (blockIdx.y == 0 && threadIdx.x < C)
+        bpart[blockIdx.x * C + threadIdx.x] = sdb[0][threadIdx.x] + sdb[1][threadIdx.x] + sdb[2][threadIdx.x] + sdb[3][threadIdx.x];
+}
+
+__global__ void head_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dW,
+                                   float* __restrict__ db, int groups, int CW, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < CW) {
+        float s = 0.f;
+        for (int gidx = 0; gidx < groups; ++gidx) s += part[(int64_t)gidx * CW + idx];
+        dW[idx] = s;
+    } else if (idx < CW + C) {
+        const int c = idx - CW;
+        float s = 0.f;
+        for (int gidx = 0; gidx < groups; ++gidx) s += bpart[gidx * C + c];
+        db[c] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int mmdfn_head_fwd(const float* F, const float* mask, const float* W, const float* bias, float* logp, int64_t N,
+                              int Wd, int C, int ldf, float mscale, void* stream) {
+    if (N <= 0 || Wd < 4 || (Wd & 3) || C < 1 || C > HC_MAX || ldf < Wd || (ldf & 3) || (int64_t)C * Wd * 4 > 150 * 1024) return -1;
+    int64_t grid = (N + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    if (int e = mmdfn_allow_big_lds(head_fwd_kernel)) return e;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)grid), dim3(256), (size_t)C * Wd * sizeof(float), (hipStream_t)stream, F, mask,
+                       W, bias, logp, N, Wd, C, ldf, mscale);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t mmdfn_head_bwd_workspace(int Wd, int C) { return (int64_t)HB_GROUPS * ((int64_t)C * Wd + C); }
+
+extern "C" int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
+                              float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, float mscale,
+                              void* stream) {
+    if (N <= 0 || Wd < 4 || (Wd & 3) || C < 1 || C > HC_MAX || ldf < Wd || (ldf & 3) || lddf < Wd || (lddf & 3)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    float* part = workspace;
+    float* bpart = workspace + (int64_t)HB_GROUPS * C * Wd;
+    const int nblk = (Wd + HB_COLS - 1) / HB_COLS;
+    const size_t lds = (size_t)4 * C * HB_COLS * sizeof(float);       // wave partials (>= the C x HB_COLS weight block)
+    if (lds > 150 * 1024) return -1;
+    if (int e = mmdfn_allow_big_lds(head_bwd_kernel)) return e;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(HB_GROUPS, nblk), dim3(256), lds, s, dlogp, logp, F, mask, W, dF, part, bpart, N, Wd, C,
+                       ldf, lddf, mscale);
+    MMDFN_CHECK_LAUNCH();
+    const int total = C * Wd + C;
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, bpart, dW, db, HB_GROUPS, C * Wd, C);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}

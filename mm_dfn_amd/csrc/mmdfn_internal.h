@@ -35,6 +35,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// more than 64 KB of dynamic LDS per workgroup needs the attribute raised once per kernel (gfx950: 160 KB per CU)
+template <class Kern>
+inline int mmdfn_allow_big_lds(Kern kern) {
+    static thread_local const void* done[8] = {nullptr};
+    const void* key = reinterpret_cast<const void*>(kern);
+    for (int i = 0; i < 8; ++i)
+        if (done[i] == key) return 0;
+    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < 8; ++i)
+        if (done[i] == nullptr) { done[i] = key; break; }
+    return 0;
+}
+
 // launchers implemented in propagate.hip / tile_dot.hip, used by adjacency.hip
 int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* H, float* out,
                            const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,

@@ -189,8 +189,10 @@ class DevicePrefetcher:
         tensors, rest = batch[:6], batch[6:]
         # dialogue lengths from the HOST copy of umask (run_train_erc.py:194 reads them back from the device with B
         # syncs): they key the trainer's captured-step cache without a device round trip
-        um = tensors[4]
-        lengths = ((um == 1).to(torch.int64) * torch.arange(1, um.shape[1] + 1).unsqueeze(0)).max(1).values.tolist()
+        # (numpy, not torch: a torch CPU reduction forks the whole intra-op thread pool -- 6-27 ms per batch measured on
+        # the 256-thread host of the GPU box, tools/prof_stream.py)
+        um = tensors[4].numpy()
+        lengths = [int(v) for v in ((um == 1) * np.arange(1, um.shape[1] + 1)[None, :]).max(1)]
         with torch.cuda.stream(stream):
             dev = []
             for t in tensors:

@@ -204,8 +204,7 @@ class DialogueGNNModel(nn.Module):
             el = self.graph_net_l(feats[2], seq_lengths, qmask)
             fused = (self.gatedatt(ea, ev, el, self.modals) if self.att_type == 'gated'
                      else torch.cat([ea, ev, el], dim=-1))
-            z = F.relu(self.dropout_(fused))
-            return F.log_softmax(ops.linear(z, self.smax_fc.weight, self.smax_fc.bias), 1), None, None, None, None
+            return ops.head(fused, self.smax_fc.weight, self.smax_fc.bias, self.dropout_.p, self.training), None, None, None, None
         if self.use_speaker or self.use_modal:
             fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label)
         else:
@@ -216,6 +215,6 @@ class DialogueGNNModel(nn.Module):
             idx = _flat_index([int(x) for x in seq_lengths], L, B, fused.device)
             padded = fused.new_zeros(L * B, fused.shape[1]).index_copy(0, idx, fused).view(L, B, -1)
             fused = self.mfn(padded).reshape(L * B, -1).index_select(0, idx)
-        z = F.relu(self.dropout_(fused))
-        log_prob = F.log_softmax(ops.linear(z, self.smax_fc.weight, self.smax_fc.bias), 1)
+        # dropout -> ReLU -> smax_fc -> log_softmax (model.py:1328-1337) as one fused launch each way
+        log_prob = ops.head(fused, self.smax_fc.weight, self.smax_fc.bias, self.dropout_.p, self.training)
         return log_prob, None, None, None, None

@@ -21,14 +21,14 @@ ROW_LIMIT = 32768
 
 def eligible(x, nfeat, nhidden, nlayers, params):
     return (x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= ROW_LIMIT and nlayers >= 1
-            and nhidden % 4 == 0 and 4 <= nhidden <= 128 and nfeat % 4 == 0 and 4 <= nfeat <= 256
+            and nhidden % 4 == 0 and 4 <= nhidden <= 112 and nfeat % 4 == 0 and 4 <= nfeat <= 256
             and (not torch.is_grad_enabled() or all(ops._leaf(p) for p in params)))
 
 
 class _GcnStack(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, tiles, cross, masks, lay, symmetric, lamda, alpha, reason, use_residue, W0, b0, w_ih, w_hh, b_ih,
-                b_hh, *convW):
+    def forward(ctx, x, tiles, cross, masks, mscale, lay, symmetric, lamda, alpha, reason, use_residue, W0, b0, w_ih, w_hh,
+                b_ih, b_hh, *convW):
         lib = _hip.lib()
         P, st = _hip.ptr, _hip.stream()
         x = x.contiguous()
@@ -47,7 +47,7 @@ class _GcnStack(torch.autograd.Function):
         xd = out if use_residue else new(R, F)                 # x_d lives in the left F columns of the residue output
         ldxd = F + H if use_residue else F
         h0, cur = new(R, H), new(R, H)
-        _hip.check(lib.mmdfn_gcn_input_fwd(P(x), P(mx), P(W0), P(b0), P(m0), P(xd), P(h0), P(cur), R, F, H, ldxd, st),
+        _hip.check(lib.mmdfn_gcn_input_fwd(P(x), P(mx), P(W0), P(b0), P(m0), P(xd), P(h0), P(cur), R, F, H, ldxd, mscale, st),
                    "mmdfn_gcn_input_fwd")
         bsum = (b_ih + b_hh) if reason else None
         h = c = None
@@ -75,14 +75,14 @@ class _GcnStack(torch.autograd.Function):
             gmask = new(R, H)
             theta = math.log(lamda / (i + 1) + 1)
             _hip.check(lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(convW[i]), P(q if reason else None), P(ml[i]), P(dst),
-                                                 P(gmask), theta, alpha, R, H, ldo, st), "mmdfn_gcnii_layer_fwd")
+                                                 P(gmask), theta, alpha, R, H, ldo, mscale, st), "mmdfn_gcnii_layer_fwd")
             rec.update(zin=zin, hi=hi, gmask=gmask, theta=theta)
             layers.append(rec)
             cur = dst
         ctx.layers = layers
         # (xd is a detached alias: holding the output itself would tie this node and its output into a reference cycle)
         ctx.misc = dict(lay=lay, symmetric=symmetric, alpha=alpha, reason=reason, use_residue=use_residue, R=R, F=F, H=H,
-                        mx=mx, m0=m0, xd=xd.detach(), h0=h0, tiles=tiles, cross=cross)
+                        mx=mx, m0=m0, xd=xd.detach(), h0=h0, tiles=tiles, cross=cross, mscale=mscale)
         ctx.params = (W0, b0, w_ih, w_hh, b_ih, b_hh, convW)
         return out
 
@@ -135,17 +135,18 @@ class _GcnStack(torch.autograd.Function):
                 dcur, lddo = dz, H
         dpre, dx = new(R, H), new(R, F)
         _hip.check(lib.mmdfn_gcn_input_bwd(P(dcur), P(m["m0"]), P(dh0), P(m["h0"]), P(W0), P(dxd), P(m["mx"]), P(dpre), P(dx), R,
-                                           F, H, lddxd, st), "mmdfn_gcn_input_bwd")
+                                           F, H, lddxd, m["mscale"], st), "mmdfn_gcn_input_bwd")
         xd = m["xd"][:, :F] if m["use_residue"] else m["xd"]
         ops.queue_wgrad(dpre, xd, W0, [b0] if b0 is not None else [])
-        return (dx, dtiles, dcross) + (None,) * (13 + len(convW))
+        return (dx, dtiles, dcross) + (None,) * (14 + len(convW))
 
 
-def gcn_stack(x, adj, masks, lamda, alpha, reason_flag, use_residue, W0, b0, lstm, convs):
+def gcn_stack(x, adj, masks, mscale, lamda, alpha, reason_flag, use_residue, W0, b0, lstm, convs):
     """x (R, F) -> [x (.) m_x | cur] (R, F + H) (or cur alone without use_residue).  ``masks``: one flat fp32 tensor of
-    keep-masks scaled by 1/(1-p) for x, h0 and every layer (R F + R H + nl R H floats), or None (eval / p = 0)."""
+    0 / 1 keep flags for x, h0 and every layer (R F + R H + nl R H floats; the kernels multiply by ``mscale`` = 1/(1-p)),
+    or None (eval / p = 0)."""
     w_ih = w_hh = b_ih = b_hh = None
     if reason_flag:
         w_ih, w_hh, b_ih, b_hh = lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0
-    return _GcnStack.apply(x, adj.tiles, adj.cross, masks, adj.layout, adj.symmetric, float(lamda), float(alpha),
+    return _GcnStack.apply(x, adj.tiles, adj.cross, masks, float(mscale), adj.layout, adj.symmetric, float(lamda), float(alpha),
                            bool(reason_flag), bool(use_residue), W0, b0, w_ih, w_hh, b_ih, b_hh, *convs)

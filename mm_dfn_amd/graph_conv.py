@@ -105,12 +105,13 @@ class GCNII_lyc(nn.Module):
         """Dialogue-graph sizes: the whole stack as one autograd node of fused kernels (gcn_stack.py)."""
         R, nfeat = x.shape
         H = con_width(self.convs)
-        masks = None
+        masks, mscale = None, 1.0
         if self.training and self.dropout > 0:
-            # the keep-masks of x, h0 and every layer from one fill + one dropout launch (scaled by 1/(1-p))
-            masks = F.dropout(torch.ones(R * nfeat + (1 + len(self.convs)) * R * H, dtype=x.dtype, device=x.device),
-                              self.dropout, True)
-        cur = gcn_stack.gcn_stack(x, adj, masks, self.lamda, self.alpha, self.reason_flag, self.use_residue,
+            # the 0 / 1 keep flags of x, h0 and every layer from ONE random-number launch; the kernels scale by 1/(1-p)
+            masks = torch.empty(R * nfeat + (1 + len(self.convs)) * R * H, dtype=x.dtype, device=x.device)
+            masks.bernoulli_(1.0 - self.dropout)
+            mscale = 1.0 / (1.0 - self.dropout)
+        cur = gcn_stack.gcn_stack(x, adj, masks, mscale, self.lamda, self.alpha, self.reason_flag, self.use_residue,
                                   self.fcs[0].weight, self.fcs[0].bias, self.rnn, [c.weight for c in self.convs])
         if not self.return_feature:
             cur = F.log_softmax(self.fcs[-1](cur), dim=1)

@@ -55,6 +55,5 @@ class MultiStreamGraphModel(nn.Module):
             raise ValueError("expected %d streams, got %d" % (len(self.linears), len(U_list)))
         feats = self.project(U_list, seq_lengths)
         fused = self.graph_model.forward_streams(feats, seq_lengths, qmask, test_label)
-        z = F.relu(self.dropout_(fused))
-        log_prob = F.log_softmax(ops.linear(z, self.smax_fc.weight, self.smax_fc.bias), 1)
+        log_prob = ops.head(fused, self.smax_fc.weight, self.smax_fc.bias, self.dropout_.p, self.training)
         return log_prob, None, None, None, None

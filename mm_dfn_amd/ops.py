@@ -814,6 +814,63 @@ def linear2(x, w1, w2, b1, b2):
     return _Linear2.apply(x, w1, w2, b1, b2)
 
 
+class _Head(torch.autograd.Function):
+    """log_softmax(relu(F (.) mask * mscale) W^T + b): the classifier head of model.py:1328-1337 as one launch each way
+    (csrc/head.hip); mask = 0 / 1 keep flags of the head dropout or None."""
+
+    @staticmethod
+    def forward(ctx, Fm, mask, mscale, weight, bias):
+        _hip.require_cuda(Fm, weight)
+        _hip.require_f32(Fm, mask, weight, bias)
+        if Fm.stride(1) != 1 or Fm.stride(0) % 4 or Fm.data_ptr() % 16:
+            Fm = Fm.contiguous()
+        N, Wd = Fm.shape
+        C = weight.shape[0]
+        weight, bias = weight.contiguous(), bias.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        logp = torch.empty(N, C, dtype=torch.float32, device=Fm.device)
+        rc = _hip.lib().mmdfn_head_fwd(_hip.ptr(Fm), _hip.ptr(mask), _hip.ptr(weight), _hip.ptr(bias), _hip.ptr(logp), N, Wd, C,
+                                       Fm.stride(0), float(mscale), _hip.stream())
+        _hip.check(rc, "mmdfn_head_fwd")
+        ctx.mscale = float(mscale)
+        ctx.save_for_backward(Fm, mask, weight, logp)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        Fm, mask, weight, logp = ctx.saved_tensors
+        N, Wd = Fm.shape
+        C = weight.shape[0]
+        dlogp = dlogp.contiguous()
+        lib = _hip.lib()
+        dF = torch.empty(N, Wd, dtype=torch.float32, device=Fm.device)
+        dW = torch.empty(C, Wd, dtype=torch.float32, device=Fm.device)
+        db = torch.empty(C, dtype=torch.float32, device=Fm.device)
+        ws = torch.empty(int(lib.mmdfn_head_bwd_workspace(Wd, C)), dtype=torch.float32, device=Fm.device)
+        rc = lib.mmdfn_head_bwd(_hip.ptr(dlogp), _hip.ptr(logp), _hip.ptr(Fm), _hip.ptr(mask), _hip.ptr(weight), _hip.ptr(dF),
+                                _hip.ptr(dW), _hip.ptr(db), _hip.ptr(ws), N, Wd, C, Fm.stride(0), Wd, ctx.mscale, _hip.stream())
+        _hip.check(rc, "mmdfn_head_bwd")
+        return dF, None, None, dW, db
+
+
+def head_supported(Fm, weight):
+    return (Fm.is_cuda and Fm.dtype == torch.float32 and Fm.dim() == 2 and weight.shape[0] <= 8 and Fm.shape[1] % 4 == 0
+            and weight.shape[0] * Fm.shape[1] * 4 <= 150 * 1024)
+
+
+def head(Fm, weight, bias, p=0.0, training=False):
+    """log_softmax(Linear(relu(dropout(Fm)))) (reference model.py:1328-1337).  Wide heads (> 8 classes) take the library
+    composition."""
+    if not head_supported(Fm, weight) or bias is None:
+        z = torch.relu(torch.nn.functional.dropout(Fm, p, training))
+        return torch.log_softmax(linear(z, weight, bias), 1)
+    mask, mscale = None, 1.0
+    if training and p > 0:
+        mask = torch.empty(Fm.shape, dtype=torch.float32, device=Fm.device).bernoulli_(1.0 - p)
+        mscale = 1.0 / (1.0 - p)
+    return _Head.apply(Fm, mask, mscale, weight, bias)
+
+
 def matmul_kn(x, w):
     _hip.require_cuda(x)
     return _MatmulKN.apply(x, w)

@@ -117,8 +117,8 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
     seed_everything(seed)
     vids = []
     for data in dataloader:
-        if train_flag:
-            optimizer.zero_grad()
+        if train_flag and graph_cache is None:
+            optimizer.zero_grad()         # (a replayed step hands over fresh gradient tensors: nothing to reset)
         textf, visuf, acouf, qmask, umask, label = [d.cuda() for d in data[:6]] if cuda_flag else data[:6]
         lengths = getattr(data, "lengths", None) or lengths_from_umask(umask)
         if graph_cache is not None:
