@@ -230,7 +230,7 @@ int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, f
 /* ---------------------------------------------------------------------------
  * Fused stages of the GCNII "dynamic fusion" stack (GCNII_lyc.forward model_GCN.py:444-488, GraphConvolution.forward
  * :176-189): each is ONE launch whose dense contraction runs as exact-f32 MFMA with the pointwise work in its
- * prologue / epilogue (csrc/gcn_stack.hip).  R rows (= M * N graph nodes), H = hidden width (<= 112, multiple of 4),
+ * prologue / epilogue (csrc/gcn_stack.hip).  R rows (= M * N graph nodes), H = hidden width (<= 100, multiple of 4),
  * F = input width (<= 256, multiple of 4); every mask is a float keep-mask (0 / 1) multiplied by mscale = 1/(1-p) where
  * it is used, NULL = ones.
  *

@@ -6,26 +6,31 @@
 //   layer (K7)    out = relu(theta [hi | h0] W + (1 - theta)((1 - alpha) hi + alpha h0)) (.) m_i + q  (:178-186, :469-472)
 // and their backward counterparts.  (hi = A_hat . h' is K6, propagate.hip.)  The dense contractions are true
 // contractions and run on the matrix cores as exact-f32 MFMA (v_mfma_f32_16x16x4_f32, k-ordered fp32 fma chain); the
-// pointwise work around them lives in the same kernel -- operands are formed while they are staged, results leave
-// straight from the accumulators -- so no intermediate (P, G, S2, dP ...) makes a round trip through HBM that the
+// pointwise work around them lives in the same kernel -- operands are formed while they are staged, results are
+// finished row-wise from LDS -- so no intermediate (P, G, S2, dP ...) makes a round trip through HBM that the
 // algorithm does not need, and nothing is concatenated or transposed in memory.
 //
 // One structure for all six kernels ("weight-stationary"): the contraction is rows x weights with tiny weights
 // (<= 400 x 200) and many rows, so a workgroup parks its slice of the WEIGHTS in LDS once (as k-contiguous rows
-// whatever layout the parameter has; row stride = 4 * odd dwords: conflict-free 16-byte fragment reads) and then
-// streams 16-row blocks of the activations past it:
+// whatever layout the parameter has; row stride = 4 * odd dwords: conflict-free 16-byte fragment reads; rows
+// zero-padded to a multiple of 16 so the MFMA loop has no tail predicate) and then streams 16-row blocks of the
+// activations past it:
 //     stage A(block)   : all 256 threads load the block's operands with 16-byte loads, form the A matrix element-wise
 //                        (mask, ReLU gate, LSTM gate backward ...), write side outputs (x_d, dpre, dP, dG) and park A
-//                        in LDS; the raw loads of block i+1 are issued before the MFMAs of block i,
-//     contract         : 4 waves x their 16-column tiles, both MFMA fragments are 16-byte LDS reads
-//                        (lane (i, g) holds k = k0 + 4g .. +3 of row / column i; MFMA step j consumes component j),
-//     epilogue         : from the accumulators (the LSTM cell needs the four gates of a unit: the four waves own one
-//                        gate each and meet in LDS).
-// grid = (row groups, column blocks): <= ~256 workgroups, each looping over its row blocks.  These launches are
-// latency-bound at dialogue-graph sizes (5 280 rows at BASELINE cfg2); long-dialogue batches (cfg5: ~10^5 rows) keep
-// the unfused path whose contractions run on the bf16-piece pipeline.
+//                        in LDS; the raw loads of block i+1 (and the epilogue operands of block i) are issued before
+//                        the MFMAs of block i,
+//     contract         : 4 waves x their 16-column tiles, straight-line code: both MFMA fragments are unconditional
+//                        16-byte LDS reads (lane (i, g) holds k = k0 + 4g .. +3 of row / column i; MFMA step j
+//                        consumes component j), every wave runs the same number of tiles (a surplus tile recomputes
+//                        tile 0 and is dropped) -- a divergent-looking tile predicate makes hipcc wrap every MFMA in
+//                        an exec-mask branch and copy the accumulator out after each one (4x slower, measured),
+//     epilogue         : accumulators -> LDS -> row-wise 16-byte loads / stores by all threads.
+// grid = (row groups, column blocks): <= ~256 workgroups (LDS holds one weight slice per CU), each looping over its
+// row blocks.  These launches are latency-bound at dialogue-graph sizes (5 280 rows at BASELINE cfg2); long-dialogue
+// batches (cfg5: ~10^5 rows) keep the unfused path whose contractions run on the bf16-piece pipeline.
 #include "mmdfn_internal.h"
 #include "../../include/mmdfn_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,86 +39,143 @@ constexpr int RB = 16;   // rows per block
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 one4() { return make_float4(1.f, 1.f, 1.f, 1.f); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 scl4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float s, float4 b) { return make_float4(a.x * s + b.x, a.y * s + b.y, a.z * s + b.z, a.w * s + b.w); }
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// LDS row stride (floats) for rows of K floats: 16-byte aligned and (stride / 4) odd, so that the 16 rows a quarter
-// wave reads at one k land on 16 different 16-byte bank groups.
+// LDS row stride (floats) for rows of K floats: room for K rounded up to 16 (the MFMA loop reads whole 16-wide chunks;
+// the padding holds zeros), 16-byte aligned and (stride / 4) odd, so that the 16 rows a quarter wave reads at one k
+// land on 16 different 16-byte bank groups.
 __host__ __device__ inline int lds_stride(int K) {
-    int ld = K + 4;
+    int ld = ((K + 15) & ~15) + 4;
     if (((ld >> 2) & 1) == 0) ld += 4;
     return ld;
 }
 
-// Park `ncols` weight rows (output columns n0 .. n0+ncols-1, all K) in LDS as k-contiguous rows sW[n][k].
-//   kmajor = false: the parameter is (N, K) with k-contiguous rows (nn.Linear / nn.LSTM layout), row stride ldsrc
-//   kmajor = true : the parameter is (K, N) (GraphConvolution.weight; any W used as "x . W"), element [k][n] at k * ldsrc + n
-__device__ __forceinline__ void stage_weights(float* sW, int ldw, const float* __restrict__ W, int ldsrc, int n0, int ncols,
-                                              int K, bool kmajor) {
-    if (!kmajor) {
-        const int K4 = K >> 2;
-        for (int i = threadIdx.x; i < ncols * K4; i += 256) {
-            const int n = i / K4, k = (i - n * K4) * 4;
-            st4(sW + n * ldw + k, ld4(W + (int64_t)(n0 + n) * ldsrc + k));
-        }
-    } else {
-        for (int i = threadIdx.x; i < ncols * K; i += 256) {      // consecutive threads: consecutive n (coalesced reads)
-            const int k = i / ncols, n = i - k * ncols;
-            sW[n * ldw + k] = W[(int64_t)k * ldsrc + n0 + n];
-        }
+// zero columns K .. ld-1 of `nrows` LDS rows (addresses nobody else writes: no barrier needed against the data stores)
+__device__ __forceinline__ void zero_pads(float* base, int nrows, int ld, int K) {
+    const int np4 = (ld - K) >> 2;
+    for (int i = threadIdx.x; i < nrows * np4; i += 256) {
+        const int r = i / np4, j = i - r * np4;
+        st4(base + r * ld + K + 4 * j, zero4());
     }
 }
 
-// acc[t] += A (16 x K, LDS rows sA[i][k]) . W_t^T (tile t = 16 LDS weight rows starting at sW + wrow0[t] * ldw).
-template <int MAXT>
-__device__ __forceinline__ void contract(f32x4 (&acc)[MAXT], int nt, const int (&wrow0)[MAXT], const float* sA, int lda,
-                                         const float* sW, int ldw, int K) {
-    const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
-    const float* ap = sA + fi * lda + 4 * g;
-    const float* bp[MAXT];
+// Park `ncols` weight rows (output columns n0 .. n0+ncols-1, all K) in LDS as k-contiguous rows sW[n][k].
+//   KMAJOR = false: the parameter is (N, K) with k-contiguous rows (nn.Linear / nn.LSTM layout), row stride ldsrc
+//   KMAJOR = true : the parameter is (K, N) (GraphConvolution.weight; any W used as "x . W"), element [k][n] at k * ldsrc + n
+// Two phases so that a kernel can put EVERY load of its prologue in flight at once (the weight slice, the first row
+// block, the first epilogue operands) and pay the memory latency once: issue() only loads (all <= 26 16-byte slots of
+// a thread), commit() writes them to LDS.
+constexpr int NWS = 26;      // 26 slots x 256 threads x 16 B = 104 KB >= every weight slice used below
+template <bool KMAJOR>
+struct WeightStager {
+    float4 v[NWS];
+    __device__ __forceinline__ void issue(const float* __restrict__ W, int ldsrc, int n0, int ncols, int K) {
+        const int inner = KMAJOR ? (ncols >> 2) : (K >> 2);       // 16-byte slots per source row
+        const int total = KMAJOR ? K * inner : ncols * inner;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) bp[t] = sW + (wrow0[t < nt ? t : 0] + fi) * ldw + 4 * g;
-    const int nk = (K + 15) >> 4;
-    // fragments of chunk kc + 1 are fetched before the MFMAs of chunk kc (two static register sets)
-    float4 a0, a1, b0[MAXT], b1[MAXT];
-#define CT_LOAD(A_, B_, KC)                                                                                \
-    do {                                                                                                   \
-        const bool ok_ = 16 * (KC) + 4 * g < K;      /* K % 4 == 0: a float4 is inside or outside as a whole */ \
-        A_ = ok_ ? ld4(ap + 16 * (KC)) : zero4();                                                          \
-        _Pragma("unroll") for (int t = 0; t < MAXT; ++t) B_[t] = (ok_ && t < nt) ? ld4(bp[t] + 16 * (KC)) : zero4(); \
-    } while (0)
-#define CT_MMA(A_, B_)                                                                                     \
-    do {                                                                                                   \
-        const float av_[4] = {A_.x, A_.y, A_.z, A_.w};                                                     \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
-            _Pragma("unroll") for (int t = 0; t < MAXT; ++t) {                                             \
-                if (t < nt) {                                                                              \
-                    const float bv_ = (j == 0) ? B_[t].x : (j == 1) ? B_[t].y : (j == 2) ? B_[t].z : B_[t].w; \
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[j], bv_, acc[t], 0, 0, 0);           \
-                }                                                                                          \
-            }                                                                                              \
-    } while (0)
-    CT_LOAD(a0, b0, 0);
-    for (int kc = 0; kc < nk; kc += 2) {
-        if (kc + 1 < nk) CT_LOAD(a1, b1, kc + 1);
-        CT_MMA(a0, b0);
-        if (kc + 1 < nk) {
-            if (kc + 2 < nk) CT_LOAD(a0, b0, kc + 2);
-            CT_MMA(a1, b1);
+        for (int e = 0; e < NWS; ++e) {
+            const int i = threadIdx.x + 256 * e;
+            const int r = i / inner, j = i - r * inner;
+            const float* src = KMAJOR ? W + (int64_t)r * ldsrc + n0 + 4 * j : W + (int64_t)(n0 + r) * ldsrc + 4 * j;
+            v[e] = (i < total) ? ld4(src) : zero4();
         }
     }
+    __device__ __forceinline__ void commit(float* sW, int ldw, int ncols, int K) const {
+        const int inner = KMAJOR ? (ncols >> 2) : (K >> 2);
+        const int total = KMAJOR ? K * inner : ncols * inner;
+#pragma unroll
+        for (int e = 0; e < NWS; ++e) {
+            const int i = threadIdx.x + 256 * e;
+            if (i >= total) continue;
+            const int r = i / inner, j = i - r * inner;
+            if (KMAJOR) {                                         // r = k, columns 4j .. 4j+3
+                float* d = sW + (4 * j) * ldw + r;
+                d[0] = v[e].x; d[ldw] = v[e].y; d[2 * ldw] = v[e].z; d[3 * ldw] = v[e].w;
+            } else {                                              // r = column, k = 4j
+                st4(sW + r * ldw + 4 * j, v[e]);
+            }
+        }
+        zero_pads(sW, ncols, ldw, K);
+    }
+};
+
+// acc[t] += A (16 x K, LDS rows sA[i][k]) . W_t^T  for t < NT, tile t = the 16 LDS weight rows starting at row
+// wrow0[t].  Straight-line: no predicate on the tile or on k (K is walked in whole chunks of 16: the LDS rows are
+// zero-padded), fragments of chunk kc + 1 are fetched before the MFMAs of chunk kc.
+template <int NT>
+__device__ __forceinline__ void contract(f32x4 (&acc)[NT], const int (&wrow0)[NT], const float* sA, int lda, const float* sW,
+                                         int ldw, int K) {
+    const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
+    const float* ap = sA + fi * lda + 4 * g;
+    const float* bp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bp[t] = sW + (wrow0[t] + fi) * ldw + 4 * g;
+    const int nk = (K + 15) >> 4;
+    float4 a0, a1, b0[NT], b1[NT];
+#define CT_LOAD(A_, B_, KC)                                                          \
+    do {                                                                             \
+        A_ = ld4(ap + 16 * (KC));                                                    \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) B_[t] = ld4(bp[t] + 16 * (KC)); \
+    } while (0)
+#define CT_MMA(A_, B_)                                                                                         \
+    do {                                                                                                       \
+        const float av_[4] = {A_.x, A_.y, A_.z, A_.w};                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                   \
+                const float bv_ = (j == 0) ? B_[t].x : (j == 1) ? B_[t].y : (j == 2) ? B_[t].z : B_[t].w;     \
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[j], bv_, acc[t], 0, 0, 0);                   \
+            }                                                                                                  \
+    } while (0)
+    CT_LOAD(a0, b0, 0);
+    int kc = 0;
+    for (; kc + 2 <= nk; kc += 2) {
+        CT_LOAD(a1, b1, kc + 1);
+        CT_MMA(a0, b0);
+        if (kc + 2 < nk) CT_LOAD(a0, b0, kc + 2);      // uniform scalar branch
+        CT_MMA(a1, b1);
+    }
+    if (kc < nk) CT_MMA(a0, b0);
 #undef CT_LOAD
 #undef CT_MMA
 }
 
-// rows blocks of this workgroup: rb = blockIdx.x, blockIdx.x + gridDim.x, ...
+// tiles of this wave: global tile indices w, w + 4, ... < ntiles; a surplus slot recomputes tile 0 (result dropped)
+template <int NT>
+__device__ __forceinline__ int wave_tiles(int (&wrow0)[NT], int ntiles) {
+    const int w = threadIdx.x >> 6;
+    int nt = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tile = w + 4 * t;
+        wrow0[t] = tile < ntiles ? 16 * tile : 0;
+        nt += tile < ntiles ? 1 : 0;
+    }
+    return nt;
+}
+
+// accumulators -> LDS sP[16][ldp] (C/D layout of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + r)
+template <int NT>
+__device__ __forceinline__ void spill_tiles(const f32x4 (&acc)[NT], const int (&wrow0)[NT], int nt, float* sP, int ldp) {
+    const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sP[(4 * g + r) * ldp + wrow0[t] + fi] = acc[t][r];
+        }
+    }
+}
+
 #define FOR_ROW_BLOCKS(rb, nrb) for (int rb = blockIdx.x; rb < (nrb); rb += gridDim.x)
 
 // ------------------------------------------------------------------------------------------------------------------
 // input stage:  x_d = x (.) m_x * ms (written to xd, row stride ldxd);  h0 = relu(x_d W0^T + b0);  cur0 = h0 (.) m_0 * ms
-//   x (R, F) contiguous, W0 (H, F) nn.Linear layout; masks are keep flags (any value, scaled by ms) or null (= ones).
+//   x (R, F) contiguous, W0 (H, F) nn.Linear layout; masks are 0 / 1 keep flags (scaled by ms) or null (= ones).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mx,
                                                             const float* __restrict__ W0, const float* __restrict__ b0,
@@ -121,17 +183,18 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
                                                             float* __restrict__ h0, float* __restrict__ cur0, int R,
                                                             int F, int H, int ldxd, float ms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int ldw = lds_stride(F);
+    const int ldw = lds_stride(F), ldp = ((H + 15) & ~15) + 4;   // whole 16-column tiles fit a row of sP
     float* sW = smem;                         // [H][ldw]
-    float* sA = smem + H * ldw;               // [2][16][ldw]
-    stage_weights(sW, ldw, W0, F, 0, H, F, false);
+    float* sA = sW + H * ldw;                 // [2][16][ldw]
+    float* sP = sA + 2 * RB * ldw;            // [16][ldp]
+    WeightStager<false> wst;
+    wst.issue(W0, F, 0, H, F);
     const int nrb = (R + RB - 1) / RB;
-    const int F4 = F >> 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, g = lane >> 4;
-    const int ntiles = (H + 15) >> 4;
-    int nt = 0, wrow0[2] = {0, 0};
-    for (int t = w; t < ntiles && nt < 2; t += 4) wrow0[nt++] = 16 * t;
+    const int F4 = F >> 2, H4 = H >> 2;
+    int wrow0[2];
+    const int nt = wave_tiles<2>(wrow0, (H + 15) >> 4);
     constexpr int NS = 4;                     // float4 slots per thread per block (16 * F / 4 / 256 <= 4 for F <= 256)
+    constexpr int NE = 2;                     // epilogue slots (16 * H / 4 / 256 <= 2)
     float4 rx[NS], rm[NS];
     auto issue = [&](int rb) {
 #pragma unroll
@@ -140,7 +203,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
             const int r = i / F4, k = (i - r * F4) * 4, row = rb * RB + r;
             const bool ok = i < RB * F4 && row < R;
             rx[s] = ok ? ld4(x + (int64_t)row * F + k) : zero4();
-            rm[s] = (ok && mx) ? scl4(ld4(mx + (int64_t)row * F + k), ms) : make_float4(1.f, 1.f, 1.f, 1.f);
+            rm[s] = (ok && mx) ? scl4(ld4(mx + (int64_t)row * F + k), ms) : one4();
         }
     };
     auto park = [&](int rb, float* dst) {
@@ -154,28 +217,38 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
             if (row < R) st4(xd + (int64_t)row * ldxd + k, v);
         }
     };
-    int rb0 = blockIdx.x;
-    if (rb0 < nrb) { issue(rb0); park(rb0, sA); }
+    const int rb0 = blockIdx.x;
+    if (rb0 < nrb) issue(rb0);
+    wst.commit(sW, ldw, H, F);
+    zero_pads(sA, 2 * RB, ldw, F);
+    if (rb0 < nrb) park(rb0, sA);
     __syncthreads();
     int buf = 0;
     FOR_ROW_BLOCKS(rb, nrb) {
         const int nxt = rb + gridDim.x;
         if (nxt < nrb) issue(nxt);
+        float4 em[NE], eb[NE];
+#pragma unroll
+        for (int s = 0; s < NE; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * H4 && row < R;
+            em[s] = (ok && m0) ? scl4(ld4(m0 + (int64_t)row * H + n), ms) : one4();
+            eb[s] = (ok && b0) ? ld4(b0 + n) : zero4();
+        }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        contract<2>(acc, nt, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, F);
+        contract<2>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, F);
+        spill_tiles<2>(acc, wrow0, nt, sP, ldp);
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int n = wrow0[t] + fi;
-            if (t >= nt || n >= H) continue;
-            const float bb = b0 ? b0[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = rb * RB + 4 * g + r;
-                if (rr >= R) continue;
-                const float v = fmaxf(acc[t][r] + bb, 0.f);
-                h0[(int64_t)rr * H + n] = v;
-                cur0[(int64_t)rr * H + n] = m0 ? v * m0[(int64_t)rr * H + n] * ms : v;
-            }
+        for (int s = 0; s < NE; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            if (i >= RB * H4 || row >= R) continue;
+            float4 v = add4(ld4(sP + r * ldp + n), eb[s]);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            st4(h0 + (int64_t)row * H + n, v);
+            st4(cur0 + (int64_t)row * H + n, mul4(v, em[s]));
         }
         if (nxt < nrb) park(nxt, sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -192,17 +265,18 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mx, float* __restrict__ dpre,
                                                             float* __restrict__ dx, int R, int F, int H, int lddxd, float ms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int ldw = lds_stride(H);
+    const int ldw = lds_stride(H), ldp = ((F + 15) & ~15) + 4;
     float* sW = smem;                         // [F][ldw]  (dx = dpre . W0: output column n, contraction index k < H)
-    float* sA = smem + F * ldw;               // [2][16][ldw]
-    stage_weights(sW, ldw, W0, F, 0, F, H, true);
+    float* sA = sW + F * ldw;                 // [2][16][ldw]
+    float* sP = sA + 2 * RB * ldw;            // [16][ldp]
+    WeightStager<true> wst;
+    wst.issue(W0, F, 0, F, H);
     const int nrb = (R + RB - 1) / RB;
-    const int H4 = H >> 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, g = lane >> 4;
-    const int ntiles = (F + 15) >> 4;
-    int nt = 0, wrow0[4] = {0, 0, 0, 0};
-    for (int t = w; t < ntiles && nt < 4; t += 4) wrow0[nt++] = 16 * t;
+    const int H4 = H >> 2, F4 = F >> 2;
+    int wrow0[4];
+    const int nt = wave_tiles<4>(wrow0, (F + 15) >> 4);
     constexpr int NS = 2;                     // 16 * H / 4 / 256 <= 2 for H <= 128
+    constexpr int NE = 4;                     // 16 * F / 4 / 256 <= 4
     float4 rd[NS], rmk[NS], rh0[NS], rdh[NS];
     auto issue = [&](int rb) {
 #pragma unroll
@@ -212,7 +286,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
             const bool ok = i < RB * H4 && row < R;
             const int64_t o = (int64_t)row * H + k;
             rd[s] = (ok && dcur0) ? ld4(dcur0 + o) : zero4();
-            rmk[s] = (ok && m0) ? scl4(ld4(m0 + o), ms) : make_float4(1.f, 1.f, 1.f, 1.f);
+            rmk[s] = (ok && m0) ? scl4(ld4(m0 + o), ms) : one4();
             rdh[s] = (ok && dh0) ? ld4(dh0 + o) : zero4();
             rh0[s] = ok ? ld4(h0 + o) : zero4();
         }
@@ -230,29 +304,36 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
             if (row < R) st4(dpre + (int64_t)row * H + k, v);
         }
     };
-    if ((int)blockIdx.x < nrb) { issue(blockIdx.x); park(blockIdx.x, sA); }
+    if ((int)blockIdx.x < nrb) issue(blockIdx.x);
+    wst.commit(sW, ldw, F, H);
+    zero_pads(sA, 2 * RB, ldw, H);
+    if ((int)blockIdx.x < nrb) park(blockIdx.x, sA);
     __syncthreads();
     int buf = 0;
     FOR_ROW_BLOCKS(rb, nrb) {
         const int nxt = rb + gridDim.x;
         if (nxt < nrb) issue(nxt);
+        float4 ed[NE], em[NE];
+#pragma unroll
+        for (int s = 0; s < NE; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / F4, n = (i - r * F4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * F4 && row < R;
+            ed[s] = (ok && dxd) ? ld4(dxd + (int64_t)row * lddxd + n) : zero4();
+            em[s] = (ok && mx) ? scl4(ld4(mx + (int64_t)row * F + n), ms) : one4();
+        }
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        contract<4>(acc, nt, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, H);
+        contract<4>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, H);
+        spill_tiles<4>(acc, wrow0, nt, sP, ldp);
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = wrow0[t] + fi;
-            if (t >= nt || n >= F) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = rb * RB + 4 * g + r;
-                if (rr >= R) continue;
-                float v = acc[t][r];
-                if (dxd) v += dxd[(int64_t)rr * lddxd + n];
-                if (mx) v *= mx[(int64_t)rr * F + n] * ms;
-                dx[(int64_t)rr * F + n] = v;
-            }
+        for (int s = 0; s < NE; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / F4, n = (i - r * F4) * 4, row = rb * RB + r;
+            if (i >= RB * F4 || row >= R) continue;
+            st4(dx + (int64_t)row * F + n, mul4(add4(ld4(sP + r * ldp + n), ed[s]), em[s]));
         }
         if (nxt < nrb) park(nxt, sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -272,16 +353,16 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
                                                               int H, int ldo, float ms) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = 2 * H;
-    const int ldw = lds_stride(K);
+    const int ldw = lds_stride(K), ldp = ((H + 15) & ~15) + 4;
     float* sW = smem;                         // [H][ldw]
-    float* sA = smem + H * ldw;               // [2][16][ldw]   rows [hi | h0]
-    stage_weights(sW, ldw, W, H, 0, H, K, true);
+    float* sA = sW + H * ldw;                 // [2][16][ldw]   rows [hi | h0]
+    float* sP = sA + 2 * RB * ldw;            // [16][ldp]
+    WeightStager<true> wst;
+    wst.issue(W, H, 0, H, K);
     const int nrb = (R + RB - 1) / RB;
     const int H4 = H >> 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, g = lane >> 4;
-    const int ntiles = (H + 15) >> 4;
-    int nt = 0, wrow0[2] = {0, 0};
-    for (int t = w; t < ntiles && nt < 2; t += 4) wrow0[nt++] = 16 * t;
+    int wrow0[2];
+    const int nt = wave_tiles<2>(wrow0, (H + 15) >> 4);
     constexpr int NS = 2;                     // per source: 16 * H / 4 / 256 <= 2
     float4 ra[NS], rb_[NS];
     auto issue = [&](int rb) {
@@ -304,29 +385,46 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
             st4(dst + r * ldw + H + k, rb_[s]);
         }
     };
-    if ((int)blockIdx.x < nrb) { issue(blockIdx.x); park(sA); }
+    if ((int)blockIdx.x < nrb) issue(blockIdx.x);
+    wst.commit(sW, ldw, H, K);
+    zero_pads(sA, 2 * RB, ldw, K);
+    if ((int)blockIdx.x < nrb) park(sA);
     __syncthreads();
     int buf = 0;
     FOR_ROW_BLOCKS(rb, nrb) {
         const int nxt = rb + gridDim.x;
         if (nxt < nrb) issue(nxt);
         const float* A = sA + buf * RB * ldw;
+        float4 eq[NS], em[NS];                // epilogue operands of this block: in flight while the matrix cores work
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * H4 && row < R;
+            eq[s] = (ok && q) ? ld4(q + (int64_t)row * H + n) : zero4();
+            em[s] = (ok && m) ? scl4(ld4(m + (int64_t)row * H + n), ms) : one4();
+        }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        contract<2>(acc, nt, wrow0, A, ldw, sW, ldw, K);
+        contract<2>(acc, wrow0, A, ldw, sW, ldw, K);
+        spill_tiles<2>(acc, wrow0, nt, sP, ldp);
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int n = wrow0[t] + fi;
-            if (t >= nt || n >= H) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = 4 * g + r, rr = rb * RB + rl;
-                if (rr >= R) continue;
-                const int64_t o = (int64_t)rr * H + n;
-                const float pre = theta * acc[t][r] + (1.0f - theta) * ((1.0f - alpha) * A[rl * ldw + n] + alpha * A[rl * ldw + H + n]);
-                const float mm = m ? m[o] * ms : 1.0f;
-                out[(int64_t)rr * ldo + n] = fmaxf(pre, 0.f) * mm + (q ? q[o] : 0.f);
-                gmask[o] = pre > 0.f ? mm : 0.f;
-            }
+        for (int s = 0; s < NS; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            if (i >= RB * H4 || row >= R) continue;
+            const float4 p = ld4(sP + r * ldp + n), vh = ld4(A + r * ldw + n), v0 = ld4(A + r * ldw + H + n);
+            float4 o, gm;
+#define K7F(F_)                                                                                            \
+    {                                                                                                      \
+        const float pre = theta * p.F_ + (1.0f - theta) * ((1.0f - alpha) * vh.F_ + alpha * v0.F_);       \
+        o.F_ = fmaxf(pre, 0.f) * em[s].F_ + eq[s].F_;                                                      \
+        gm.F_ = pre > 0.f ? em[s].F_ : 0.f;                                                                \
+    }
+            K7F(x) K7F(y) K7F(z) K7F(w)
+#undef K7F
+            st4(out + (int64_t)row * ldo + n, o);
+            st4(gmask + (int64_t)row * H + n, gm);
         }
         if (nxt < nrb) park(sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -343,16 +441,16 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
                                                               float theta, float alpha, int R, int H, int lddo, int acc_h0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N = 2 * H;
-    const int ldw = lds_stride(H);
+    const int ldw = lds_stride(H), ldp = ((N + 15) & ~15) + 4;
     float* sW = smem;                         // [2H][ldw]
-    float* sA = smem + N * ldw;               // [2][16][ldw]   rows dP
-    stage_weights(sW, ldw, W, H, 0, N, H, false);
+    float* sA = sW + N * ldw;                 // [2][16][ldw]   rows dP
+    float* sP = sA + 2 * RB * ldw;            // [16][ldp]
+    WeightStager<false> wst;
+    wst.issue(W, H, 0, N, H);
     const int nrb = (R + RB - 1) / RB;
     const int H4 = H >> 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, g = lane >> 4;
-    const int ntiles = (N + 15) >> 4;
-    int nt = 0, wrow0[4] = {0, 0, 0, 0};
-    for (int t = w; t < ntiles && nt < 4; t += 4) wrow0[nt++] = 16 * t;
+    int wrow0[4];
+    const int nt = wave_tiles<4>(wrow0, (N + 15) >> 4);
     constexpr int NS = 2;
     float4 rd[NS], rg[NS];
     auto issue = [&](int rb) {
@@ -376,7 +474,10 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
             if (row < R) st4(dP + (int64_t)row * H + k, v);
         }
     };
-    if ((int)blockIdx.x < nrb) { issue(blockIdx.x); park(blockIdx.x, sA); }
+    if ((int)blockIdx.x < nrb) issue(blockIdx.x);
+    wst.commit(sW, ldw, N, H);
+    zero_pads(sA, 2 * RB, ldw, H);
+    if ((int)blockIdx.x < nrb) park(blockIdx.x, sA);
     __syncthreads();
     // (1 - theta)(1 - alpha) gg = c1 dP, (1 - theta) alpha gg = c2 dP   (theta = ln(lamda / l + 1) > 0)
     const float c1 = (1.0f - theta) * (1.0f - alpha) / theta, c2 = (1.0f - theta) * alpha / theta;
@@ -385,28 +486,27 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
         const int nxt = rb + gridDim.x;
         if (nxt < nrb) issue(nxt);
         const float* A = sA + buf * RB * ldw;
+        float4 eo[NS];                        // running dh0 of this block (the h0 half is the accumulating one)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            eo[s] = (acc_h0 && i < RB * H4 && row < R) ? ld4(dh0 + (int64_t)row * H + n) : zero4();
+        }
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        contract<4>(acc, nt, wrow0, A, ldw, sW, ldw, H);
+        contract<4>(acc, wrow0, A, ldw, sW, ldw, H);
+        spill_tiles<4>(acc, wrow0, nt, sP, ldp);
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = wrow0[t] + fi;
-            if (t >= nt || n >= N) continue;
-            const int nn = n < H ? n : n - H;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = 4 * g + r, rr = rb * RB + rl;
-                if (rr >= R) continue;
-                const int64_t o = (int64_t)rr * H + nn;
-                const float dp = A[rl * ldw + nn];
-                if (n < H) {
-                    dhi[o] = acc[t][r] + c1 * dp;
-                } else {
-                    const float v = acc[t][r] + c2 * dp;
-                    dh0[o] = acc_h0 ? dh0[o] + v : v;
-                }
-            }
+        for (int s = 0; s < NS; ++s) {
+            const int i = threadIdx.x + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            if (i >= RB * H4 || row >= R) continue;
+            const float4 dp = ld4(A + r * ldw + n);
+            st4(dhi + (int64_t)row * H + n, fma4(dp, c1, ld4(sP + r * ldp + n)));
+            st4(dh0 + (int64_t)row * H + n, add4(fma4(dp, c2, ld4(sP + r * ldp + H + n)), eo[s]));
         }
         if (nxt < nrb) park(nxt, sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -430,27 +530,33 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
                                                             float* __restrict__ c_out, int R, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = h ? 2 * H : H;
-    const int ldw = lds_stride(K);
+    const int ldw = lds_stride(K), lde = UB + 4;
     float* sW = smem;                                  // [4 gates][UB][ldw]
     float* sA = sW + 4 * UB * ldw;                     // [2][16][ldw]   rows [q | h]
-    float* sE = sA + 2 * RB * ldw;                     // [4 gates][16][UB + 1] pre-activations
+    float* sE = sA + 2 * RB * ldw;                     // [4 gates][16][lde] pre-activations
     const int u0 = blockIdx.y * UB;
     const int nu = min(UB, H - u0);
-    // weights: LDS row (gate, ul) <- [W_ih | W_hh] row gate * H + u0 + ul; rows of missing units stay zero
-    for (int i = threadIdx.x; i < 4 * UB * (ldw >> 2); i += 256) st4(sW + 4 * i, zero4());
-    __syncthreads();
+    // weights: LDS row (gate, ul) <- [W_ih | W_hh] row gate * H + u0 + ul; rows of missing units are zero.  All loads
+    // of the slice (<= 13 + 13 16-byte slots per thread) go out at once, the first row block's right behind them.
     const int H4 = H >> 2;
-    for (int i = threadIdx.x; i < 4 * nu * H4; i += 256) {
-        const int rowl = i / H4, k = (i - rowl * H4) * 4;
-        const int gate = rowl / nu, ul = rowl - gate * nu;
-        const int64_t src = (int64_t)(gate * H + u0 + ul) * H + k;
-        st4(sW + (gate * UB + ul) * ldw + k, ld4(Wih + src));
-        if (h) st4(sW + (gate * UB + ul) * ldw + H + k, ld4(Whh + src));
+    constexpr int NW1 = 13;                            // 4 gates x 32 units x (H / 4 <= 25) / 256 threads
+    float4 vi[NW1], vh[NW1];
+    {
+        const int total = 4 * UB * H4;
+#pragma unroll
+        for (int e = 0; e < NW1; ++e) {
+            const int i = threadIdx.x + 256 * e;
+            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            const int gate = rowl / UB, ul = rowl - gate * UB;
+            const bool ok = i < total && ul < nu;
+            const int64_t src = (int64_t)(gate * H + u0 + ul) * H + k;
+            vi[e] = ok ? ld4(Wih + src) : zero4();
+            vh[e] = (ok && h) ? ld4(Whh + src) : zero4();
+        }
     }
     const int nrb = (R + RB - 1) / RB;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, g = lane >> 4;
-    const int nt = (nu + 15) >> 4;                     // unit tiles of this block (1 or 2), gate = wave
-    const int wrow0[2] = {w * UB, w * UB + 16};
+    const int w = threadIdx.x >> 6;
+    const int wrow0[2] = {w * UB, w * UB + 16};        // gate = wave, both unit tiles (units past nu: zero weight rows)
     constexpr int NS = 2;
     float4 rq[NS], rh[NS];
     auto issue = [&](int rb) {
@@ -473,32 +579,61 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
             if (h) st4(dst + r * ldw + H + k, rh[s]);
         }
     };
-    if ((int)blockIdx.x < nrb) { issue(blockIdx.x); park(sA); }
+    if ((int)blockIdx.x < nrb) issue(blockIdx.x);
+    {
+        const int total = 4 * UB * H4;
+#pragma unroll
+        for (int e = 0; e < NW1; ++e) {
+            const int i = threadIdx.x + 256 * e;
+            if (i >= total) continue;
+            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            st4(sW + rowl * ldw + k, vi[e]);                       // rowl = gate * UB + ul
+            if (h) st4(sW + rowl * ldw + H + k, vh[e]);
+        }
+        zero_pads(sW, 4 * UB, ldw, K);
+    }
+    zero_pads(sA, 2 * RB, ldw, K);
+    if ((int)blockIdx.x < nrb) park(sA);
+    // the cell math: threads 0 .. 127 own one (row, 4 units) group of the 16 x 32 block each
+    const int er = threadIdx.x >> 3, eu = (threadIdx.x & 7) * 4;
+    const bool ethread = threadIdx.x < RB * (UB / 4) && eu < nu;
+    float4 bi = zero4(), bf = zero4(), bg = zero4(), bo = zero4();
+    if (ethread) {
+        bi = ld4(bsum + u0 + eu); bf = ld4(bsum + H + u0 + eu); bg = ld4(bsum + 2 * H + u0 + eu); bo = ld4(bsum + 3 * H + u0 + eu);
+    }
     __syncthreads();
     int buf = 0;
     FOR_ROW_BLOCKS(rb, nrb) {
         const int nxt = rb + gridDim.x;
         if (nxt < nrb) issue(nxt);
+        const int erow = rb * RB + er;
+        const float4 cp = (c && ethread && erow < R) ? ld4(c + (int64_t)erow * H + u0 + eu) : zero4();
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        contract<2>(acc, nt, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, K);
+        contract<2>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, K);
+        {
+            const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sE[(w * RB + 4 * g + r) * (UB + 1) + 16 * t + fi] = acc[t][r];
+                for (int r = 0; r < 4; ++r) sE[(w * RB + 4 * g + r) * lde + 16 * t + fi] = acc[t][r];
+        }
         __syncthreads();
-        for (int i = threadIdx.x; i < RB * nu; i += 256) {
-            const int rl = i / nu, ul = i - rl * nu, rr = rb * RB + rl, u = u0 + ul;
-            if (rr >= R) continue;
-            const float gi = sigm(sE[(0 * RB + rl) * (UB + 1) + ul] + bsum[u]);
-            const float gf = sigm(sE[(1 * RB + rl) * (UB + 1) + ul] + bsum[H + u]);
-            const float gg = tanhf(sE[(2 * RB + rl) * (UB + 1) + ul] + bsum[2 * H + u]);
-            const float go = sigm(sE[(3 * RB + rl) * (UB + 1) + ul] + bsum[3 * H + u]);
-            const int64_t o = (int64_t)rr * H + u;
-            const float cn = gf * (c ? c[o] : 0.f) + gi * gg;
-            float* gr = gates + (int64_t)rr * 4 * H + u;
-            gr[0] = gi; gr[H] = gf; gr[2 * H] = gg; gr[3 * H] = go;
-            c_out[o] = cn;
-            h_out[o] = go * tanhf(cn);
+        if (ethread && erow < R) {
+            const float4 pi = add4(ld4(sE + (0 * RB + er) * lde + eu), bi), pf = add4(ld4(sE + (1 * RB + er) * lde + eu), bf);
+            const float4 pg = add4(ld4(sE + (2 * RB + er) * lde + eu), bg), po = add4(ld4(sE + (3 * RB + er) * lde + eu), bo);
+            float4 gi, gf, gg, go, cn, hn;
+#define K8F(F_)                                                                 \
+    {                                                                           \
+        gi.F_ = sigm(pi.F_); gf.F_ = sigm(pf.F_); gg.F_ = tanhf(pg.F_); go.F_ = sigm(po.F_); \
+        cn.F_ = gf.F_ * cp.F_ + gi.F_ * gg.F_;                                  \
+        hn.F_ = go.F_ * tanhf(cn.F_);                                           \
+    }
+            K8F(x) K8F(y) K8F(z) K8F(w)
+#undef K8F
+            float* gr = gates + (int64_t)erow * 4 * H + u0 + eu;
+            st4(gr, gi); st4(gr + H, gf); st4(gr + 2 * H, gg); st4(gr + 3 * H, go);
+            st4(c_out + (int64_t)erow * H + u0 + eu, cn);
+            st4(h_out + (int64_t)erow * H + u0 + eu, hn);
         }
         if (nxt < nrb) park(sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -525,71 +660,124 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
                                                             int lddres) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = 4 * H;
-    const int ldw = lds_stride(K);
+    const int ldw = lds_stride(K), ldp = CBW + 4;
     float* sW = smem;                                  // [CBW][ldw]
-    float* sA = sW + CBW * ldw;                        // [16][ldw]   rows dG
+    float* sA = sW + CBW * ldw;                        // [2][16][ldw]   rows dG; the consumed buffer doubles as sP
     const int nb = (H + CBW - 1) / CBW;
     const bool is_dh = (int)blockIdx.y >= nb;
     const int n0 = (is_dh ? blockIdx.y - nb : blockIdx.y) * CBW;
     const int ncols = min(CBW, H - n0);
-    stage_weights(sW, ldw, is_dh ? Whh : Wih, H, n0, ncols, K, true);
+    WeightStager<true> wst;
+    wst.issue(is_dh ? Whh : Wih, H, n0, ncols, K);
     const int nrb = (R + RB - 1) / RB;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fi = lane & 15, g = lane >> 4;
-    const int nt = (16 * w < ncols) ? 1 : 0;
-    const int wrow0[1] = {16 * w};
+    const int w = threadIdx.x >> 6;
+    const int wrow0[1] = {16 * w < ncols ? 16 * w : 0};
+    const int nt = 16 * w < ncols ? 1 : 0;
     const bool writer = blockIdx.y == 0;
-    FOR_ROW_BLOCKS(rb, nrb) {
-        __syncthreads();                               // the previous block's fragment reads (and the weights) are done
-        for (int idx = threadIdx.x; idx < RB * H; idx += 256) {
-            const int rl = idx / H, u = idx - rl * H;
-            const int rr = rb * RB + rl;
-            float di = 0.f, df = 0.f, dg = 0.f, dO = 0.f;
-            if (rr < R) {
-                const float* gr = gates + (int64_t)rr * 4 * H + u;
-                const float gi = gr[0], gf = gr[H], gg = gr[2 * H], go = gr[3 * H];
-                const int64_t o = (int64_t)rr * H + u;
-                const float dh = (dh_a ? dh_a[o] : 0.f) + (dh_b ? dh_b[o] : 0.f);
-                const float tc = tanhf(c_new[o]);
-                const float dc = (dc_next ? dc_next[o] : 0.f) + dh * go * (1.0f - tc * tc);
-                const float cp = c_prev ? c_prev[o] : 0.f;
-                dO = dh * tc * go * (1.0f - go);
-                di = dc * gg * gi * (1.0f - gi);
-                df = dc * cp * gf * (1.0f - gf);
-                dg = dc * gi * (1.0f - gg * gg);
-                if (writer) {
-                    float* d = dG + (int64_t)rr * 4 * H + u;
-                    d[0] = di; d[H] = df; d[2 * H] = dg; d[3 * H] = dO;
-                    if (has_h) dc_prev[o] = dc * gf;
-                }
-            }
-            float* s = sA + rl * ldw + u;
-            s[0] = di; s[H] = df; s[2 * H] = dg; s[3 * H] = dO;
-        }
-        __syncthreads();
-        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-        contract<1>(acc, nt, wrow0, sA, ldw, sW, ldw, K);
-        const int n = n0 + 16 * w + fi;
-        if (nt && n < H) {
+    const int H4 = H >> 2;
+    constexpr int NS = 2;                              // 16 * H / 4 / 256 <= 2 for H <= 128
+    float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdc[NS];
+    auto issue = [&](int rb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = rb * RB + 4 * g + r;
-                if (rr >= R) continue;
-                const int64_t o = (int64_t)rr * H + n;
-                if (is_dh) dh_prev[o] = acc[0][r];
-                else dq[o] = acc[0][r] + (dres ? dres[(int64_t)rr * lddres + n] : 0.f);
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int i = threadIdx.x + 256 * s_;
+            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * H4 && row < R;
+            const int64_t o = (int64_t)row * H + u;
+            const float* gr = gates + (int64_t)row * 4 * H + u;
+            rgi[s_] = ok ? ld4(gr) : zero4();
+            rgf[s_] = ok ? ld4(gr + H) : zero4();
+            rgg[s_] = ok ? ld4(gr + 2 * H) : zero4();
+            rgo[s_] = ok ? ld4(gr + 3 * H) : zero4();
+            rcn[s_] = ok ? ld4(c_new + o) : zero4();
+            rcp[s_] = (ok && c_prev) ? ld4(c_prev + o) : zero4();
+            float4 d = (ok && dh_a) ? ld4(dh_a + o) : zero4();
+            if (ok && dh_b) d = add4(d, ld4(dh_b + o));
+            rdh[s_] = d;
+            rdc[s_] = (ok && dc_next) ? ld4(dc_next + o) : zero4();
+        }
+    };
+    auto park = [&](int rb, float* dst) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int i = threadIdx.x + 256 * s_;
+            if (i >= RB * H4) continue;
+            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB + r;
+            float4 di, df, dg, dO, dcp;
+#define GB1(F)                                                                      \
+    {                                                                               \
+        const float gi = rgi[s_].F, gf = rgf[s_].F, gg = rgg[s_].F, go = rgo[s_].F; \
+        const float tc = tanhf(rcn[s_].F);                                          \
+        const float dc = rdc[s_].F + rdh[s_].F * go * (1.0f - tc * tc);             \
+        dO.F = rdh[s_].F * tc * go * (1.0f - go);                                   \
+        di.F = dc * gg * gi * (1.0f - gi);                                          \
+        df.F = dc * rcp[s_].F * gf * (1.0f - gf);                                   \
+        dg.F = dc * gi * (1.0f - gg * gg);                                          \
+        dcp.F = dc * gf;                                                            \
+    }
+            GB1(x) GB1(y) GB1(z) GB1(w)
+#undef GB1
+            float* sp = dst + r * ldw + u;               // rows past R carry zeros (their loads were zeroed)
+            st4(sp, di); st4(sp + H, df); st4(sp + 2 * H, dg); st4(sp + 3 * H, dO);
+            if (writer && row < R) {
+                float* d = dG + (int64_t)row * 4 * H + u;
+                st4(d, di); st4(d + H, df); st4(d + 2 * H, dg); st4(d + 3 * H, dO);
+                if (has_h) st4(dc_prev + (int64_t)row * H + u, dcp);
             }
         }
+    };
+    if ((int)blockIdx.x < nrb) issue(blockIdx.x);
+    wst.commit(sW, ldw, ncols, K);
+    if (ncols < CBW) {                                 // weight rows of missing columns: zeros (their results are dropped)
+        for (int i = threadIdx.x; i < (CBW - ncols) * (ldw >> 2); i += 256) st4(sW + ncols * ldw + 4 * i, zero4());
+    }
+    zero_pads(sA, 2 * RB, ldw, K);
+    if ((int)blockIdx.x < nrb) park(blockIdx.x, sA);
+    __syncthreads();
+    // epilogue mapping: thread -> (row, 4 columns) of the 16 x 64 block
+    const int er = threadIdx.x >> 4, en = (threadIdx.x & 15) * 4;
+    int buf = 0;
+    FOR_ROW_BLOCKS(rb, nrb) {
+        const int nxt = rb + gridDim.x;
+        if (nxt < nrb) issue(nxt);
+        const int erow = rb * RB + er;
+        const bool eok = en < ncols && erow < R;
+        const float4 rv = (!is_dh && dres && eok) ? ld4(dres + (int64_t)erow * lddres + n0 + en) : zero4();
+        f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+        float* Acur = sA + buf * RB * ldw;
+        contract<1>(acc, wrow0, Acur, ldw, sW, ldw, K);
+        __syncthreads();                               // every wave is done reading A(cur): its space becomes sP
+        spill_tiles<1>(acc, wrow0, nt, Acur, ldp);
+        __syncthreads();
+        if (eok) {
+            const float4 v = add4(ld4(Acur + er * ldp + en), rv);
+            st4((is_dh ? dh_prev : dq) + (int64_t)erow * H + n0 + en, v);
+        }
+        if (nxt < nrb) park(nxt, sA + (buf ^ 1) * RB * ldw);
+        __syncthreads();
+        buf ^= 1;
     }
 }
 
-inline bool bad_dims(int64_t R, int H) { return R <= 0 || H < 4 || (H & 3) || H > 112 || R > (int64_t)1 << 30; }
+inline bool bad_dims(int64_t R, int H) { return R <= 0 || H < 4 || (H & 3) || H > 100 || R > (int64_t)1 << 30; }
 
 inline int row_groups(int R, int column_blocks) {
     const int nrb = (R + RB - 1) / RB;
     int gq = (256 + column_blocks - 1) / column_blocks;     // ~ one workgroup per CU (LDS holds one weight slice per CU)
     if (gq > nrb) gq = nrb;
+    // even out the row blocks per workgroup: with 330 blocks on 256 groups 74 workgroups would do two and set the pace
+    const int per = (nrb + gq - 1) / gq;
+    gq = (nrb + per - 1) / per;
     return gq < 1 ? 1 : gq;
 }
+
+#define LAUNCH_BIG_LDS(kern, grid, lds, stream, ...)                                  \
+    do {                                                                              \
+        if ((lds) > 156 * 1024) return -1;                                            \
+        if (int e_ = mmdfn_allow_big_lds(kern)) return e_;                            \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)(stream), __VA_ARGS__); \
+        MMDFN_CHECK_LAUNCH();                                                         \
+    } while (0)
 
 }  // namespace
 
@@ -597,25 +785,19 @@ extern "C" int mmdfn_gcn_input_fwd(const float* x, const float* mx, const float*
                                    float* xd, float* h0, float* cur0, int R, int F, int H, int ldxd, float mscale,
                                    void* stream) {
     if (bad_dims(R, H) || F < 4 || (F & 3) || F > 256 || ldxd < F || (ldxd & 3)) return -1;
-    const size_t lds = (size_t)(H + 2 * RB) * lds_stride(F) * sizeof(float);
-    if (lds > 160 * 1024) return -1;
-    if (int e = mmdfn_allow_big_lds(gcn_input_fwd_kernel)) return e;
-    hipLaunchKernelGGL(gcn_input_fwd_kernel, dim3(row_groups(R, 1)), dim3(256), lds, (hipStream_t)stream, x, mx, W0, b0, m0, xd,
-                       h0, cur0, R, F, H, ldxd, mscale);
-    MMDFN_CHECK_LAUNCH();
+    const size_t lds = ((size_t)(H + 2 * RB) * lds_stride(F) + RB * (((H + 15) & ~15) + 4)) * sizeof(float);
+    LAUNCH_BIG_LDS(gcn_input_fwd_kernel, dim3(row_groups(R, 1)), lds, stream, x, mx, W0, b0, m0, xd, h0, cur0, R, F, H, ldxd,
+                   mscale);
     return 0;
 }
 
 extern "C" int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const float* dh0, const float* h0, const float* W0,
                                    const float* dxd, const float* mx, float* dpre, float* dx, int R, int F, int H, int lddxd,
                                    float mscale, void* stream) {
-    if (bad_dims(R, H) || F < 4 || (F & 3) || F > 256 || (dxd && (lddxd < F))) return -1;
-    const size_t lds = (size_t)(F + 2 * RB) * lds_stride(H) * sizeof(float);
-    if (lds > 160 * 1024) return -1;
-    if (int e = mmdfn_allow_big_lds(gcn_input_bwd_kernel)) return e;
-    hipLaunchKernelGGL(gcn_input_bwd_kernel, dim3(row_groups(R, 1)), dim3(256), lds, (hipStream_t)stream, dcur0, m0, dh0, h0, W0,
-                       dxd, mx, dpre, dx, R, F, H, lddxd, mscale);
-    MMDFN_CHECK_LAUNCH();
+    if (bad_dims(R, H) || F < 4 || (F & 3) || F > 256 || (dxd && (lddxd < F || (lddxd & 3)))) return -1;
+    const size_t lds = ((size_t)(F + 2 * RB) * lds_stride(H) + RB * (((F + 15) & ~15) + 4)) * sizeof(float);
+    LAUNCH_BIG_LDS(gcn_input_bwd_kernel, dim3(row_groups(R, 1)), lds, stream, dcur0, m0, dh0, h0, W0, dxd, mx, dpre, dx, R, F, H,
+                   lddxd, mscale);
     return 0;
 }
 
@@ -623,12 +805,9 @@ extern "C" int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* 
                                    const float* bsum, float* gates, float* h_out, float* c_out, int R, int H, void* stream) {
     if (bad_dims(R, H) || (h == nullptr) != (c == nullptr)) return -1;
     const int ncb = (H + UB - 1) / UB;
-    const size_t lds = ((size_t)(4 * UB + 2 * RB) * lds_stride(h ? 2 * H : H) + 4 * RB * (UB + 1)) * sizeof(float);
-    if (lds > 160 * 1024) return -1;
-    if (int e = mmdfn_allow_big_lds(lstm_gate_fwd_kernel)) return e;
-    hipLaunchKernelGGL(lstm_gate_fwd_kernel, dim3(row_groups(R, ncb), ncb), dim3(256), lds, (hipStream_t)stream, q, h, c, Wih,
-                       Whh, bsum, gates, h_out, c_out, R, H);
-    MMDFN_CHECK_LAUNCH();
+    const size_t lds = ((size_t)(4 * UB + 2 * RB) * lds_stride(h ? 2 * H : H) + 4 * RB * (UB + 4)) * sizeof(float);
+    LAUNCH_BIG_LDS(lstm_gate_fwd_kernel, dim3(row_groups(R, ncb), ncb), lds, stream, q, h, c, Wih, Whh, bsum, gates, h_out,
+                   c_out, R, H);
     return 0;
 }
 
@@ -637,39 +816,30 @@ extern "C" int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, cons
                                    const float* dres, float* dG, float* dc_prev, float* dq, float* dh_prev, int R, int H,
                                    int has_h, int lddres, void* stream) {
     if (bad_dims(R, H) || (has_h && (dc_prev == nullptr || dh_prev == nullptr || c_prev == nullptr))) return -1;
-    if (dres != nullptr && lddres < H) return -1;
+    if (dres != nullptr && (lddres < H || (lddres & 3))) return -1;
     const int nb = (H + CBW - 1) / CBW;
     const int ncb = has_h ? 2 * nb : nb;
-    const size_t lds = (size_t)(CBW + RB) * lds_stride(4 * H) * sizeof(float);
-    if (lds > 160 * 1024) return -1;
-    if (int e = mmdfn_allow_big_lds(lstm_gate_bwd_kernel)) return e;
-    hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(row_groups(R, ncb), ncb), dim3(256), lds, (hipStream_t)stream, gates, c_prev,
-                       c_new, dh_a, dh_b, dc_next, Wih, Whh, dres, dG, dc_prev, dq, dh_prev, R, H, has_h, lddres);
-    MMDFN_CHECK_LAUNCH();
+    const size_t lds = (size_t)(CBW + 2 * RB) * lds_stride(4 * H) * sizeof(float);
+    LAUNCH_BIG_LDS(lstm_gate_bwd_kernel, dim3(row_groups(R, ncb), ncb), lds, stream, gates, c_prev, c_new, dh_a, dh_b, dc_next,
+                   Wih, Whh, dres, dG, dc_prev, dq, dh_prev, R, H, has_h, lddres);
     return 0;
 }
 
 extern "C" int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const float* W, const float* q, const float* m,
                                      float* out, float* gmask, float theta, float alpha, int R, int H, int ldo, float mscale,
                                      void* stream) {
-    if (bad_dims(R, H) || ldo < H) return -1;
-    const size_t lds = (size_t)(H + 2 * RB) * lds_stride(2 * H) * sizeof(float);
-    if (lds > 160 * 1024) return -1;
-    if (int e = mmdfn_allow_big_lds(gcnii_layer_fwd_kernel)) return e;
-    hipLaunchKernelGGL(gcnii_layer_fwd_kernel, dim3(row_groups(R, 1)), dim3(256), lds, (hipStream_t)stream, hi, h0, W, q, m, out,
-                       gmask, theta, alpha, R, H, ldo, mscale);
-    MMDFN_CHECK_LAUNCH();
+    if (bad_dims(R, H) || ldo < H || (ldo & 3)) return -1;
+    const size_t lds = ((size_t)(H + 2 * RB) * lds_stride(2 * H) + RB * (((H + 15) & ~15) + 4)) * sizeof(float);
+    LAUNCH_BIG_LDS(gcnii_layer_fwd_kernel, dim3(row_groups(R, 1)), lds, stream, hi, h0, W, q, m, out, gmask, theta, alpha, R, H,
+                   ldo, mscale);
     return 0;
 }
 
 extern "C" int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
                                      float theta, float alpha, int R, int H, int lddo, int acc_h0, void* stream) {
     if (bad_dims(R, H) || lddo < H || (lddo & 3) || !(theta > 0.f)) return -1;
-    const size_t lds = (size_t)(2 * H + 2 * RB) * lds_stride(H) * sizeof(float);
-    if (lds > 160 * 1024) return -1;
-    if (int e = mmdfn_allow_big_lds(gcnii_layer_bwd_kernel)) return e;
-    hipLaunchKernelGGL(gcnii_layer_bwd_kernel, dim3(row_groups(R, 1)), dim3(256), lds, (hipStream_t)stream, dout, gmask, W, dP,
-                       dhi, dh0, theta, alpha, R, H, lddo, acc_h0);
-    MMDFN_CHECK_LAUNCH();
+    const size_t lds = ((size_t)(2 * H + 2 * RB) * lds_stride(H) + RB * (((2 * H + 15) & ~15) + 4)) * sizeof(float);
+    LAUNCH_BIG_LDS(gcnii_layer_bwd_kernel, dim3(row_groups(R, 1)), lds, stream, dout, gmask, W, dP, dhi, dh0, theta, alpha, R, H,
+                   lddo, acc_h0);
     return 0;
 }

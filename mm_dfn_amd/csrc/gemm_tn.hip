@@ -53,55 +53,61 @@ __device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const 
         s_r[e] = idx >> 4;
         s_c[e] = (idx & 15) * 4;
     }
-    float4 ra[2], rb[2];
-    auto issue = [&](int r0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r = r0 + s_r[e];
-            const int rc = r < r_end ? r : r_end - 1;
-            const int rbs = rc + bshift;
-            const int rbc = rbs < 0 ? 0 : (rbs < R ? rbs : R - 1);
-            const int ca = m0 + s_c[e], cb = n0 + s_c[e];
-            ra[e] = *reinterpret_cast<const float4*>(A + (int64_t)rc * lda + (ca < M ? ca : 0));
-            rb[e] = *reinterpret_cast<const float4*>(B + (int64_t)rbc * ldb + (cb < N ? cb : 0));
-        }
-    };
+    // two register sets form a ring: the loads of chunk c + 2 are issued during chunk c and stored to LDS at the top
+    // of chunk c + 2, i.e. two MFMA blocks later -- twice the bytes in flight of a distance-1 prefetch (the kernel is
+    // latency-bound: a split is 10-20 chunks long).  Unrolled by two so that the ring index is static.
+    float4 ra[2][2], rb[2][2];
+#define TN_ISSUE(SET, R0)                                                                                     \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                       \
+            const int r = (R0) + s_r[e];                                                                      \
+            const int rc = r < r_end ? r : r_end - 1;                                                         \
+            const int rbs = rc + bshift;                                                                      \
+            const int rbc = rbs < 0 ? 0 : (rbs < R ? rbs : R - 1);                                            \
+            const int ca = m0 + s_c[e], cb = n0 + s_c[e];                                                     \
+            ra[SET][e] = *reinterpret_cast<const float4*>(A + (int64_t)rc * lda + (ca < M ? ca : 0));         \
+            rb[SET][e] = *reinterpret_cast<const float4*>(B + (int64_t)rbc * ldb + (cb < N ? cb : 0));        \
+        }                                                                                                     \
+    } while (0)
+#define TN_CHUNK(SET, C)                                                                                      \
+    do {                                                                                                      \
+        const int r0 = r_begin + (C) * BR;                                                                    \
+        float* as = As[(C) & 1];                                                                              \
+        float* bs = Bs[(C) & 1];                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                       \
+            const bool rok = (r0 + s_r[e]) < r_end;                                                           \
+            const int rbs = r0 + s_r[e] + bshift;                                                             \
+            const bool aok = rok && (m0 + s_c[e] < M), bok = rok && (n0 + s_c[e] < N) && rbs >= 0 && rbs < R; \
+            /* M, N are multiples of 4 (checked by the launcher), so a float4 is fully inside or outside */   \
+            const float4 va = ra[SET][e], vb = rb[SET][e];                                                    \
+            *reinterpret_cast<float4*>(&as[s_r[e] * LDA + s_c[e]]) =                                          \
+                make_float4(aok ? va.x : 0.f, aok ? va.y : 0.f, aok ? va.z : 0.f, aok ? va.w : 0.f);          \
+            *reinterpret_cast<float4*>(&bs[s_r[e] * LDB + s_c[e]]) =                                          \
+                make_float4(bok ? vb.x : 0.f, bok ? vb.y : 0.f, bok ? vb.z : 0.f, bok ? vb.w : 0.f);          \
+        }                                                                                                     \
+        __syncthreads();                                                                                      \
+        if ((C) + 2 < nchunks) TN_ISSUE(SET, r0 + 2 * BR);                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < BR / 4; ++ks) {                                               \
+            const int rr = 4 * ks + g; /* MFMA k index = row within the chunk */                              \
+            float av[2], bv[2];                                                                               \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) av[i] = as[rr * LDA + 32 * wm + 16 * i + fi];       \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) bv[j] = bs[rr * LDB + 32 * wn + 16 * j + fi];       \
+            csum[0] += av[0];                                                                                 \
+            csum[1] += av[1];                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);       \
+        }                                                                                                     \
+    } while (0)
     const int nchunks = (r_end - r_begin + BR - 1) / BR;
-    if (nchunks > 0) issue(r_begin);
-    for (int c = 0; c < nchunks; ++c) {
-        const int r0 = r_begin + c * BR;
-        float* as = As[c & 1];
-        float* bs = Bs[c & 1];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const bool rok = (r0 + s_r[e]) < r_end;
-            const int rbs = r0 + s_r[e] + bshift;
-            const bool aok = rok && (m0 + s_c[e] < M), bok = rok && (n0 + s_c[e] < N) && rbs >= 0 && rbs < R;
-            // M, N are multiples of 4 (checked by the launcher), so a float4 is fully inside or outside
-            *reinterpret_cast<float4*>(&as[s_r[e] * LDA + s_c[e]]) =
-                make_float4(aok ? ra[e].x : 0.f, aok ? ra[e].y : 0.f, aok ? ra[e].z : 0.f, aok ? ra[e].w : 0.f);
-            *reinterpret_cast<float4*>(&bs[s_r[e] * LDB + s_c[e]]) =
-                make_float4(bok ? rb[e].x : 0.f, bok ? rb[e].y : 0.f, bok ? rb[e].z : 0.f, bok ? rb[e].w : 0.f);
-        }
-        __syncthreads();
-        if (c + 1 < nchunks) issue(r0 + BR);
-#pragma unroll
-        for (int ks = 0; ks < BR / 4; ++ks) {
-            const int rr = 4 * ks + g;   // MFMA k index = row within the chunk
-            float av[2], bv[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = as[rr * LDA + 32 * wm + 16 * i + fi];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = bs[rr * LDB + 32 * wn + 16 * j + fi];
-            csum[0] += av[0];
-            csum[1] += av[1];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+    if (nchunks > 0) TN_ISSUE(0, r_begin);
+    if (nchunks > 1) TN_ISSUE(1, r_begin + BR);
+    for (int c = 0; c < nchunks; c += 2) {
+        TN_CHUNK(0, c);
+        if (c + 1 < nchunks) TN_CHUNK(1, c + 1);
     }
+#undef TN_ISSUE
+#undef TN_CHUNK
     // partial tile -> workspace [split][M][N]; C/D layout: col (n) = lane&15, row (m) = 4g + r
     float* P = part + (int64_t)split * M * N;
 #pragma unroll
@@ -250,14 +256,24 @@ __global__ void gemm_tn_batch_reduce_kernel(const TnOuts oq) {
     const int64_t stride = (int64_t)nblk * blockDim.x;
     for (int64_t idx = (blockIdx.x - oq.blk_prefix[p]) * (int64_t)blockDim.x + threadIdx.x; idx < total + M; idx += stride) {
         if (idx < total) {
+            // fixed summation order, 8 independent loads in flight per thread (a plain loop pays the latency per slab)
             float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += part[(int64_t)k * total + idx];
+            int k = 0;
+            for (; k + 8 <= splits; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = part[(int64_t)(k + e) * total + idx];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[e];
+            }
+            for (; k < splits; ++k) s += part[(int64_t)k * total + idx];
             const int m = (int)(idx / N);
             float* dst = C + (int64_t)m * ldc + (idx - (int64_t)m * N);
             *dst = acc ? *dst + s : s;
         } else if (cs != nullptr) {
             const int m = (int)(idx - total);
             float s = 0.f;
+#pragma unroll 8
             for (int k = 0; k < splits; ++k) s += colpart[(int64_t)k * M + m];
             cs[m] = acc ? cs[m] + s : s;
             if (cs2 != nullptr) cs2[m] = acc ? cs2[m] + s : s;

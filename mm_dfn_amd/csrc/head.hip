@@ -18,15 +18,25 @@ namespace {
 
 constexpr int HC_MAX = 8;        // classes (IEMOCAP 6, MELD 7); wider heads stay on the library path
 constexpr int HB_COLS = 1024;    // feature columns per backward column block (4 float4 per lane)
-constexpr int HB_GROUPS = 128;   // row groups (workgroups per column block) of the backward pass
+constexpr int HB_GROUPS = 256;   // row groups (workgroups per column block) of the backward pass
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ Fm, const float* __restrict__ mask,
                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        float* __restrict__ logp, int64_t N, int W, int C, int ldf,
                                                        float mscale) {
     extern __shared__ __attribute__((aligned(16))) float sW[];       // [C][W]
-    for (int i = threadIdx.x; i < C * W / 4; i += 256)
-        reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(Wt)[i];
+    {   // batches of 8 independent 16-byte loads per thread (one load in flight per thread would pay the latency 6x)
+        const int total = C * W / 4;
+        for (int base = threadIdx.x; base < total; base += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (base + 256 * e < total) v[e] = reinterpret_cast<const float4*>(Wt)[base + 256 * e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (base + 256 * e < total) reinterpret_cast<float4*>(sW)[base + 256 * e] = v[e];
+        }
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int W4 = W / 4;
@@ -82,9 +92,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int col0 = blockIdx.y * HB_COLS;
     const int cols = min(HB_COLS, W - col0);
     const int cols4 = cols / 4;
-    for (int i = threadIdx.x; i < C * cols4; i += 256) {
-        const int c = i / cols4, j = i - c * cols4;
-        reinterpret_cast<float4*>(sm)[c * (HB_COLS / 4) + j] = *reinterpret_cast<const float4*>(Wt + (int64_t)c * W + col0 + 4 * j);
+    for (int base = threadIdx.x; base < C * cols4; base += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = base + 256 * e, c = i / cols4, j = i - c * cols4;
+            if (i < C * cols4) v[e] = *reinterpret_cast<const float4*>(Wt + (int64_t)c * W + col0 + 4 * j);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = base + 256 * e, c = i / cols4, j = i - c * cols4;
+            if (i < C * cols4) reinterpret_cast<float4*>(sm)[c * (HB_COLS / 4) + j] = v[e];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -172,8 +191,17 @@ __global__ void head_reduce_kernel(const float* __restrict__ part, const float* 
                                    float* __restrict__ db, int groups, int CW, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < CW) {
+        // fixed order, 8 independent loads in flight per thread (a plain loop pays the memory latency 128 times)
         float s = 0.f;
-        for (int gidx = 0; gidx < groups; ++gidx) s += part[(int64_t)gidx * CW + idx];
+        int gidx = 0;
+        for (; gidx + 8 <= groups; gidx += 8) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = part[(int64_t)(gidx + e) * CW + idx];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[e];
+        }
+        for (; gidx < groups; ++gidx) s += part[(int64_t)gidx * CW + idx];
         dW[idx] = s;
     } else if (idx < CW + C) {
         const int c = idx - CW;

@@ -42,8 +42,12 @@ inline int mmdfn_allow_big_lds(Kern kern) {
     const void* key = reinterpret_cast<const void*>(kern);
     for (int i = 0; i < 8; ++i)
         if (done[i] == key) return 0;
-    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
+    // (a little below the 160 KB of a CU: kernels may also hold a few hundred bytes of static LDS)
+    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // do not leave the error for the next launch check to find
+        return (int)e;
+    }
     for (int i = 0; i < 8; ++i)
         if (done[i] == nullptr) { done[i] = key; break; }
     return 0;

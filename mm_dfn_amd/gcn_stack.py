@@ -21,7 +21,7 @@ ROW_LIMIT = 32768
 
 def eligible(x, nfeat, nhidden, nlayers, params):
     return (x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= ROW_LIMIT and nlayers >= 1
-            and nhidden % 4 == 0 and 4 <= nhidden <= 112 and nfeat % 4 == 0 and 4 <= nfeat <= 256
+            and nhidden % 4 == 0 and 4 <= nhidden <= 100 and nfeat % 4 == 0 and 4 <= nfeat <= 256
             and (not torch.is_grad_enabled() or all(ops._leaf(p) for p in params)))
 
 
