@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs (cfg2 ragged, cfg3, cfg4 shard, cfg5, streamed)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the K6 roofline legs (profiling runs of the step alone)")
+    ap.add_argument("--only-roofline", action="store_true", help="profiling aid: run only the K6 roofline legs (clean rocprof traces)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per cpu_baseline mode")
@@ -285,6 +286,11 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
+    # stdout carries ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner
+    # at teardown, gloo's connection log) are pointed at stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -301,6 +307,13 @@ def main():
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # eager + captured steps share parameters
 
+    if a.only_roofline:
+        out = {"note": "K6 roofline legs only (profiling aid)"}
+        cfg = dict(synthetic.CONFIGS[a.config])
+        lengths = synthetic.make_lengths(None, cfg["B"], cfg["L"], False)
+        roofline_legs(out, a, dev, sum(lengths), lengths)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
     use_dp = world > 1 or a.force_dp
     if use_dp:
         os.environ.setdefault("RANK", "0")
@@ -444,7 +457,7 @@ def main():
                 torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline and not use_dp:
             out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads, a.dropout, a.cpu_budget)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
         torch.distributed.destroy_process_group()
 

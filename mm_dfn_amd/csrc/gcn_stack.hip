@@ -44,7 +44,11 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 scl4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 fma4(float4 a, float s, float4 b) { return make_float4(a.x * s + b.x, a.y * s + b.y, a.z * s + b.z, a.w * s + b.w); }
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each), as in gru.hip: the
+// accurate libm expf / tanhf are ~60-100 instructions each and the LSTM cell evaluates six per element -- more issue
+// slots than the contraction next to it.  Absolute error < 3e-7 (parity budget of the stack: 1e-5).
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // LDS row stride (floats) for rows of K floats: room for K rounded up to 16 (the MFMA loop reads whole 16-wide chunks;
 // the padding holds zeros), 16-byte aligned and (stride / 4) odd, so that the 16 rows a quarter wave reads at one k
@@ -594,12 +598,13 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
     }
     zero_pads(sA, 2 * RB, ldw, K);
     if ((int)blockIdx.x < nrb) park(sA);
-    // the cell math: threads 0 .. 127 own one (row, 4 units) group of the 16 x 32 block each
-    const int er = threadIdx.x >> 3, eu = (threadIdx.x & 7) * 4;
-    const bool ethread = threadIdx.x < RB * (UB / 4) && eu < nu;
-    float4 bi = zero4(), bf = zero4(), bg = zero4(), bo = zero4();
+    // the cell math: every thread owns one (row, 2 units) group of the 16 x 32 block
+    const int er = threadIdx.x >> 4, eu = (threadIdx.x & 15) * 2;
+    const bool ethread = eu < nu;                      // nu is a multiple of 4
+    float2 bi = make_float2(0.f, 0.f), bf = bi, bg = bi, bo = bi;
     if (ethread) {
-        bi = ld4(bsum + u0 + eu); bf = ld4(bsum + H + u0 + eu); bg = ld4(bsum + 2 * H + u0 + eu); bo = ld4(bsum + 3 * H + u0 + eu);
+        bi = *reinterpret_cast<const float2*>(bsum + u0 + eu); bf = *reinterpret_cast<const float2*>(bsum + H + u0 + eu);
+        bg = *reinterpret_cast<const float2*>(bsum + 2 * H + u0 + eu); bo = *reinterpret_cast<const float2*>(bsum + 3 * H + u0 + eu);
     }
     __syncthreads();
     int buf = 0;
@@ -607,7 +612,8 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
         const int nxt = rb + gridDim.x;
         if (nxt < nrb) issue(nxt);
         const int erow = rb * RB + er;
-        const float4 cp = (c && ethread && erow < R) ? ld4(c + (int64_t)erow * H + u0 + eu) : zero4();
+        const float2 cp = (c && ethread && erow < R) ? *reinterpret_cast<const float2*>(c + (int64_t)erow * H + u0 + eu)
+                                                     : make_float2(0.f, 0.f);
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         contract<2>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, K);
         {
@@ -619,21 +625,24 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
         }
         __syncthreads();
         if (ethread && erow < R) {
-            const float4 pi = add4(ld4(sE + (0 * RB + er) * lde + eu), bi), pf = add4(ld4(sE + (1 * RB + er) * lde + eu), bf);
-            const float4 pg = add4(ld4(sE + (2 * RB + er) * lde + eu), bg), po = add4(ld4(sE + (3 * RB + er) * lde + eu), bo);
-            float4 gi, gf, gg, go, cn, hn;
+            const float2 pi = *reinterpret_cast<const float2*>(sE + (0 * RB + er) * lde + eu);
+            const float2 pf = *reinterpret_cast<const float2*>(sE + (1 * RB + er) * lde + eu);
+            const float2 pg = *reinterpret_cast<const float2*>(sE + (2 * RB + er) * lde + eu);
+            const float2 po = *reinterpret_cast<const float2*>(sE + (3 * RB + er) * lde + eu);
+            float2 gi, gf, gg, go, cn, hn;
 #define K8F(F_)                                                                 \
     {                                                                           \
-        gi.F_ = sigm(pi.F_); gf.F_ = sigm(pf.F_); gg.F_ = tanhf(pg.F_); go.F_ = sigm(po.F_); \
+        gi.F_ = sigm(pi.F_ + bi.F_); gf.F_ = sigm(pf.F_ + bf.F_); gg.F_ = tanhf_(pg.F_ + bg.F_); go.F_ = sigm(po.F_ + bo.F_); \
         cn.F_ = gf.F_ * cp.F_ + gi.F_ * gg.F_;                                  \
-        hn.F_ = go.F_ * tanhf(cn.F_);                                           \
+        hn.F_ = go.F_ * tanhf_(cn.F_);                                          \
     }
-            K8F(x) K8F(y) K8F(z) K8F(w)
+            K8F(x) K8F(y)
 #undef K8F
             float* gr = gates + (int64_t)erow * 4 * H + u0 + eu;
-            st4(gr, gi); st4(gr + H, gf); st4(gr + 2 * H, gg); st4(gr + 3 * H, go);
-            st4(c_out + (int64_t)erow * H + u0 + eu, cn);
-            st4(h_out + (int64_t)erow * H + u0 + eu, hn);
+            *reinterpret_cast<float2*>(gr) = gi; *reinterpret_cast<float2*>(gr + H) = gf;
+            *reinterpret_cast<float2*>(gr + 2 * H) = gg; *reinterpret_cast<float2*>(gr + 3 * H) = go;
+            *reinterpret_cast<float2*>(c_out + (int64_t)erow * H + u0 + eu) = cn;
+            *reinterpret_cast<float2*>(h_out + (int64_t)erow * H + u0 + eu) = hn;
         }
         if (nxt < nrb) park(sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -707,7 +716,7 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
 #define GB1(F)                                                                      \
     {                                                                               \
         const float gi = rgi[s_].F, gf = rgf[s_].F, gg = rgg[s_].F, go = rgo[s_].F; \
-        const float tc = tanhf(rcn[s_].F);                                          \
+        const float tc = tanhf_(rcn[s_].F);                                         \
         const float dc = rdc[s_].F + rdh[s_].F * go * (1.0f - tc * tc);             \
         dO.F = rdh[s_].F * tc * go * (1.0f - go);                                   \
         di.F = dc * gg * gi * (1.0f - gi);                                          \

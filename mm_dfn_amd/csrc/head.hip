@@ -18,7 +18,7 @@ namespace {
 
 constexpr int HC_MAX = 8;        // classes (IEMOCAP 6, MELD 7); wider heads stay on the library path
 constexpr int HB_COLS = 1024;    // feature columns per backward column block (4 float4 per lane)
-constexpr int HB_GROUPS = 256;   // row groups (workgroups per column block) of the backward pass
+constexpr int HB_GROUPS = 128;   // row groups (workgroups per column block) of the backward pass
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ Fm, const float* __restrict__ mask,
                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
@@ -187,27 +187,32 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         bpart[blockIdx.x * C + threadIdx.x] = sdb[0][threadIdx.x] + sdb[1][threadIdx.x] + sdb[2][threadIdx.x] + sdb[3][threadIdx.x];
 }
 
-__global__ void head_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ dW,
-                                   float* __restrict__ db, int groups, int CW, int C) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < CW) {
-        // fixed order, 8 independent loads in flight per thread (a plain loop pays the memory latency 128 times)
-        float s = 0.f;
-        int gidx = 0;
-        for (; gidx + 8 <= groups; gidx += 8) {
-            float v[8];
+// sums the per-workgroup slabs: 8 lanes per output element, each adds its share of the slabs in a fixed order (all
+// its loads in flight at once), the 8 partial sums meet with shuffles in a fixed tree -> bit-reproducible
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart,
+                                                          float* __restrict__ dW, float* __restrict__ db, int groups, int CW,
+                                                          int C) {
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    float s = 0.f;
+    if (idx < CW + C) {
+        const float* src = idx < CW ? part + idx : bpart + (idx - CW);
+        const int stride = idx < CW ? CW : C;
+        float v[HB_GROUPS / 8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = part[(int64_t)(gidx + e) * CW + idx];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[e];
+        for (int e = 0; e < HB_GROUPS / 8; ++e) {
+            const int gidx = sub + 8 * e;
+            v[e] = gidx < groups ? src[(int64_t)gidx * stride] : 0.f;
         }
-        for (; gidx < groups; ++gidx) s += part[(int64_t)gidx * CW + idx];
-        dW[idx] = s;
-    } else if (idx < CW + C) {
-        const int c = idx - CW;
-        float s = 0.f;
-        for (int gidx = 0; gidx < groups; ++gidx) s += bpart[gidx * C + c];
-        db[c] = s;
+#pragma unroll
+        for (int e = 0; e < HB_GROUPS / 8; ++e) s += v[e];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0 && idx < CW + C) {
+        if (idx < CW) dW[idx] = s;
+        else db[idx - CW] = s;
     }
 }
 
@@ -241,7 +246,7 @@ extern "C" int mmdfn_head_bwd(const float* dlogp, const float* logp, const float
     hipLaunchKernelGGL(head_bwd_kernel, dim3(HB_GROUPS, nblk), dim3(256), lds, s, dlogp, logp, F, mask, W, dF, part, bpart, N, Wd, C,
                        ldf, lddf, mscale);
     MMDFN_CHECK_LAUNCH();
-    const int total = C * Wd + C;
+    const int total = (C * Wd + C) * 8;               // 8 lanes per output element
     hipLaunchKernelGGL(head_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, bpart, dW, db, HB_GROUPS, C * Wd, C);
     MMDFN_CHECK_LAUNCH();
     return 0;

@@ -1,0 +1,54 @@
+"""Per-step time by kernel family from a rocprofv3 --kernel-trace --stats CSV of `bench.py --no-extra --no-roofline
+--no-cpu-baseline` (one workload per CSV).    python tools/step_breakdown.py <kernel_stats.csv> <out.json> [label]"""
+import csv
+import json
+import re
+import sys
+
+FAMILIES = [
+    ("gru_recurrence", r"gru_seq_"),
+    ("weight_gradients", r"gemm_tn"),
+    ("gcn_stack_fused", r"lstm_gate_|gcnii_layer_|gcn_input_|lstm_pointwise|gcnii_combine"),
+    ("propagate_K6", r"propagate_"),
+    ("adjacency_K5_K6b", r"tile_dot|unit_cross|rdeg_cross|scale_tiles|symmetrize|bwd_rowsum|bwd_etile|bwd_ecross|cross_dot|unit_bwd"),
+    ("projections_hand_written", r"linear_kernel|linear_split"),
+    ("projections_hipblaslt", r"^Cijk_"),
+    ("head_and_loss", r"head_|focal_loss"),
+    ("encoder_glue", r"party_"),
+    ("optimizer", r"adam_step"),
+    ("aten_and_runtime", r"at::native|rocclr|rocprim|elementwise_kernel_with_index"),
+]
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    calls = {r["Name"]: int(r["Calls"]) for r in rows}
+    steps = max((c for n, c in calls.items() if "gru_seq_fwd" in n), default=0) // 2
+    if steps <= 0:
+        raise SystemExit("no gru_seq_fwd kernel in the trace: cannot tell the step count")
+    fam = {k: dict(us_per_step=0.0, launches_per_step=0.0) for k, _ in FAMILIES}
+    fam["other"] = dict(us_per_step=0.0, launches_per_step=0.0)
+    for r in rows:
+        name = r["Name"]
+        for k, pat in FAMILIES:
+            if re.search(pat, name):
+                break
+        else:
+            k = "other"
+        fam[k]["us_per_step"] += float(r["TotalDurationNs"]) / 1e3 / steps
+        fam[k]["launches_per_step"] += int(r["Calls"]) / steps
+    total = sum(v["us_per_step"] for v in fam.values())
+    out = {"source": sys.argv[1].split("/")[-1], "label": sys.argv[3] if len(sys.argv) > 3 else "", "steps_in_trace": steps,
+           "kernel_us_per_step": round(total, 1), "launches_per_step": round(sum(v["launches_per_step"] for v in fam.values()), 1),
+           "families": {k: {"us_per_step": round(v["us_per_step"], 1), "share": round(v["us_per_step"] / total, 3),
+                            "launches_per_step": round(v["launches_per_step"], 1)}
+                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["us_per_step"]) if v["us_per_step"] > 0}}
+    dom = next(iter(out["families"]))
+    out["dominant"] = "%s: %.0f us of %.0f us kernel time per step (%.0f %%)" % (
+        dom, out["families"][dom]["us_per_step"], total, 100 * out["families"][dom]["share"])
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
