@@ -101,12 +101,24 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
         if gru.hidden_size != H or gru.num_layers != 2 or not gru.bidirectional or gru.batch_first:
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
     cur = list(xs)
+    # stacked copies [W_ih_fwd; W_ih_rev] of every (module, layer) for the input-gradient GEMMs of the backward pass:
+    # ONE multi-tensor copy launch per step (the forward contraction reads the two parameters directly)
+    wcat = None
+    if torch.is_grad_enabled():
+        halves = [w for layer in range(2) for gru in grus for w in _layer_params(gru, layer)[0]]
+        with torch.no_grad():
+            wcat = torch.empty(len(halves) // 2, 2 * halves[0].shape[0], halves[0].shape[1], dtype=halves[0].dtype,
+                               device=halves[0].device)
+            torch._foreach_copy_([wcat[i // 2, (i % 2) * halves[0].shape[0]:(i % 2 + 1) * halves[0].shape[0]]
+                                  for i in range(len(halves))], halves)
     for layer in range(2):
         prm = [_layer_params(gru, layer) for gru in grus]
         # hoisted input contractions (all t, both directions) of every group: one launch per group on the two
         # directions' own weight_ih / bias_ih parameters
         pre = gi0 if (layer == 0 and gi0 is not None) else [None] * len(grus)
-        gis = [pre[g] if pre[g] is not None else ops.linear2(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1])
+        gis = [pre[g] if pre[g] is not None else
+               ops.linear2(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1],
+                           None if wcat is None else wcat[layer * len(grus) + g])
                for g in range(len(grus))]
         args = []
         for gi, p in zip(gis, prm):

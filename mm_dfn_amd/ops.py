@@ -500,21 +500,28 @@ def flush_queued_wgrads():
     # gradient destinations: fresh buffers handed to .grad (the usual case: backward runs with .grad = None), or the
     # existing .grad accumulated in place
     work = []                                   # (out, C, colsum targets, accumulate, segment slice)
-    fresh = set()                               # gradients allocated by this flush (their row ranges are disjoint)
+    fresh = set()                               # gradients allocated by this flush
+    covered = {}                                # id(weight) -> rows filled by this flush (row-range contributions)
+    for o in outs:
+        covered[id(o["weight"])] = covered.get(id(o["weight"]), 0) + (o["rows"][1] - o["rows"][0])
     for o in outs:
         w = o["weight"]
         have = [w.grad is not None and id(w) not in fresh] + [b.grad is not None for b in o["biases"]]
         acc = any(have)
         full = o["rows"] == (0, w.shape[0])
         if w.grad is None:
-            # a row-range contribution may be the only one of its parameter: rows nobody fills must be zero
-            w.grad = (torch.empty if (full and not acc) else torch.zeros)(tuple(w.shape), dtype=torch.float32, device=dev)
+            # row ranges that together cover the parameter (GraphConvolution.weight: [hi^T dP ; h0^T dP]) need no
+            # zero fill; a range that leaves rows nobody writes does
+            whole = covered[id(w)] >= w.shape[0]
+            w.grad = (torch.empty if (whole and not acc) else torch.zeros)(tuple(w.shape), dtype=torch.float32, device=dev)
             fresh.add(id(w))
+            if whole and not acc:
+                fresh.add(("written", id(w)))
         elif not w.grad.is_contiguous():
             w.grad = w.grad.contiguous()
         C = w.grad if full else w.grad[o["rows"][0]:o["rows"][1]]
         if id(w) in fresh and not full:
-            acc_here = 1                        # zero-initialised above: adding is the same as writing
+            acc_here = 0 if ("written", id(w)) in fresh else 1       # zero-initialised: adding is the same as writing
         else:
             acc_here = 1 if acc else 0
         cs = []
@@ -775,7 +782,7 @@ class _Linear2(torch.autograd.Function):
     concatenated copy per step (csrc/linear.hip, mmdfn_linear2)."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, b1, b2):
+    def forward(ctx, x, w1, w2, b1, b2, wcat):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         _hip.require_cuda(x2, w1, w2)
@@ -790,28 +797,31 @@ class _Linear2(torch.autograd.Function):
                                       R, K, N, x2.stride(0), N, 0, 0, _hip.stream())
         _hip.check(rc, "mmdfn_linear2")
         ctx.refs = (w1, w2, b1, b2)
-        ctx.save_for_backward(x2, w1c, w2c)
+        ctx.save_for_backward(x2, w1c, w2c, wcat)
         return y.view(*shp[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w1, w2 = ctx.saved_tensors
+        x2, w1, w2, wcat = ctx.saved_tensors
         p1, p2, b1, b2 = ctx.refs
         n1 = w1.shape[0]
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         d1, d2 = dy2[:, :n1], dy2[:, n1:]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.addmm(d1 @ w1, d2, w2).view(*dy.shape[:-1], w1.shape[1])
+            # the input gradient is one plain library GEMM over the stacked weight when the caller provides a stacked
+            # copy (bigru2 packs all of a step's in one launch), two accumulating GEMMs on the parameters otherwise
+            dx = (dy2 @ wcat if wcat is not None else torch.addmm(d1 @ w1, d2, w2)).view(*dy.shape[:-1], w1.shape[1])
         dw1, db1 = _wgrad(d1, x2, p1, b1)
         dw2, db2 = _wgrad(d2, x2, p2, b2)
-        return dx, dw1, dw2, db1, db2
+        return dx, dw1, dw2, db1, db2, None
 
 
-def linear2(x, w1, w2, b1, b2):
+def linear2(x, w1, w2, b1, b2, wcat=None):
+    """``wcat``: optional (n1 + n2, K) stacked copy of [w1; w2] (no gradient flows through it) used for the input gradient."""
     if w1.shape[1] % 4 or w1.shape[1] < 4:
         raise ValueError("linear2: the contraction width must be a multiple of 4")
-    return _Linear2.apply(x, w1, w2, b1, b2)
+    return _Linear2.apply(x, w1, w2, b1, b2, wcat)
 
 
 class _Head(torch.autograd.Function):

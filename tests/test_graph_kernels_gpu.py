@@ -463,6 +463,13 @@ def test_two_block_projection(R, K, n1, n2):
     assert rel_err(x.grad, xr.grad) < 1e-5
     for p, r in zip((w1, w2, b1, b2), pr):
         assert p.grad is not None and rel_err(p.grad, r.grad) < 1e-5
+    # with a stacked weight copy for the input gradient (what bigru2 passes): same gradients
+    x2 = x.detach().clone().requires_grad_(True)
+    g_before = [p.grad.clone() for p in (w1, w2, b1, b2)]
+    (ops.linear2(x2, w1, w2, b1, b2, torch.cat([w1, w2], 0).detach()) * W).sum().backward()
+    assert rel_err(x2.grad, xr.grad) < 1e-5
+    for p, g0 in zip((w1, w2, b1, b2), g_before):
+        assert rel_err(p.grad, 2 * g0.double().cpu()) < 1e-5          # accumulated into the existing .grad
     # no biases (the project-then-gather path adds the bias after the gather)
     y0 = ops.linear2(x.detach(), w1, w2, None, None)
     assert rel_err(y0, yr - torch.cat([pr[2], pr[3]], 0)) < 2e-6
