@@ -153,7 +153,7 @@ def quick_leg(cfgname, ragged, dropout, steps=12, warmup=4):
     def fwd_bwd():
         logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
         loss = loss_f(logp, label)
-        loss.backward()
+        train.backward(loss)
         return loss
 
     dt = timed_replays(CapturedStep(model, fwd_bwd, warmup=2), steps, warmup)
@@ -183,7 +183,7 @@ def cfg5_leg(name, dropout, steps=6, warmup=2):
 
     def fwd_bwd():
         loss = loss_f(model(batch["streams"], batch["qmask"], batch["umask"], lengths)[0], label)
-        loss.backward()
+        train.backward(loss)
         return loss
 
     dt = timed_replays(CapturedStep(model, fwd_bwd, warmup=1), steps, warmup)
@@ -340,7 +340,7 @@ def main():
         loss = loss_f(logp, label)
         if dp is not None:
             loss = loss * scale        # the summed bucket is then the gradient of the mean over ALL ranks' utterances
-        loss.backward()
+        train.backward(loss)
         return loss
 
     def eager_step():

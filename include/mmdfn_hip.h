@@ -109,18 +109,24 @@ int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross,
  *   y[g]     : (T, rows, 2H) out; direction 1 runs t = T-1 .. 0; zero initial state
  *   gates[g] : (T, rows, 2, 4, H) out: r, z, n and W_hn h + b_hn (saved for backward)
  * H must be 100 (the reference hard-codes D_e = 100).
+ * mask / ym (arrays of ngroups pointers, or both NULL; entries may be NULL): the inter-layer dropout of
+ *   nn.GRU(num_layers=2, dropout=p) (model.py:866,868) folded into the output stage: mask[g] (T, rows, 2H) holds 0 / 1
+ *   keep flags and ym[g] receives y (.) mask * mscale (mscale = 1/(1-p)), the next layer's input; y stays unmasked
+ *   (it is the recurrence's own state history).
  * ------------------------------------------------------------------------- */
 int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const float* const* w_hh,
                       const float* const* b_hh, float* const* y, float* const* gates,
+                      const float* const* mask, float* const* ym, float mscale,
                       const int* rows, const int* T, int H, void* stream);
 
 /* Backward through time of the same recurrence: given dy[g] (T, rows, 2H) writes
  *   dgi[g], dgh[g] : (T, rows, 2, 3H)  gradients of the input-side / hidden-side gate
  *   pre-activations (they differ only in the n gate: dgh_n = dgi_n * r).
- * Weight gradients are dense contractions of these done by the caller. */
+ * Weight gradients are dense contractions of these done by the caller.
+ * mask (array, or NULL; entries may be NULL): dy[g] is the gradient of ym[g], i.e. dy (.) mask * mscale reaches y. */
 int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const float* const* y,
                       const float* const* gates, const float* const* w_hh,
-                      float* const* dgi, float* const* dgh,
+                      float* const* dgi, float* const* dgh, const float* const* mask, float mscale,
                       const int* rows, const int* T, int H, void* stream);
 
 /* ---------------------------------------------------------------------------
@@ -169,11 +175,13 @@ int mmdfn_gcnii_combine_bwd(const float* P, const float* S2, const float* mask, 
  *   `weights` is a HOST array of Mn floats (speaker_weights, model.py:816).
  * Backward entries: dX / dbase are Mn host-array entries of device (L, B, H) buffers;
  *   combine_bwd expects dbase and dE pre-zeroed (it writes only the rows that exist).
+ *   gather_bwd: `addend` (NULL, or Mn entries each NULL or an (L, B, H) buffer) is added to dX -- the gradient that
+ *   reaches X_m as the base of the combine stage, so that no separate accumulation launch is needed.
  * ------------------------------------------------------------------------- */
 int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, const float* bias, float* S,
                        int32_t* rank, int L, int B, int P, int H, void* stream);
 int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX,
-                           int L, int B, int P, int H, void* stream);
+                           const float* const* addend, int L, int B, int P, int H, void* stream);
 int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const int32_t* rank,
                         const int64_t* flat_idx, float* out, const float* weights,
                         int L, int B, int P, int N, int H, void* stream);
@@ -237,7 +245,8 @@ int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* const* B, f
  * input stage (model_GCN.py:453-456):  xd = x (.) mx (row stride ldxd);  h0 = relu(xd W0^T + b0);  cur0 = h0 (.) m0
  *   bwd:  dpre = (dcur0 (.) m0 + dh0) (.) [h0 > 0]  (operand of dW0 / db0);  dx = (dpre W0 + dxd) (.) mx,
  *         dxd = gradient reaching xd directly (row stride lddxd) or NULL.
- * gate (K8, model_GCN.py:463-467, nn.LSTM seq_len 1, gate order i f g o, W_ih / W_hh (4H, H), bsum = b_ih + b_hh):
+ * gate (K8, model_GCN.py:463-467, nn.LSTM seq_len 1, gate order i f g o, W_ih / W_hh (4H, H), bias = bsum + bsum2
+ *   (b_ih, b_hh; bsum2 may be NULL):
  *   fwd:  (h_out, c_out) = LSTMCell(q, (h, c));  h = c = NULL is the zero state;  gates (R, 4H) = gate ACTIVATIONS.
  *   bwd:  dh' = dh_a + dh_b (either NULL), dc_next (NULL = 0) -> dG (R, 4H) pre-activation gradients (operand of
  *         dW_ih, dW_hh, db), dc_prev, dq = dG W_ih + dres (row stride lddres, NULL = 0), dh_prev = dG W_hh;  has_h = 0: the incoming
@@ -255,7 +264,8 @@ int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const float* dh0, c
                         const float* dxd, const float* mx, float* dpre, float* dx, int R, int F, int H, int lddxd,
                         float mscale, void* stream);
 int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
-                        const float* bsum, float* gates, float* h_out, float* c_out, int R, int H, void* stream);
+                        const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                        void* stream);
 int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh_a, const float* dh_b,
                         const float* dc_next, const float* Wih, const float* Whh, const float* dres, float* dG,
                         float* dc_prev, float* dq, float* dh_prev, int R, int H, int has_h, int lddres, void* stream);
@@ -297,13 +307,16 @@ int mmdfn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  *   mask: (N, Wd) 0 / 1 keep flags or NULL, W: (C, Wd) nn.Linear layout, C <= 8 classes, Wd % 4 == 0.
  *   bwd: dF (row stride lddf), dW (C, Wd), db (C) from dlogp; workspace: mmdfn_head_bwd_workspace(Wd, C) floats;
  *   dW / db are reduced in a fixed order (bit-reproducible).
+ *   split = 0: F / dF are plain (N, Wd) matrices.  split = Wm > 0 (Wm % 4 == 0, Wd % Wm == 0): F / dF are Wd / Wm
+ *   consecutive (N, Wm) matrices of row stride ldf / lddf, read as their column-wise concatenation -- the (M, N, Wm)
+ *   output of the graph stack used as cat([F[0], .., F[M-1]], -1) (model_mm.py:113-117) without materialising it.
  * ------------------------------------------------------------------------- */
 int mmdfn_head_fwd(const float* F, const float* mask, const float* W, const float* bias, float* logp, int64_t N, int Wd,
-                   int C, int ldf, float mscale, void* stream);
+                   int C, int ldf, int split, float mscale, void* stream);
 int64_t mmdfn_head_bwd_workspace(int Wd, int C);
 int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
-                   float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, float mscale,
-                   void* stream);
+                   float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split,
+                   float mscale, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K10  FocalLoss (reference loss.py:14-34) as one launch each way:

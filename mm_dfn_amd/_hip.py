@@ -22,15 +22,15 @@ SIGNATURES = {
     "mmdfn_tile_outer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_adj_build": [_P] * 8 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
     "mmdfn_adj_build_bwd": [_P] * 15 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
-    "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P],
+    "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P],
     "mmdfn_lstm_pointwise_fwd": [_P, _P, _P, _P, _L, _I, _P],
     "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_gcnii_combine_bwd": [_P, _P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
     "mmdfn_gcn_input_fwd": [_P] * 8 + [_I] * 4 + [_F, _P],
     "mmdfn_gcn_input_bwd": [_P] * 9 + [_I] * 4 + [_F, _P],
-    "mmdfn_lstm_gate_fwd": [_P] * 9 + [_I] * 2 + [_P],
+    "mmdfn_lstm_gate_fwd": [_P] * 10 + [_I] * 2 + [_P],
     "mmdfn_lstm_gate_bwd": [_P] * 13 + [_I] * 4 + [_P],
     "mmdfn_gcnii_layer_fwd": [_P] * 7 + [_F, _F, _I, _I, _I, _F, _P],
     "mmdfn_gcnii_layer_bwd": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _P],
@@ -42,19 +42,19 @@ SIGNATURES = {
     "mmdfn_gemm_tn_grouped": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_gemm_tn_batch_workspace": [_I, _P, _P, _I, _P, _P],
     "mmdfn_gemm_tn_batch": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "mmdfn_head_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
+    "mmdfn_head_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P],
     "mmdfn_head_bwd_workspace": [_I, _I],
-    "mmdfn_head_bwd": [_P] * 9 + [_L, _I, _I, _I, _I, _F, _P],
+    "mmdfn_head_bwd": [_P] * 9 + [_L, _I, _I, _I, _I, _I, _F, _P],
     "mmdfn_focal_loss_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "mmdfn_focal_loss_bwd": [_P, _P, _P, _P, _L, _I, _P],
     "mmdfn_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "mmdfn_party_gather": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_party_combine": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HipLibraryError(RuntimeError):
@@ -128,7 +128,7 @@ def require_cuda(*tensors):
 
 def ptr_array(tensors):
     """Host array of device pointers (one per group) for the grouped entry points."""
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
 def int_array(values):

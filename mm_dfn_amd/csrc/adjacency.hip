@@ -11,7 +11,7 @@
 //             scale_tiles -> T[p,q] = S[p,q] * r_p * r_q
 //   backward: symmetrize  -> W = dT + dT^T
 //             bwd_rowsum  -> d(degree)
-//             bwd_etile   -> E = (W r_p r_q + dd_p + dd_q) * sim'(G)   (+ cross)
+//             bwd_etile   -> E = (W r_p r_q + dd_p + dd_q) * sim'(G)   (+ the cross diagonals, same launch)
 //             propagate   -> d(unit) = E . unit                         (propagate.hip)
 //             unit_bwd    -> dX = (du - u (u.du)) / ||x||
 #include "mmdfn_internal.h"
@@ -160,12 +160,28 @@ __global__ __launch_bounds__(256) void bwd_rowsum_kernel(const float* __restrict
     }
 }
 
-// E[p,q] = (W[p,q] r_p r_q + dd_p + dd_q) * sim'(G[p,q])   -- one wave per tile row
+// E[p,q] = (W[p,q] r_p r_q + dd_p + dd_q) * sim'(G[p,q])   -- one wave per tile row; the blocks behind the tile rows
+// (blockIdx.x >= tile_blocks, y = 0) do the cross diagonals: ecross[k][r] = (dcross r_m r_n + dd_m + dd_n) * w * sim'(cdot)
 __global__ __launch_bounds__(256) void bwd_etile_kernel(const float* __restrict__ W, const float* __restrict__ cosg,
                                                         const float* __restrict__ rdeg, const float* __restrict__ ddeg,
-                                                        float* __restrict__ E, const int32_t* __restrict__ dia_len,
+                                                        float* __restrict__ E, const float* __restrict__ dcross,
+                                                        const float* __restrict__ cdot, float* __restrict__ ecross,
+                                                        const int32_t* __restrict__ dia_len,
                                                         const int32_t* __restrict__ row_start,
-                                                        const int64_t* __restrict__ tile_base, int N, int max_len) {
+                                                        const int64_t* __restrict__ tile_base, int M, int N, int max_len,
+                                                        int tile_blocks, float modal_weight) {
+    if ((int)blockIdx.x >= tile_blocks) {
+        const int row = ((int)blockIdx.x - tile_blocks) * 256 + threadIdx.x;
+        if (blockIdx.y != 0 || row >= N) return;
+        for (int m = 0; m < M; ++m)
+            for (int n = m + 1; n < M; ++n) {
+                const int64_t o = (int64_t)mmdfn_pair_index(m, n, M) * N + row;
+                const float rm = rdeg[(int64_t)m * N + row], rn = rdeg[(int64_t)n * N + row];
+                ecross[o] = (dcross[o] * rm * rn + ddeg[(int64_t)m * N + row] + ddeg[(int64_t)n * N + row]) *
+                            modal_weight * mmdfn_dsim(cdot[o]);
+            }
+        return;
+    }
     const int i = blockIdx.x / ((max_len + 3) / 4);
     const int p = (blockIdx.x % ((max_len + 3) / 4)) * 4 + (threadIdx.x >> 6);
     const int m = blockIdx.y;
@@ -183,21 +199,6 @@ __global__ __launch_bounds__(256) void bwd_etile_kernel(const float* __restrict_
         if (q < L) e = (W[off + q] * rp * r[q] + ddp + dd[q]) * mmdfn_dsim(cosg[off + q]);
         E[off + q] = e;
     }
-}
-
-// ecross[k][r] = (dcross r_m r_n + dd_m + dd_n) * w * sim'(cdot)
-__global__ void bwd_ecross_kernel(const float* __restrict__ dcross, const float* __restrict__ cdot,
-                                  const float* __restrict__ rdeg, const float* __restrict__ ddeg,
-                                  float* __restrict__ ecross, int M, int N, float modal_weight) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= N) return;
-    for (int m = 0; m < M; ++m)
-        for (int n = m + 1; n < M; ++n) {
-            const int64_t o = (int64_t)mmdfn_pair_index(m, n, M) * N + row;
-            const float rm = rdeg[(int64_t)m * N + row], rn = rdeg[(int64_t)n * N + row];
-            ecross[o] = (dcross[o] * rm * rn + ddeg[(int64_t)m * N + row] + ddeg[(int64_t)n * N + row]) *
-                        modal_weight * mmdfn_dsim(cdot[o]);
-        }
 }
 
 // dX = (du - u (u.du)) / ||x||   -- one wave per (m, row)
@@ -255,11 +256,9 @@ extern "C" int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross, con
     hipLaunchKernelGGL(bwd_rowsum_kernel, dim3(B * rowblocks, M), dim3(256), 0, s, wsym, cosg, rdeg, dcross, cdot,
                        ddeg, dia_len, row_start, tile_base, M, N, max_len, modal_weight);
     MMDFN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bwd_etile_kernel, dim3(B * rowblocks, M), dim3(256), 0, s, wsym, cosg, rdeg, ddeg, etile,
-                       dia_len, row_start, tile_base, N, max_len);
-    MMDFN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bwd_ecross_kernel, dim3((N + 255) / 256), dim3(256), 0, s, dcross, cdot, rdeg, ddeg, ecross, M,
-                       N, modal_weight);
+    hipLaunchKernelGGL(bwd_etile_kernel, dim3(B * rowblocks + (N + 255) / 256, M), dim3(256), 0, s, wsym, cosg, rdeg, ddeg,
+                       etile, dcross, cdot, ecross, dia_len, row_start, tile_base, M, N, max_len, B * rowblocks,
+                       modal_weight);
     MMDFN_CHECK_LAUNCH();
     int rc = mmdfn_launch_propagate(etile, ecross, unit, dunit, dia_len, row_start, tile_base, B, M, N, D, D, D, max_len,
                                     0, s);

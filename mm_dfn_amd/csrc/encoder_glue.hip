@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const floa
     }
 }
 
-// dX_m[t,b,:] = sum_p [rank[t,b,p] >= 0] dS[rank, (m,b,p), :]
+// dX_m[t,b,:] = addend_m[t,b,:] + sum_p [rank[t,b,p] >= 0] dS[rank, (m,b,p), :]
 __global__ void party_gather_bwd_kernel(const float* __restrict__ dS, const int32_t* __restrict__ rank, ModPtrsW dX,
-                                        int L, int B, int P, int Mn, int H) {
+                                        ModPtrs addend, int L, int B, int P, int Mn, int H) {
     const int H4 = H / 4;
     const int64_t total = (int64_t)Mn * L * B * H4;
     const int64_t cols = (int64_t)Mn * B * P;
@@ -89,6 +89,9 @@ __global__ void party_gather_bwd_kernel(const float* __restrict__ dS, const int3
         const int t = (int)(r % L);
         const int m = (int)(r / L);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the gradient that reaches X_m on its other path (X_m is also the base of the combine stage): added here
+        // instead of by an autograd accumulation launch
+        if (addend.p[m]) acc = *reinterpret_cast<const float4*>(addend.p[m] + ((int64_t)t * B + b) * H + 4 * c4);
         for (int p = 0; p < P; ++p) {
             const int k = rank[((int64_t)t * B + b) * P + p];
             if (k >= 0) {
@@ -196,13 +199,17 @@ extern "C" int mmdfn_party_gather(int Mn, const float* const* X, const float* qm
     return 0;
 }
 
-extern "C" int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX, int L, int B,
-                                      int P, int H, void* stream) {
+extern "C" int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX,
+                                      const float* const* addend, int L, int B, int P, int H, void* stream) {
     if (Mn <= 0 || Mn > MAXMOD || L <= 0 || B <= 0 || P <= 0 || H <= 0 || (H & 3)) return -1;
     ModPtrsW x;
-    for (int m = 0; m < MAXMOD; ++m) x.p[m] = m < Mn ? dX[m] : nullptr;
+    ModPtrs a;
+    for (int m = 0; m < MAXMOD; ++m) {
+        x.p[m] = m < Mn ? dX[m] : nullptr;
+        a.p[m] = (addend && m < Mn) ? addend[m] : nullptr;
+    }
     hipLaunchKernelGGL(party_gather_bwd_kernel, dim3(grid_for((int64_t)Mn * L * B * (H / 4))), dim3(256), 0,
-                       (hipStream_t)stream, dS, rank, x, L, B, P, Mn, H);
+                       (hipStream_t)stream, dS, rank, x, a, L, B, P, Mn, H);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

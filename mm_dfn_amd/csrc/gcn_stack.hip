@@ -529,7 +529,7 @@ constexpr int UB = 32;   // hidden units per column block
 
 __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restrict__ q, const float* __restrict__ h,
                                                             const float* __restrict__ c, const float* __restrict__ Wih,
-                                                            const float* __restrict__ Whh, const float* __restrict__ bsum,
+                                                            const float* __restrict__ Whh, const float* __restrict__ bsum, const float* __restrict__ bsum2,
                                                             float* __restrict__ gates, float* __restrict__ h_out,
                                                             float* __restrict__ c_out, int R, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -605,6 +605,11 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
     if (ethread) {
         bi = *reinterpret_cast<const float2*>(bsum + u0 + eu); bf = *reinterpret_cast<const float2*>(bsum + H + u0 + eu);
         bg = *reinterpret_cast<const float2*>(bsum + 2 * H + u0 + eu); bo = *reinterpret_cast<const float2*>(bsum + 3 * H + u0 + eu);
+        if (bsum2) {                                   // b_ih + b_hh formed here: no separate add launch per forward
+            const float2 ci = *reinterpret_cast<const float2*>(bsum2 + u0 + eu), cf = *reinterpret_cast<const float2*>(bsum2 + H + u0 + eu);
+            const float2 cg = *reinterpret_cast<const float2*>(bsum2 + 2 * H + u0 + eu), co = *reinterpret_cast<const float2*>(bsum2 + 3 * H + u0 + eu);
+            bi.x += ci.x; bi.y += ci.y; bf.x += cf.x; bf.y += cf.y; bg.x += cg.x; bg.y += cg.y; bo.x += co.x; bo.y += co.y;
+        }
     }
     __syncthreads();
     int buf = 0;
@@ -811,12 +816,13 @@ extern "C" int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const fl
 }
 
 extern "C" int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
-                                   const float* bsum, float* gates, float* h_out, float* c_out, int R, int H, void* stream) {
+                                   const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                                   void* stream) {
     if (bad_dims(R, H) || (h == nullptr) != (c == nullptr)) return -1;
     const int ncb = (H + UB - 1) / UB;
     const size_t lds = ((size_t)(4 * UB + 2 * RB) * lds_stride(h ? 2 * H : H) + 4 * RB * (UB + 4)) * sizeof(float);
-    LAUNCH_BIG_LDS(lstm_gate_fwd_kernel, dim3(row_groups(R, ncb), ncb), lds, stream, q, h, c, Wih, Whh, bsum, gates, h_out,
-                   c_out, R, H);
+    LAUNCH_BIG_LDS(lstm_gate_fwd_kernel, dim3(row_groups(R, ncb), ncb), lds, stream, q, h, c, Wih, Whh, bsum, bsum2, gates,
+                   h_out, c_out, R, H);
     return 0;
 }
 

@@ -20,10 +20,20 @@ constexpr int HC_MAX = 8;        // classes (IEMOCAP 6, MELD 7); wider heads sta
 constexpr int HB_COLS = 1024;    // feature columns per backward column block (4 float4 per lane)
 constexpr int HB_GROUPS = 128;   // row groups (workgroups per column block) of the backward pass
 
+// Element (row, col) of the feature matrix.  split = 0: plain rows of stride ld.  split = Wm > 0: the matrix is the
+// column-wise concatenation of W / Wm blocks that live one after the other as (N, Wm) matrices of row stride ld -- the
+// (M, N, Wm) output of the graph stack read as cat([F[0], F[1], ...], -1) (model_mm.py:113-117) without the copy.
+// Wm is a multiple of 4, so a 16-byte chunk never straddles two blocks.
+__device__ __forceinline__ int64_t feat_off(int64_t row, int col, int ld, int split, int64_t N) {
+    if (split <= 0) return row * ld + col;
+    const int blk = col / split;
+    return ((int64_t)blk * N + row) * ld + (col - blk * split);
+}
+
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ Fm, const float* __restrict__ mask,
                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        float* __restrict__ logp, int64_t N, int W, int C, int ldf,
-                                                       float mscale) {
+                                                       int split, float mscale) {
     extern __shared__ __attribute__((aligned(16))) float sW[];       // [C][W]
     {   // batches of 8 independent 16-byte loads per thread (one load in flight per thread would pay the latency 6x)
         const int total = C * W / 4;
@@ -45,7 +55,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 0; c < HC_MAX; ++c) acc[c] = 0.f;
         for (int j = lane; j < W4; j += 64) {
-            float4 z = *reinterpret_cast<const float4*>(Fm + row * ldf + 4 * j);
+            float4 z = *reinterpret_cast<const float4*>(Fm + feat_off(row, 4 * j, ldf, split, N));
             if (mask) {
                 const float4 m = *reinterpret_cast<const float4*>(mask + row * W + 4 * j);
                 z.x *= m.x * mscale; z.y *= m.y * mscale; z.z *= m.z * mscale; z.w *= m.w * mscale;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ Fm, const float* __restrict__ mask,
                                                        const float* __restrict__ Wt, float* __restrict__ dF,
                                                        float* __restrict__ part, float* __restrict__ bpart, int64_t N, int W,
-                                                       int C, int ldf, int lddf, float mscale) {
+                                                       int C, int ldf, int lddf, int split, float mscale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [C][cols] weight block, later the wave partials
     const int col0 = blockIdx.y * HB_COLS;
     const int cols = min(HB_COLS, W - col0);
@@ -134,8 +144,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         for (int s = 0; s < HB_COLS / 256; ++s) {
             const int j = lane + 64 * s;
             if (j >= cols4) continue;
-            const int64_t o = row * ldf + col0 + 4 * j;
-            float4 z = *reinterpret_cast<const float4*>(Fm + o);
+            float4 z = *reinterpret_cast<const float4*>(Fm + feat_off(row, col0 + 4 * j, ldf, split, N));
             float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
             if (mask) {
                 m = *reinterpret_cast<const float4*>(mask + row * W + col0 + 4 * j);
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             }
             d.x = z.x > 0.f ? d.x * m.x : 0.f; d.y = z.y > 0.f ? d.y * m.y : 0.f;
             d.z = z.z > 0.f ? d.z * m.z : 0.f; d.w = z.w > 0.f ? d.w * m.w : 0.f;
-            *reinterpret_cast<float4*>(dF + row * lddf + col0 + 4 * j) = d;
+            *reinterpret_cast<float4*>(dF + feat_off(row, col0 + 4 * j, lddf, split, N)) = d;
         }
     }
     // waves -> LDS -> one slab per workgroup (fixed order)
@@ -218,14 +227,19 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
 
 }  // namespace
 
+static bool bad_split(int Wd, int ld, int split) {
+    if (split == 0) return ld < Wd || (ld & 3);
+    return split < 4 || (split & 3) || Wd % split || ld < split || (ld & 3);
+}
+
 extern "C" int mmdfn_head_fwd(const float* F, const float* mask, const float* W, const float* bias, float* logp, int64_t N,
-                              int Wd, int C, int ldf, float mscale, void* stream) {
-    if (N <= 0 || Wd < 4 || (Wd & 3) || C < 1 || C > HC_MAX || ldf < Wd || (ldf & 3) || (int64_t)C * Wd * 4 > 150 * 1024) return -1;
+                              int Wd, int C, int ldf, int split, float mscale, void* stream) {
+    if (N <= 0 || Wd < 4 || (Wd & 3) || C < 1 || C > HC_MAX || bad_split(Wd, ldf, split) || (int64_t)C * Wd * 4 > 150 * 1024) return -1;
     int64_t grid = (N + 3) / 4;
     if (grid > 1024) grid = 1024;
     if (int e = mmdfn_allow_big_lds(head_fwd_kernel)) return e;
     hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)grid), dim3(256), (size_t)C * Wd * sizeof(float), (hipStream_t)stream, F, mask,
-                       W, bias, logp, N, Wd, C, ldf, mscale);
+                       W, bias, logp, N, Wd, C, ldf, split, mscale);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -233,9 +247,9 @@ extern "C" int mmdfn_head_fwd(const float* F, const float* mask, const float* W,
 extern "C" int64_t mmdfn_head_bwd_workspace(int Wd, int C) { return (int64_t)HB_GROUPS * ((int64_t)C * Wd + C); }
 
 extern "C" int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
-                              float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, float mscale,
-                              void* stream) {
-    if (N <= 0 || Wd < 4 || (Wd & 3) || C < 1 || C > HC_MAX || ldf < Wd || (ldf & 3) || lddf < Wd || (lddf & 3)) return -1;
+                              float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split,
+                              float mscale, void* stream) {
+    if (N <= 0 || Wd < 4 || (Wd & 3) || C < 1 || C > HC_MAX || bad_split(Wd, ldf, split) || bad_split(Wd, lddf, split)) return -1;
     hipStream_t s = (hipStream_t)stream;
     float* part = workspace;
     float* bpart = workspace + (int64_t)HB_GROUPS * C * Wd;
@@ -244,7 +258,7 @@ extern "C" int mmdfn_head_bwd(const float* dlogp, const float* logp, const float
     if (lds > 150 * 1024) return -1;
     if (int e = mmdfn_allow_big_lds(head_bwd_kernel)) return e;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(HB_GROUPS, nblk), dim3(256), lds, s, dlogp, logp, F, mask, W, dF, part, bpart, N, Wd, C,
-                       ldf, lddf, mscale);
+                       ldf, lddf, split, mscale);
     MMDFN_CHECK_LAUNCH();
     const int total = (C * Wd + C) * 8;               // 8 lanes per output element
     hipLaunchKernelGGL(head_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, bpart, dW, db, HB_GROUPS, C * Wd, C);

@@ -184,8 +184,12 @@ class DialogueGNNModel(nn.Module):
                                           gi0=[None, gi_p])
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
             if act:
-                S, rank = ops.party_gather(act, qmask)
-                ctx, E = self._run_grus([Xl, S], [self.lstm_l, self.rnn_parties])
+                # the gathered modalities come back as identities (passthrough): the combine stage below reads those, so
+                # each projected modality has one consumer and its two gradient paths meet inside the gather's backward
+                S, rank, *passed = ops.party_gather(act, qmask, passthrough=True)
+                passed = iter(passed)
+                Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
+                ctx, E = self._run_grus([Xl_, S], [self.lstm_l, self.rnn_parties])
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
         ctx = self._run_grus([Xl], [self.lstm_l])[0]
         rank = torch.full((L, B, qmask.shape[2]), -1, dtype=torch.int32, device=Xa.device)
@@ -193,6 +197,11 @@ class DialogueGNNModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, U, qmask, umask, seq_lengths, U_a=None, U_v=None, test_label=False):
+        # one pool of dropout keep flags per forward: every dropout site of the step shares one generator launch
+        with ops.flag_pool((U.shape[0], tuple(int(x) for x in seq_lengths))):
+            return self._forward(U, qmask, umask, seq_lengths, U_a, U_v, test_label)
+
+    def _forward(self, U, qmask, umask, seq_lengths, U_a, U_v, test_label):
         if U_a is None or U_v is None:
             raise ValueError("the trimodal GDF path needs U_a and U_v")
         feats = self.encode(U, qmask, seq_lengths, U_a, U_v)
@@ -205,10 +214,13 @@ class DialogueGNNModel(nn.Module):
             fused = (self.gatedatt(ea, ev, el, self.modals) if self.att_type == 'gated'
                      else torch.cat([ea, ev, el], dim=-1))
             return ops.head(fused, self.smax_fc.weight, self.smax_fc.bias, self.dropout_.p, self.training), None, None, None, None
+        # without the memory-fusion stage the head reads the (M, N, 300) graph output in place (stacked_out): the
+        # cat([a, v, l], -1) of model_mm.py:113-117 and its backward are never materialised
+        stacked = self.att_type != 'mfn'
         if self.use_speaker or self.use_modal:
-            fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label)
+            fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label, stacked)
         else:
-            fused = self.graph_model.forward_stacked(feats, seq_lengths, qmask, test_label)
+            fused = self.graph_model.forward_stacked(feats, seq_lengths, qmask, test_label, stacked)
         if self.att_type == 'mfn':
             # re-pad (N, 900) -> (L, B, 900), memory fusion over time, strip again (model.py:1303-1326)
             L, B = U.shape[0], U.shape[1]

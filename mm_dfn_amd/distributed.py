@@ -48,6 +48,27 @@ def shard_dialogues(lengths, world, rank):
     return sorted(bins[rank])
 
 
+def bucket_order(model, live):
+    """Flat-buffer order of the live parameters: model order, except that every ``weight_ih_l*_reverse`` directly follows
+    its forward twin -- the fused GRU path reads the two as one stacked (600, K) operand (gru._stacked_view), and FlatAdam
+    lays the parameters out in this order."""
+    names = {id(p): n for n, p in model.named_parameters()}
+    by_name = {names[id(p)]: p for p in live}
+    out, placed = [], set()
+    for p in live:
+        if id(p) in placed:
+            continue
+        out.append(p)
+        placed.add(id(p))
+        n = names[id(p)]
+        if ".weight_ih_l" in "." + n and not n.endswith("_reverse"):
+            twin = by_name.get(n + "_reverse")
+            if twin is not None and id(twin) not in placed:
+                out.append(twin)
+                placed.add(id(twin))
+    return out
+
+
 class GradientBucket:
     """Flat fp32 gradient bucket over the parameters that receive gradients.
 
@@ -65,7 +86,7 @@ class GradientBucket:
     def flatten(self):
         live = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
         if self.params is None:
-            self.params = live
+            self.params = bucket_order(self.model, live)
             self._ids = [id(p) for p in live]
         elif [id(p) for p in live] != self._ids:
             # the bucket layout is frozen at the first step (flat optimizer state and all-reduce offsets depend on

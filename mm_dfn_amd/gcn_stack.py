@@ -49,7 +49,6 @@ class _GcnStack(torch.autograd.Function):
         h0, cur = new(R, H), new(R, H)
         _hip.check(lib.mmdfn_gcn_input_fwd(P(x), P(mx), P(W0), P(b0), P(m0), P(xd), P(h0), P(cur), R, F, H, ldxd, mscale, st),
                    "mmdfn_gcn_input_fwd")
-        bsum = (b_ih + b_hh) if reason else None
         h = c = None
         layers = []
         for i in range(nl):
@@ -57,8 +56,8 @@ class _GcnStack(torch.autograd.Function):
             rec = dict(q=q, h_prev=h, c_prev=c)
             if reason:
                 gates, h_new, c_new = new(R, 4 * H), new(R, H), new(R, H)
-                _hip.check(lib.mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(w_ih), P(w_hh), P(bsum), P(gates), P(h_new), P(c_new),
-                                                   R, H, st), "mmdfn_lstm_gate_fwd")
+                _hip.check(lib.mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(w_ih), P(w_hh), P(b_ih), P(b_hh), P(gates), P(h_new),
+                                                   P(c_new), R, H, st), "mmdfn_lstm_gate_fwd")
                 rec.update(gates=gates, c_new=c_new)
                 h, c = h_new, c_new
                 zin = h_new

@@ -7,7 +7,6 @@ recurrence launch shared by all modules.  The nn.GRU modules only hold the param
 state_dict keys stay the reference's); their own forward (MIOpen) is never called.
 """
 import torch
-import torch.nn.functional as F
 
 from . import _hip, ops
 
@@ -17,10 +16,13 @@ H = 100
 class _GruRecurrence(torch.autograd.Function):
     """args = per group (gi, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev), flattened -> (y_0, y_1, ...).  The recurrent
     weights are the module's own parameters (no stack / cat per step): the kernels take one pointer per direction
-    and the gradients come back per parameter."""
+    and the gradients come back per parameter.  ``masks`` (one (T, rows, 2H) tensor of 0 / 1 keep flags per group, or
+    None): nn.GRU's inter-layer dropout folded into the kernels -- the outputs are then y (.) mask * mscale, written by
+    the recurrence next to its own unmasked state history, and the backward pass masks the incoming gradient as it
+    stages it (no dropout / mask-scale launches)."""
 
     @staticmethod
-    def forward(ctx, *args):
+    def forward(ctx, masks, mscale, *args):
         n = len(args) // 5
         gis = [args[5 * g].contiguous() for g in range(n)]
         whh = [args[5 * g + 1 + d].contiguous() for g in range(n) for d in range(2)]
@@ -34,14 +36,25 @@ class _GruRecurrence(torch.autograd.Function):
             gates.append(torch.empty(T, R, 2, 4, H, dtype=torch.float32, device=gi.device))
             rows.append(R)
             Ts.append(T)
+        yms = None
+        if masks is not None:
+            masks = [m.contiguous() for m in masks]
+            _hip.require_f32(*masks)
+            for m, y in zip(masks, ys):
+                if m.shape != y.shape:
+                    raise ValueError("dropout flags must have the output's shape (T, rows, 2H)")
+            yms = [torch.empty_like(y) for y in ys]
         rc = _hip.lib().mmdfn_gru_seq_fwd(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
-                                          _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
-                                          _hip.int_array(Ts), H, _hip.stream())
+                                          _hip.ptr_array(ys), _hip.ptr_array(gates),
+                                          None if masks is None else _hip.ptr_array(masks),
+                                          None if masks is None else _hip.ptr_array(yms), float(mscale),
+                                          _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
         _hip.check(rc, "mmdfn_gru_seq_fwd")
         ctx.n = n
+        ctx.masks, ctx.mscale = masks, float(mscale)
         ctx.refs = [args[5 * g + 1 + k] for g in range(n) for k in range(4)]   # the parameter objects (leaf test)
         ctx.save_for_backward(*ys, *gates, *whh)
-        return tuple(ys)
+        return tuple(ys if masks is None else yms)
 
     @staticmethod
     def backward(ctx, *dys):
@@ -55,6 +68,7 @@ class _GruRecurrence(torch.autograd.Function):
         Ts = [y.shape[0] for y in ys]
         rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
                                           _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
+                                          None if ctx.masks is None else _hip.ptr_array(ctx.masks), ctx.mscale,
                                           _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
         _hip.check(rc, "mmdfn_gru_seq_bwd")
         # recurrent-weight gradients of every group and direction join the step's weight-gradient batch:
@@ -78,7 +92,7 @@ class _GruRecurrence(torch.autograd.Function):
                     ops.gemm_tn_grouped([dict(A=A, B=B, C=dw, colsum=db, shift=shift)])
                     res.append((dw, db))
             out += [dgi[g], res[0][0], res[1][0], res[0][1], res[1][1]]
-        return tuple(out)
+        return (None, None) + tuple(out)
 
 
 def _layer_params(gru, layer):
@@ -92,6 +106,28 @@ def _layer_params(gru, layer):
     return w_ih, b_ih, hh
 
 
+def _adjacent(wf, wr):
+    return (wf.is_contiguous() and wr.is_contiguous() and wf.shape == wr.shape and wf.dtype == wr.dtype
+            and wr.data_ptr() == wf.data_ptr() + wf.numel() * wf.element_size()
+            and wf.untyped_storage().data_ptr() == wr.untyped_storage().data_ptr())
+
+
+def _stacked_view(wf, wr):
+    """[wf; wr] (2 * 3H, K) without a copy, or None.  Two leaf parameters that are not adjacent yet are moved into one
+    buffer first (``.data`` re-pointed, values kept) unless an owner of their storage forbids it (FlatAdam marks the
+    parameters it has laid out -- in an order that keeps the pairs adjacent, distributed.bucket_order) or the stream is
+    being captured."""
+    if not _adjacent(wf, wr):
+        if (not wf.is_cuda or not wf.is_leaf or not wr.is_leaf or getattr(wf, "_mmdfn_flat", False)
+                or getattr(wr, "_mmdfn_flat", False) or torch.cuda.is_current_stream_capturing()):
+            return None
+        with torch.no_grad():
+            buf = torch.cat([wf.detach().reshape(-1), wr.detach().reshape(-1)])
+            wf.data = buf[:wf.numel()].view(wf.shape)
+            wr.data = buf[wf.numel():].view(wr.shape)
+    return torch.as_strided(wf.detach(), (2 * wf.shape[0], wf.shape[1]), (wf.shape[1], 1))
+
+
 def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
     """xs[g]: (T, rows_g, 200) -> ys[g]: (T, rows_g, 200); grus[g]: the nn.GRU holding group g's weights.
     gi0[g] (optional): the first layer's gate pre-activations X W_ih^T + b_ih (T, rows_g, 600) computed by the caller
@@ -101,16 +137,20 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
         if gru.hidden_size != H or gru.num_layers != 2 or not gru.bidirectional or gru.batch_first:
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
     cur = list(xs)
-    # stacked copies [W_ih_fwd; W_ih_rev] of every (module, layer) for the input-gradient GEMMs of the backward pass:
-    # ONE multi-tensor copy launch per step (the forward contraction reads the two parameters directly)
+    # [W_ih_fwd; W_ih_rev] of every (module, layer) as ONE (600, K) operand for the input-gradient GEMMs of the backward
+    # pass.  The two parameters are kept adjacent in memory (pair_direction_weights), so this is a view; parameters some
+    # other owner has laid out differently are copied instead (one multi-tensor copy launch per step).
     wcat = None
     if torch.is_grad_enabled():
-        halves = [w for layer in range(2) for gru in grus for w in _layer_params(gru, layer)[0]]
-        with torch.no_grad():
-            wcat = torch.empty(len(halves) // 2, 2 * halves[0].shape[0], halves[0].shape[1], dtype=halves[0].dtype,
-                               device=halves[0].device)
-            torch._foreach_copy_([wcat[i // 2, (i % 2) * halves[0].shape[0]:(i % 2 + 1) * halves[0].shape[0]]
-                                  for i in range(len(halves))], halves)
+        pairs = [_layer_params(gru, layer)[0] for layer in range(2) for gru in grus]
+        wcat = [_stacked_view(wf, wr) for wf, wr in pairs]
+        if any(w is None for w in wcat):
+            halves = [w for pair in pairs for w in pair]
+            with torch.no_grad():
+                wcat = torch.empty(len(pairs), 2 * halves[0].shape[0], halves[0].shape[1], dtype=halves[0].dtype,
+                                   device=halves[0].device)
+                torch._foreach_copy_([wcat[i // 2, (i % 2) * halves[0].shape[0]:(i % 2 + 1) * halves[0].shape[0]]
+                                      for i in range(len(halves))], halves)
     for layer in range(2):
         prm = [_layer_params(gru, layer) for gru in grus]
         # hoisted input contractions (all t, both directions) of every group: one launch per group on the two
@@ -123,7 +163,12 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
         args = []
         for gi, p in zip(gis, prm):
             args += [gi] + p[2]
-        cur = list(_GruRecurrence.apply(*args))
+        masks, mscale = None, 1.0
         if layer == 0 and training and dropout > 0:
-            cur = [F.dropout(y, dropout, True) for y in cur]
+            # nn.GRU's dropout between the layers: 0 / 1 keep flags from the step's flag pool (one generator launch for
+            # every dropout site of the step), applied inside the recurrence kernels
+            masks = [ops.keep_flags(gi.shape[0] * gi.shape[1] * 2 * H, dropout, gi.device).view(gi.shape[0], gi.shape[1], 2 * H)
+                     for gi in gis]
+            mscale = 1.0 / (1.0 - dropout)
+        cur = list(_GruRecurrence.apply(masks, mscale, *args))
     return cur

@@ -51,7 +51,7 @@ class MM_GCN(nn.Module):
         feats = self._select(a, v, l, modals)
         return ops.build_adjacency(torch.stack(feats, 0), dia_len, modal_weight)
 
-    def forward(self, a, v, l, dia_len, qmask, test_label=False):
+    def forward(self, a, v, l, dia_len, qmask, test_label=False, stacked_out=False):
         if self.use_speaker and 'l' in self.modals:
             flat_q = torch.cat([qmask[:x, i, :] for i, x in enumerate(dia_len)], dim=0)
             l += self.speaker_embeddings(torch.argmax(flat_q, dim=-1))
@@ -64,19 +64,21 @@ class MM_GCN(nn.Module):
             if 'l' in self.modals:
                 l += emb[2].reshape(1, -1)
         adj = self.create_big_adj(a, v, l, dia_len, self.modals, self.modal_weight)
-        return self._graph(adj, qmask, test_label)
+        return self._graph(adj, qmask, test_label, stacked_out)
 
-    def _graph(self, adj, qmask, test_label):
+    def _graph(self, adj, qmask, test_label, stacked_out=False):
         M, N, D = adj.stacked_feats.shape
         features = self.graph_net(adj.stacked_feats.reshape(M * N, D), None, qmask, adj, test_label)
         # cat([F[:N], F[N:2N], ...], -1) (model_mm.py:117) as ONE strided copy: sliced, the backward is M zero-filled
         # (MN, 300) buffers, M slice copies and M-1 adds
+        if stacked_out and self.return_feature:
+            return features.view(M, N, -1)       # ops.head reads the M blocks in place: the concatenation never exists
         features = features.view(M, N, -1).permute(1, 0, 2).reshape(N, -1)
         if self.return_feature:
             return features
         return F.softmax(self.final_fc(features), dim=-1)
 
-    def forward_streams(self, feats, dia_len, qmask=None, test_label=False):
+    def forward_streams(self, feats, dia_len, qmask=None, test_label=False, stacked_out=False):
         """M-stream entry: ``feats`` is a list of M (N, D) node-feature matrices -- or one (M, N, D) stack -- for
         2 <= M <= 9 modality streams of the same dialogues.  The reference builds the same graph for subsets of
         'avl' only (model_mm.py:97-106, M <= 3); the block-tile kernels take any M <= 9, which is what BASELINE
@@ -87,9 +89,9 @@ class MM_GCN(nn.Module):
             raise ValueError("forward_streams expects 2..9 streams of (N, D) features")
         if self.use_speaker or self.use_modal:
             raise NotImplementedError("forward_streams: speaker / modality embeddings exist for 'avl' graphs only")
-        return self._graph(ops.build_adjacency(feats, dia_len, self.modal_weight), qmask, test_label)
+        return self._graph(ops.build_adjacency(feats, dia_len, self.modal_weight), qmask, test_label, stacked_out)
 
-    def forward_stacked(self, feats, dia_len, qmask, test_label=False):
+    def forward_stacked(self, feats, dia_len, qmask, test_label=False, stacked_out=False):
         """Same as forward(a, v, l, ...) for features that are already one (M, N, D) stack in modality order (what the
         fused encoder epilogue writes): skips the unbind / re-stack round trip and its select-backward zero fills.
         Not available with use_speaker / use_modal (they edit single modalities in place, model_mm.py:78-93)."""
@@ -97,4 +99,4 @@ class MM_GCN(nn.Module):
             raise NotImplementedError("forward_stacked: use forward(a, v, l, ...) with use_speaker / use_modal")
         if feats.dim() != 3 or feats.shape[0] != len(''.join(self.modals)) or feats.shape[0] < 2:
             raise ValueError("forward_stacked expects a (len(modals), N, D) stack")
-        return self._graph(ops.build_adjacency(feats, dia_len, self.modal_weight), qmask, test_label)
+        return self._graph(ops.build_adjacency(feats, dia_len, self.modal_weight), qmask, test_label, stacked_out)

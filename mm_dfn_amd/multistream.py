@@ -53,7 +53,8 @@ class MultiStreamGraphModel(nn.Module):
     def forward(self, U_list, qmask, umask, seq_lengths, test_label=False):
         if len(U_list) != len(self.linears):
             raise ValueError("expected %d streams, got %d" % (len(self.linears), len(U_list)))
-        feats = self.project(U_list, seq_lengths)
-        fused = self.graph_model.forward_streams(feats, seq_lengths, qmask, test_label)
-        log_prob = ops.head(fused, self.smax_fc.weight, self.smax_fc.bias, self.dropout_.p, self.training)
+        with ops.flag_pool((U_list[0].shape[0], tuple(int(x) for x in seq_lengths))):
+            feats = self.project(U_list, seq_lengths)
+            fused = self.graph_model.forward_streams(feats, seq_lengths, qmask, test_label, stacked_out=True)
+            log_prob = ops.head(fused, self.smax_fc.weight, self.smax_fc.bias, self.dropout_.p, self.training)
         return log_prob, None, None, None, None

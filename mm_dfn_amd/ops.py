@@ -256,10 +256,13 @@ def gcnii_combine(P, S2, q, mask, theta, alpha):
 
 class _PartyGather(torch.autograd.Function):
     """(X_0..X_{Mn-1} each (L,B,H) -- or ONE stacked (Mn,L,B,H) tensor --, qmask[, bias]) -> S (L, Mn*B*P, H) (+ bias on
-    every row); also returns rank (L,B,P) int32 (no grad)."""
+    every row); also returns rank (L,B,P) int32 (no grad).  With ``passthrough`` the inputs come back as extra outputs
+    (identities): a caller that also needs X_m elsewhere (the combine stage adds the party encoding onto it) uses the
+    returned alias, so X_m has ONE consumer and its two gradient contributions meet inside the backward kernel instead of
+    in an autograd accumulation launch per modality."""
 
     @staticmethod
-    def forward(ctx, qmask, bias, *Xs):
+    def forward(ctx, qmask, bias, passthrough, *Xs):
         _hip.require_cuda(qmask, *Xs)
         stacked = len(Xs) == 1 and Xs[0].dim() == 4
         if stacked:
@@ -280,30 +283,37 @@ class _PartyGather(torch.autograd.Function):
         ctx.dims = (L, B, P, H, Mn)
         ctx.stacked = stacked
         ctx.has_bias = bias is not None
+        ctx.passthrough = bool(passthrough) and not stacked
         ctx.save_for_backward(rank)
         ctx.mark_non_differentiable(rank)
+        if ctx.passthrough:
+            return (S, rank) + tuple(Xs)
         return S, rank
 
     @staticmethod
-    def backward(ctx, dS, _drank):
+    def backward(ctx, dS, _drank, *dpass):
         (rank,) = ctx.saved_tensors
         L, B, P, H, Mn = ctx.dims
-        dS = dS.contiguous()
-        dX = torch.empty(Mn, L, B, H, dtype=torch.float32, device=dS.device)
+        dev = rank.device
+        dS = dS.contiguous() if dS is not None else torch.zeros(L, Mn * B * P, H, dtype=torch.float32, device=dev)
+        dX = torch.empty(Mn, L, B, H, dtype=torch.float32, device=dev)
+        held = [None if d is None else d.contiguous() for d in dpass]
+        addend = _hip.ptr_array(held) if any(h is not None for h in held) else None
         rc = _hip.lib().mmdfn_party_gather_bwd(Mn, _hip.ptr(dS), _hip.ptr(rank), _hip.ptr_array([dX[m] for m in range(Mn)]),
-                                               L, B, P, H, _hip.stream())
+                                               addend, L, B, P, H, _hip.stream())
         _hip.check(rc, "mmdfn_party_gather_bwd")
         dbias = dS.sum((0, 1)) if ctx.has_bias and ctx.needs_input_grad[1] else None
         if ctx.stacked:
-            return None, dbias, dX
-        return (None, dbias) + tuple(dX[m] for m in range(Mn))
+            return None, dbias, None, dX
+        return (None, dbias, None) + tuple(dX[m] for m in range(Mn))
 
 
-def party_gather(Xs, qmask, bias=None):
-    """Xs: list of (L, B, H) tensors or one stacked (Mn, L, B, H) tensor."""
+def party_gather(Xs, qmask, bias=None, passthrough=False):
+    """Xs: list of (L, B, H) tensors or one stacked (Mn, L, B, H) tensor.  passthrough (list form only): returns
+    (S, rank, X_0', .., X_{Mn-1}') with X_m' identities of the inputs (see _PartyGather)."""
     if torch.is_tensor(Xs):
-        return _PartyGather.apply(qmask, bias, Xs)
-    return _PartyGather.apply(qmask, bias, *Xs)
+        return _PartyGather.apply(qmask, bias, False, Xs)
+    return _PartyGather.apply(qmask, bias, passthrough, *Xs)
 
 
 class _PartyCombine(torch.autograd.Function):
@@ -334,9 +344,11 @@ class _PartyCombine(torch.autograd.Function):
         rank, flat_idx = ctx.saved_tensors
         L, B, P, H, Mn, N = ctx.dims
         dout = dout.contiguous()
-        dbase = torch.zeros(Mn, L, B, H, dtype=torch.float32, device=dout.device)
         nact = sum(1 for w in ctx.weights[:Mn] if w != 0.0)
-        dE = torch.zeros(L, nact * B * P, H, dtype=torch.float32, device=dout.device) if ctx.has_E else None
+        nb, ne = Mn * L * B * H, (L * nact * B * P * H if ctx.has_E else 0)
+        zero = torch.zeros(nb + ne, dtype=torch.float32, device=dout.device)       # one fill for both (pad rows stay 0)
+        dbase = zero[:nb].view(Mn, L, B, H)
+        dE = zero[nb:].view(L, nact * B * P, H) if ctx.has_E else None
         rc = _hip.lib().mmdfn_party_combine_bwd(Mn, _hip.ptr(dout), _hip.ptr(rank), _hip.ptr(flat_idx),
                                                 _hip.ptr_array([dbase[m] for m in range(Mn)]), _hip.ptr(dE),
                                                 _hip.float_array(ctx.weights), L, B, P, N, H, _hip.stream())
@@ -824,59 +836,130 @@ def linear2(x, w1, w2, b1, b2, wcat=None):
     return _Linear2.apply(x, w1, w2, b1, b2, wcat)
 
 
+# ---- dropout keep flags: one generator launch per step -----------------------------------------------------------------
+# Every dropout site of the fused path (GRU inter-layer dropout, the GCN stack, the head) consumes 0 / 1 keep flags that
+# its kernel scales by 1/(1-p).  Inside a ``flag_pool()`` scope (the models open one per forward) the sites share one
+# buffer per (device, p) drawn by ONE bernoulli_ launch: the first request of a step draws as many flags as the previous
+# step with the same scope key used, later requests take slices (a request that does not fit draws its own buffer).
+# A fresh tensor per draw: slices saved for backward are never overwritten.  Outside a scope every request draws its own.
+_FLAG_SCOPE = None
+_FLAG_HINT = {}
+
+
+class flag_pool:
+    def __init__(self, key=None):
+        self.key = key
+        self.bufs = {}       # (device, p) -> [buffer, offset, used]
+
+    def __enter__(self):
+        global _FLAG_SCOPE
+        self.outer = _FLAG_SCOPE
+        if self.outer is None:
+            _FLAG_SCOPE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _FLAG_SCOPE
+        if self.outer is None:
+            _FLAG_SCOPE = None
+            for k, (_, _, used) in self.bufs.items():
+                if len(_FLAG_HINT) > 256:
+                    _FLAG_HINT.clear()
+                _FLAG_HINT[(self.key,) + k] = used
+        return False
+
+
+def keep_flags(n, p, device):
+    """n fp32 keep flags (1 with probability 1 - p), 16-byte aligned."""
+    n = int(n)
+    scope = _FLAG_SCOPE
+    if scope is None:
+        return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(1.0 - p)
+    k = (device, float(p))
+    ent = scope.bufs.get(k)
+    if ent is None:
+        ent = scope.bufs[k] = [None, 0, 0]
+    n4 = (n + 3) & ~3
+    if ent[0] is None or ent[1] + n4 > ent[0].numel():
+        want = max(n4, _FLAG_HINT.get((scope.key,) + k, 0) - ent[2])
+        ent[0] = torch.empty(want, dtype=torch.float32, device=device).bernoulli_(1.0 - p)
+        ent[1] = 0
+    out = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n4
+    ent[2] += n4
+    return out
+
+
 class _Head(torch.autograd.Function):
     """log_softmax(relu(F (.) mask * mscale) W^T + b): the classifier head of model.py:1328-1337 as one launch each way
-    (csrc/head.hip); mask = 0 / 1 keep flags of the head dropout or None."""
+    (csrc/head.hip); mask = 0 / 1 keep flags of the head dropout or None.  ``Fm``: (N, W), or the (M, N, Wm) output of
+    the graph stack standing for cat([Fm[0], .., Fm[M-1]], -1) (model_mm.py:113-117): the kernels read the blocks in
+    place and write dF in the same layout, so neither the concatenation nor its backward exists."""
 
     @staticmethod
     def forward(ctx, Fm, mask, mscale, weight, bias):
         _hip.require_cuda(Fm, weight)
         _hip.require_f32(Fm, mask, weight, bias)
-        if Fm.stride(1) != 1 or Fm.stride(0) % 4 or Fm.data_ptr() % 16:
+        if Fm.dim() == 3:
             Fm = Fm.contiguous()
-        N, Wd = Fm.shape
+            N, split = Fm.shape[1], Fm.shape[2]
+            Wd, ldf = Fm.shape[0] * split, split
+        else:
+            if Fm.stride(1) != 1 or Fm.stride(0) % 4 or Fm.data_ptr() % 16:
+                Fm = Fm.contiguous()
+            (N, Wd), split, ldf = Fm.shape, 0, Fm.stride(0)
         C = weight.shape[0]
         weight, bias = weight.contiguous(), bias.contiguous()
         mask = mask.contiguous() if mask is not None else None
         logp = torch.empty(N, C, dtype=torch.float32, device=Fm.device)
         rc = _hip.lib().mmdfn_head_fwd(_hip.ptr(Fm), _hip.ptr(mask), _hip.ptr(weight), _hip.ptr(bias), _hip.ptr(logp), N, Wd, C,
-                                       Fm.stride(0), float(mscale), _hip.stream())
+                                       ldf, split, float(mscale), _hip.stream())
         _hip.check(rc, "mmdfn_head_fwd")
         ctx.mscale = float(mscale)
+        ctx.dims = (N, Wd, split, ldf)
         ctx.save_for_backward(Fm, mask, weight, logp)
         return logp
 
     @staticmethod
     def backward(ctx, dlogp):
         Fm, mask, weight, logp = ctx.saved_tensors
-        N, Wd = Fm.shape
+        N, Wd, split, ldf = ctx.dims
         C = weight.shape[0]
         dlogp = dlogp.contiguous()
         lib = _hip.lib()
-        dF = torch.empty(N, Wd, dtype=torch.float32, device=Fm.device)
+        dF = torch.empty(Fm.shape, dtype=torch.float32, device=Fm.device)
         dW = torch.empty(C, Wd, dtype=torch.float32, device=Fm.device)
         db = torch.empty(C, dtype=torch.float32, device=Fm.device)
         ws = torch.empty(int(lib.mmdfn_head_bwd_workspace(Wd, C)), dtype=torch.float32, device=Fm.device)
         rc = lib.mmdfn_head_bwd(_hip.ptr(dlogp), _hip.ptr(logp), _hip.ptr(Fm), _hip.ptr(mask), _hip.ptr(weight), _hip.ptr(dF),
-                                _hip.ptr(dW), _hip.ptr(db), _hip.ptr(ws), N, Wd, C, Fm.stride(0), Wd, ctx.mscale, _hip.stream())
+                                _hip.ptr(dW), _hip.ptr(db), _hip.ptr(ws), N, Wd, C, ldf, split if split else Wd, split,
+                                ctx.mscale, _hip.stream())
         _hip.check(rc, "mmdfn_head_bwd")
         return dF, None, None, dW, db
 
 
+def _head_width(Fm):
+    return Fm.shape[0] * Fm.shape[2] if Fm.dim() == 3 else Fm.shape[1]
+
+
 def head_supported(Fm, weight):
-    return (Fm.is_cuda and Fm.dtype == torch.float32 and Fm.dim() == 2 and weight.shape[0] <= 8 and Fm.shape[1] % 4 == 0
-            and weight.shape[0] * Fm.shape[1] * 4 <= 150 * 1024)
+    return (Fm.is_cuda and Fm.dtype == torch.float32 and Fm.dim() in (2, 3) and weight.shape[0] <= 8 and Fm.shape[-1] % 4 == 0
+            and weight.shape[0] * _head_width(Fm) * 4 <= 150 * 1024)
 
 
 def head(Fm, weight, bias, p=0.0, training=False):
-    """log_softmax(Linear(relu(dropout(Fm)))) (reference model.py:1328-1337).  Wide heads (> 8 classes) take the library
-    composition."""
+    """log_softmax(Linear(relu(dropout(Fm)))) (reference model.py:1328-1337).  ``Fm``: the fused features (N, W), or
+    the stacked graph output (M, N, Wm) standing for its column-wise concatenation (N, M Wm).  Wide heads (> 8 classes)
+    take the library composition."""
     if not head_supported(Fm, weight) or bias is None:
+        if Fm.dim() == 3:
+            Fm = Fm.permute(1, 0, 2).reshape(Fm.shape[1], -1)
         z = torch.relu(torch.nn.functional.dropout(Fm, p, training))
         return torch.log_softmax(linear(z, weight, bias), 1)
     mask, mscale = None, 1.0
     if training and p > 0:
-        mask = torch.empty(Fm.shape, dtype=torch.float32, device=Fm.device).bernoulli_(1.0 - p)
+        N = Fm.shape[1] if Fm.dim() == 3 else Fm.shape[0]
+        mask = keep_flags(N * _head_width(Fm), p, Fm.device).view(N, _head_width(Fm))
         mscale = 1.0 / (1.0 - p)
     return _Head.apply(Fm, mask, mscale, weight, bias)
 

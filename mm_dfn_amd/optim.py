@@ -33,6 +33,7 @@ class FlatAdam:
         for p in params:
             n = p.numel()
             p.data = flat[off:off + n].view_as(p)
+            p._mmdfn_flat = True       # this storage layout is owned here: nobody may re-point the parameter
             off += n
         self.flat_p = flat
         self.m = torch.zeros_like(flat)

@@ -39,6 +39,20 @@ def flatten_labels(label, lengths):
     return label[keep]
 
 
+_UNIT_SEED = {}
+
+
+def backward(loss):
+    """``loss.backward()`` seeded with a cached scalar 1 (autograd otherwise allocates and fills a fresh one: one more
+    launch per step)."""
+    one = _UNIT_SEED.get(loss.device)
+    if one is None or one.dtype != loss.dtype:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            return loss.backward()               # a tensor created under capture belongs to that graph's pool
+        one = _UNIT_SEED[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(one)
+
+
 class StepGraphCache:
     """Shape-keyed hipGraph cache for the pass loop: one captured step per batch signature (dialogue lengths, padded
     shape, train / eval), replayed whenever that signature comes back.
@@ -80,7 +94,7 @@ class StepGraphCache:
                 out["log_prob"] = model(textf, qmask, umask, lengths, acouf, visuf, test_label)[0]
                 loss = loss_f(out["log_prob"], flat)
                 if train_flag:
-                    loss.backward()
+                    backward(loss)
                 return loss
 
             mode = model.training
@@ -135,7 +149,7 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
             labels.append(flat)
             losses.append(loss.detach())
             if train_flag:
-                loss.backward()
+                backward(loss)
         if train_flag:
             ops.join_weight_grads()       # weight gradients may have been computed on the side stream
             if step_hook is not None:

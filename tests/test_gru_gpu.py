@@ -56,9 +56,10 @@ def test_matches_torch_gru_module_eval():
     assert abs_err(got, want) < 2e-6
 
 
+@pytest.mark.parametrize("passthrough", [False, True])
 @pytest.mark.parametrize("w", [[3.0, 0.0, 1.0], [1.0, 2.0, 0.5], [0.0, 0.0, 2.0]])
 @pytest.mark.parametrize("P,lengths", [(2, [15, 9, 1, 6]), (9, [12, 12, 3]), (3, [1]), (2, [110, 64, 80])])
-def test_party_gather_combine_kernels_match_index_composition(P, lengths, w):
+def test_party_gather_combine_kernels_match_index_composition(P, lengths, w, passthrough):
     """K3/K4 kernels vs the torch index-op composition of oracle/mmdfn_vectorised.py (itself checked against the oracle
     on CPU in tests/test_host_logic.py), forward and backward, including a non-one-hot qmask row."""
     from mm_dfn_amd import ops
@@ -87,9 +88,18 @@ def test_party_gather_combine_kernels_match_index_composition(P, lengths, w):
     Xk = [x.clone().requires_grad_(True) for x in Xs]
     # the party encoder only sees the modalities with a non-zero weight (E: one column block per such modality)
     act = [i for i in range(3) if w[i] != 0.0]
-    Sk, rank = ops.party_gather([Xk[i] for i in act], q)
+    bases = list(Xk)
+    if passthrough:
+        # the gathered modalities return as identities; the combine stage reads those, so both gradient paths of X_m
+        # meet inside the gather's backward kernel (no autograd accumulation)
+        Sk, rank, *passed = ops.party_gather([Xk[i] for i in act], q, passthrough=True)
+        for slot, i in enumerate(act):
+            assert passed[slot].data_ptr() == Xk[i].data_ptr()
+            bases[i] = passed[slot]
+    else:
+        Sk, rank = ops.party_gather([Xk[i] for i in act], q)
     Ek = torch.tanh(Sk * 0.7 + 0.1)
-    outk = ops.party_combine(Xk, Ek, rank, idx, w)
+    outk = ops.party_combine(bases, Ek, rank, idx, w)
     (outk * Wg).sum().backward()
     BP = B * P
     for slot, i in enumerate(act):
@@ -97,3 +107,99 @@ def test_party_gather_combine_kernels_match_index_composition(P, lengths, w):
     assert abs_err(outk, outr) < 1e-6
     for i in range(3):
         assert rel_err(Xk[i].grad, Xr[i].grad) < 1e-6
+
+
+@pytest.mark.parametrize("shapes", [[(9, 3)], [(110, 16), (110, 64)], [(13, 300)], [(6, 700), (11, 5)]])
+def test_inter_layer_dropout_inside_the_recurrence_kernels(shapes):
+    """nn.GRU(dropout=p) between the layers (model.py:866,868): the forward kernel writes y (.) mask * 1/(1-p) next to its
+    own unmasked history, the backward kernel masks the incoming gradient while staging it -- against the unfused
+    composition (recurrence, then torch multiply) on the same keep flags, for every rows-per-workgroup variant."""
+    rs = np.random.RandomState(17 + len(shapes) + shapes[0][1])
+    H = fused.H
+    p = 0.5
+    ms = 1.0 / (1.0 - p)
+
+    def leaves():
+        out = []
+        r2 = np.random.RandomState(3)
+        for T, R in shapes:
+            out += [torch.from_numpy(r2.randn(T, R, 6 * H).astype(np.float32)).to(DEV).requires_grad_(True)]
+            out += [torch.from_numpy((r2.randn(3 * H, H) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True) for _ in range(2)]
+            out += [torch.from_numpy((r2.randn(3 * H) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True) for _ in range(2)]
+        return out
+
+    masks = [torch.from_numpy((rs.uniform(size=(T, R, 2 * H)) > p).astype(np.float32)).to(DEV) for T, R in shapes]
+    ws = [torch.from_numpy(rs.randn(T, R, 2 * H).astype(np.float32)).to(DEV) for T, R in shapes]
+    a = leaves()
+    got = fused._GruRecurrence.apply(masks, ms, *a)
+    sum((y * w).sum() for y, w in zip(got, ws)).backward()
+    b = leaves()
+    plain = fused._GruRecurrence.apply(None, 1.0, *b)
+    want = [y * m * ms for y, m in zip(plain, masks)]
+    sum((y * w).sum() for y, w in zip(want, ws)).backward()
+    for g in range(len(shapes)):
+        assert torch.equal(got[g], want[g])
+        assert rel_err(a[5 * g].grad, b[5 * g].grad) < 1e-6          # d(gate pre-activations)
+        for k in range(1, 5):                                       # recurrent weights / biases (end-of-backward batch)
+            assert rel_err(a[5 * g + k].grad, b[5 * g + k].grad) < 1e-5, (g, k)
+
+
+def test_train_mode_dropout_through_bigru2_is_unbiased_and_reaches_the_gradients():
+    """bigru2(training=True, dropout=p): keep flags from the step's pool, no torch dropout op in the graph."""
+    from mm_dfn_amd import ops
+    g = make_gru(8).to(DEV)
+    x = torch.randn(30, 24, 200, device=DEV, requires_grad=True)
+    with ops.flag_pool("t"):
+        y_tr = fused.bigru2([x], [g], 0.5, True)[0]
+    with torch.no_grad():
+        y_ev = fused.bigru2([x.detach()], [g], 0.5, False)[0]
+    assert float((y_tr - y_ev).abs().max()) > 1e-3              # the second layer saw a dropped-out input
+    node_names = set()
+    stack = [y_tr.grad_fn]
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in node_names:
+            continue
+        node_names.add(fn)
+        stack += [f for f, _ in fn.next_functions]
+    assert not any("Dropout" in type(fn).__name__ for fn in node_names)
+    y_tr.sum().backward()
+    assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+    for p in g.parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all())
+
+
+def test_direction_weight_pairs_become_one_stacked_operand_without_a_copy():
+    """[W_ih; W_ih_reverse] for the input-gradient GEMM: the first training forward moves each pair into one buffer
+    (values kept, .data re-pointed); afterwards the stacked operand is a view -- no per-step packing launch -- and the
+    gradients equal those of the copying path (parameters an optimizer has laid out itself)."""
+    g = make_gru(9).to(DEV)
+    before = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    x = torch.randn(12, 5, 200, device=DEV, requires_grad=True)
+    w = torch.randn(12, 5, 200, device=DEV)
+    (fused.bigru2([x], [g], 0.0, True)[0] * w).sum().backward()
+    for layer in range(2):
+        wf, wr = getattr(g, "weight_ih_l%d" % layer), getattr(g, "weight_ih_l%d_reverse" % layer)
+        assert fused._adjacent(wf, wr)
+        sv = fused._stacked_view(wf, wr)
+        assert sv.data_ptr() == wf.data_ptr() and torch.equal(sv, torch.cat([wf, wr], 0))
+    for k, v in g.state_dict().items():
+        assert torch.equal(v, before[k])
+    # an in-place update (what an optimizer does) is seen through the view
+    with torch.no_grad():
+        g.weight_ih_l0_reverse.add_(1.0)
+    assert torch.equal(fused._stacked_view(g.weight_ih_l0, g.weight_ih_l0_reverse)[300:], g.weight_ih_l0_reverse)
+    with torch.no_grad():
+        g.weight_ih_l0_reverse.sub_(1.0)
+    grads = {k: p.grad.clone() for k, p in g.named_parameters()}
+    xg = x.grad.clone()
+    # copying path: parameters flagged as laid out by someone else and NOT adjacent
+    g2 = make_gru(9).to(DEV)
+    for p in g2.parameters():
+        p._mmdfn_flat = True
+    x2 = x.detach().clone().requires_grad_(True)
+    (fused.bigru2([x2], [g2], 0.0, True)[0] * w).sum().backward()
+    assert not fused._adjacent(g2.weight_ih_l0, g2.weight_ih_l0_reverse)
+    assert rel_err(x2.grad, xg) < 1e-6
+    for k, p in g2.named_parameters():
+        assert rel_err(p.grad, grads[k]) < 1e-6, k

@@ -192,3 +192,36 @@ def test_focal_loss_alpha_table_must_cover_the_classes():
     assert f.alpha.numel() == 2
     lp = torch.log_softmax(torch.randn(4, 2), 1)
     assert torch.isfinite(f(lp, torch.tensor([0, 1, 1, 0])))
+
+
+def test_flag_pool_shares_one_draw_per_step():
+    """ops.keep_flags inside a flag_pool scope: the first step draws per request, later steps with the same key draw once
+    and hand out disjoint 16-byte aligned slices; outside a scope every request is its own draw."""
+    import torch
+    from mm_dfn_amd import ops
+    dev = torch.device("cpu")
+    a = ops.keep_flags(10, 0.5, dev)
+    assert a.shape == (10,) and set(a.unique().tolist()) <= {0.0, 1.0}
+    bufs = []
+    for step in range(3):
+        with ops.flag_pool(("k", 1)):
+            x = ops.keep_flags(1001, 0.5, dev)
+            y = ops.keep_flags(64, 0.5, dev)
+            z = ops.keep_flags(7, 0.25, dev)          # another p: its own buffer
+            with ops.flag_pool("inner"):               # nested scopes join the outer one
+                u = ops.keep_flags(30, 0.5, dev)
+        same = x.untyped_storage().data_ptr() == y.untyped_storage().data_ptr() == u.untyped_storage().data_ptr()
+        assert same == (step > 0)
+        assert z.untyped_storage().data_ptr() != x.untyped_storage().data_ptr()
+        if step > 0:
+            assert y.storage_offset() == 1004 and u.storage_offset() == 1068
+            assert x.untyped_storage().nbytes() == 4 * (1004 + 64 + 32)
+        bufs.append(x)
+        assert 0.3 < float(x.mean()) < 0.7
+    assert bufs[1].untyped_storage().data_ptr() != bufs[2].untyped_storage().data_ptr()   # a fresh buffer per step
+    assert ops._FLAG_SCOPE is None
+    # a step that asks for more than the hint: the overflow request draws its own buffer
+    with ops.flag_pool(("k", 1)):
+        x = ops.keep_flags(1001, 0.5, dev)
+        big = ops.keep_flags(5000, 0.5, dev)
+    assert big.shape == (5000,) and big.untyped_storage().data_ptr() != x.untyped_storage().data_ptr()

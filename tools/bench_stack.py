@@ -19,8 +19,8 @@ dG, o3, o4, o5 = t(R, 4 * H), t(R, H), t(R, H), t(R, F)
 CASES = {
     "gcn_input_fwd": lambda: lib.mmdfn_gcn_input_fwd(P(x), P(mx), P(W0), P(b0), P(m0), P(xd), P(o1), P(o2), R, F, H, F + H, 2.0, st()),
     "gcn_input_bwd": lambda: lib.mmdfn_gcn_input_bwd(P(q), P(m0), P(h), P(h0), P(W0), P(xd), P(mx), P(o1), P(o5), R, F, H, F + H, 2.0, st()),
-    "lstm_gate_fwd": lambda: lib.mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(Wih), P(Whh), P(bsum), P(dG), P(o1), P(o2), R, H, st()),
-    "lstm_gate_fwd(first)": lambda: lib.mmdfn_lstm_gate_fwd(P(q), None, None, P(Wih), P(Whh), P(bsum), P(dG), P(o1), P(o2), R, H, st()),
+    "lstm_gate_fwd": lambda: lib.mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(Wih), P(Whh), P(bsum), None, P(dG), P(o1), P(o2), R, H, st()),
+    "lstm_gate_fwd(first)": lambda: lib.mmdfn_lstm_gate_fwd(P(q), None, None, P(Wih), P(Whh), P(bsum), None, P(dG), P(o1), P(o2), R, H, st()),
     "lstm_gate_bwd": lambda: lib.mmdfn_lstm_gate_bwd(P(gates), P(c), P(h), P(q), P(hi), P(m), P(Wih), P(Whh), P(h0), P(dG), P(o1), P(o2), P(o3), R, H, 1, H, st()),
     "gcnii_layer_fwd": lambda: lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(W), P(q), P(m), P(o1), P(gmask), 0.4, 0.2, R, H, H, 2.0, st()),
     "gcnii_layer_bwd": lambda: lib.mmdfn_gcnii_layer_bwd(P(q), P(gmask), P(W), P(o1), P(o2), P(o3), 0.4, 0.2, R, H, H, 1, st()),

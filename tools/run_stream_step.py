@@ -22,7 +22,7 @@ loss_f = FocalLoss(gamma=0.5)
 
 def fwd_bwd():
     loss = loss_f(model(b["streams"], b["qmask"], b["umask"], b["lengths"])[0], label)
-    loss.backward()
+    train.backward(loss)
     return loss
 
 
