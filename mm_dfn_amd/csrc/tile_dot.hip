@@ -105,6 +105,57 @@ __global__ __launch_bounds__(64 * NW) void tile_dot_kernel(
     }
 }
 
+// dcross_{mn}[r] (+)= X[(m,r)].Y[(n,r)] + X[(n,r)].Y[(m,r)]
+// Four rows per wave: a 16-lane group owns one row, lane j of the group holds elements j, j+16, ... of every
+// modality's X and Y row in registers (each loaded ONCE), the M(M-1)/2 pair products are formed from registers and
+// reduced over the 16 lanes with four DPP steps -- all four rows of the wave share every instruction.  (First
+// version: one row per wave, rows re-read from L1 for every pair, 15 full-wave reductions per row: 40 us at L=512,
+// M=6.)
+template <int MMAX, int KSL>
+__device__ __forceinline__ void cross_dot_block(int block, const float* __restrict__ X, const float* __restrict__ Y,
+                                                float* __restrict__ dcross, int M, int N, int K, int ldx, int ldy,
+                                                int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const int row = (block * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool rok = row < N;
+    const int rowc = rok ? row : N - 1;
+    float xv[MMAX][KSL], yv[MMAX][KSL];
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int sidx = 0; sidx < KSL; ++sidx) {
+            const int k = j + 16 * sidx;
+            const bool ok = (m < M) && (k < K);
+            xv[m][sidx] = ok ? X[((int64_t)m * N + rowc) * ldx + k] : 0.f;
+            yv[m][sidx] = ok ? Y[((int64_t)m * N + rowc) * ldy + k] : 0.f;
+        }
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m)
+#pragma unroll
+        for (int n = m + 1; n < MMAX; ++n) {
+            if (n >= M) continue;
+            float s = 0.f;
+#pragma unroll
+            for (int sidx = 0; sidx < KSL; ++sidx) s += xv[m][sidx] * yv[n][sidx] + xv[n][sidx] * yv[m][sidx];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            if (j == 0 && rok) {
+                const int64_t o = (int64_t)mmdfn_pair_index(m, n, M) * N + row;
+                dcross[o] = accumulate ? dcross[o] + s : s;
+            }
+        }
+}
+
+template <int MMAX, int KSL>
+__global__ __launch_bounds__(256) void cross_dot_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                        float* __restrict__ dcross, int M, int N, int K,
+                                                        int ldx, int ldy, int accumulate) {
+    cross_dot_block<MMAX, KSL>(blockIdx.x, X, Y, dcross, M, N, K, ldx, ldy, accumulate);
+}
+
 // ---------------------------------------------------------------------------------------------
 // v2 (K <= 208): each wave sweeps q in groups of four 16-column tiles.
 //   * B fragments of the next tile are prefetched into a second register set while the current tile's
@@ -118,11 +169,17 @@ __global__ __launch_bounds__(256) void tile_dot_v2_kernel(
     const float* __restrict__ X, const float* __restrict__ Y, float* __restrict__ out_tiles,
     float* __restrict__ out_aux, float* __restrict__ deg, const int32_t* __restrict__ dia_len,
     const int32_t* __restrict__ row_start, const int64_t* __restrict__ tile_base, int B, int M, int N, int K,
-    int ldx, int ldy, int max_rb, int accumulate) {
+    int ldx, int ldy, int max_rb, int accumulate, float* __restrict__ dcross, int tile_blocks) {
     constexpr int BM = 64;
     constexpr int LDP = 68;                       // patch row stride (floats), 16-byte aligned rows
     __shared__ __attribute__((aligned(16))) float patch[4][16 * LDP];
 
+    if (EPI == 0 && (int)blockIdx.x >= tile_blocks) {
+        // the blocks behind the tiles: the cross-modal diagonals of the same outer product (M <= 3), so that the
+        // adjacency gradient of a layer is ONE launch
+        cross_dot_block<3, KC>((int)blockIdx.x - tile_blocks, X, Y, dcross, M, N, K, ldx, ldy, accumulate);
+        return;
+    }
     const int Rd = M * max_rb;
     const int bid = blockIdx.x;
     const int yq = bid >> 3;
@@ -249,15 +306,16 @@ __global__ __launch_bounds__(256) void tile_dot_v2_kernel(
 template <int KC>
 int launch_v2(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg, const int32_t* dia_len,
               const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx, int ldy,
-              int max_len, int epi, int accumulate, hipStream_t s) {
+              int max_len, int epi, int accumulate, hipStream_t s, float* dcross) {
     const int max_rb = (max_len + 63) / 64;
-    dim3 grid(((B + 7) / 8) * 8 * M * max_rb);
+    const int tile_blocks = ((B + 7) / 8) * 8 * M * max_rb;
     if (epi == 0)
-        hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 0>), grid, dim3(256), 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
-                           row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate);
+        hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 0>), dim3(tile_blocks + (dcross ? (N + 15) / 16 : 0)), dim3(256), 0, s, X, Y,
+                           out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate,
+                           dcross, tile_blocks);
     else
-        hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 1>), grid, dim3(256), 0, s, X, Y, out_tiles, out_aux, deg, dia_len,
-                           row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate);
+        hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 1>), dim3(tile_blocks), dim3(256), 0, s, X, Y, out_tiles, out_aux, deg,
+                           dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate, nullptr, tile_blocks);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -278,50 +336,6 @@ int launch(const float* X, const float* Y, float* out_tiles, float* out_aux, flo
                            row_start, tile_base, M, N, K, ldx, ldy, max_rb, accumulate);
     MMDFN_CHECK_LAUNCH();
     return 0;
-}
-
-// dcross_{mn}[r] (+)= X[(m,r)].Y[(n,r)] + X[(n,r)].Y[(m,r)]
-// Four rows per wave: a 16-lane group owns one row, lane j of the group holds elements j, j+16, ... of every
-// modality's X and Y row in registers (each loaded ONCE), the M(M-1)/2 pair products are formed from registers and
-// reduced over the 16 lanes with four DPP steps -- all four rows of the wave share every instruction.  (First
-// version: one row per wave, rows re-read from L1 for every pair, 15 full-wave reductions per row: 40 us at L=512,
-// M=6.)
-template <int MMAX, int KSL>
-__global__ __launch_bounds__(256) void cross_dot_kernel(const float* __restrict__ X, const float* __restrict__ Y,
-                                                        float* __restrict__ dcross, int M, int N, int K,
-                                                        int ldx, int ldy, int accumulate) {
-    const int lane = threadIdx.x & 63;
-    const int j = lane & 15;
-    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const bool rok = row < N;
-    const int rowc = rok ? row : N - 1;
-    float xv[MMAX][KSL], yv[MMAX][KSL];
-#pragma unroll
-    for (int m = 0; m < MMAX; ++m)
-#pragma unroll
-        for (int sidx = 0; sidx < KSL; ++sidx) {
-            const int k = j + 16 * sidx;
-            const bool ok = (m < M) && (k < K);
-            xv[m][sidx] = ok ? X[((int64_t)m * N + rowc) * ldx + k] : 0.f;
-            yv[m][sidx] = ok ? Y[((int64_t)m * N + rowc) * ldy + k] : 0.f;
-        }
-#pragma unroll
-    for (int m = 0; m < MMAX; ++m)
-#pragma unroll
-        for (int n = m + 1; n < MMAX; ++n) {
-            if (n >= M) continue;
-            float s = 0.f;
-#pragma unroll
-            for (int sidx = 0; sidx < KSL; ++sidx) s += xv[m][sidx] * yv[n][sidx] + xv[n][sidx] * yv[m][sidx];
-            s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            s += __shfl_xor(s, 8, 64);
-            if (j == 0 && rok) {
-                const int64_t o = (int64_t)mmdfn_pair_index(m, n, M) * N + row;
-                dcross[o] = accumulate ? dcross[o] + s : s;
-            }
-        }
 }
 
 // any M (<= 9) / K: one wave per row, rows streamed per pair
@@ -349,10 +363,12 @@ __global__ __launch_bounds__(256) void cross_dot_generic_kernel(const float* __r
 
 }  // namespace
 
-int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
-                          const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                          int B, int M, int N, int K, int ldx, int ldy, int max_len, int epi, int accumulate,
-                          hipStream_t s) {
+// fused_cross (in/out, may be NULL): on entry the dcross buffer the caller would like filled by the same launch; set
+// to NULL on return when that happened (short dialogues, M <= 3: the v2 kernel), left alone otherwise.
+static int launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
+                           const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                           int B, int M, int N, int K, int ldx, int ldy, int max_len, int epi, int accumulate,
+                           hipStream_t s, float** fused_cross) {
     if (B <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 3) || max_len <= 0) return -1;
     if (ldx < K || ldy < K || (ldx & 3) || (ldy & 3)) return -1;
 #ifdef MMDFN_TUNING
@@ -375,8 +391,13 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
     constexpr const char* e = nullptr;
 #endif
     if (e == nullptr || e[0] == '0') {
-        if (K <= 112) return launch_v2<7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
-        if (K <= 208) return launch_v2<13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
+        float* dc = nullptr;
+        if (fused_cross && *fused_cross && epi == 0 && M > 1 && M <= 3 && K <= 208) {
+            dc = *fused_cross;
+            *fused_cross = nullptr;
+        }
+        if (K <= 112) return launch_v2<7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s, dc);
+        if (K <= 208) return launch_v2<13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s, dc);
     }
     if (K <= 112) return launch<4, 7>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
     if (K <= 208) return launch<4, 13>(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi, accumulate, s);
@@ -384,15 +405,23 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
     return -1;
 }
 
+int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
+                          const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
+                          int B, int M, int N, int K, int ldx, int ldy, int max_len, int epi, int accumulate,
+                          hipStream_t s) {
+    return launch_tile_dot(X, Y, out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_len, epi,
+                           accumulate, s, nullptr);
+}
+
 extern "C" int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, float* dcross,
                                 const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                                 int B, int M, int N, int d, int ldx, int ldy, int max_len, int accumulate,
                                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    int rc = mmdfn_launch_tile_dot(X, Y, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, d, ldx, ldy,
-                                   max_len, 0, accumulate, s);
+    int rc = launch_tile_dot(X, Y, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, d, ldx, ldy, max_len, 0,
+                             accumulate, s, &dcross);
     if (rc) return rc;
-    if (M > 1 && dcross) {
+    if (M > 1 && dcross) {              // (NULL by now if the tile launch took the cross diagonals along)
 #define CROSS_DOT(MM, KS) \
     hipLaunchKernelGGL((cross_dot_kernel<MM, KS>), dim3((N + 15) / 16), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy, accumulate)
         if (M <= 3 && d <= 112) CROSS_DOT(3, 7);

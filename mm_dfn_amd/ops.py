@@ -286,6 +286,7 @@ class _PartyGather(torch.autograd.Function):
         ctx.passthrough = bool(passthrough) and not stacked
         ctx.save_for_backward(rank)
         ctx.mark_non_differentiable(rank)
+        ctx.set_materialize_grads(False)       # no zero-filled stand-ins for the integer output / unused identities
         if ctx.passthrough:
             return (S, rank) + tuple(Xs)
         return S, rank

@@ -20,6 +20,12 @@ shapes = [("party gi", 10560, 200, 600), ("text gi", 1760, 200, 600), ("party dX
           ("linear_l", 1760, 100, 200), ("fcs0", 5280, 200, 100), ("lstm gate", 5280, 100, 400), ("S2.W", 5280, 200, 100),
           ("cfg4 party gi", 21120, 200, 600), ("cfg3 party gi", 28512, 200, 600), ("cfg5 fcs0", 98304, 200, 100),
           ("cfg5 gate", 98304, 100, 400), ("cfg5 proj", 98304, 512, 200), ("party gi 2mod", 7040, 200, 600), ("party gi 2mod cfg4", 14080, 200, 600), ("mid", 8192, 200, 256), ("mid2", 16384, 100, 128)]
+if os.environ.get("HOT"):
+    # the GEMMs that stay on the library in the cfg2 step (profiles/r02_linear_vs_hipblaslt.txt): modality projections
+    # (forward) and the GRU input-gradient GEMMs dG . [W_ih; W_ih_reverse] (for the hand-written kernel the weight is
+    # given pre-transposed, i.e. its best case: no transpose launch counted)
+    shapes = [("linear_a / linear_l fwd", 1760, 100, 200), ("linear text fwd", 1760, 512, 200), ("ctx GRU dX", 1760, 600, 200),
+              ("party GRU dX", 7040, 600, 200), ("party GRU gi (ours in production)", 7040, 200, 600)]
 if os.environ.get("ONLY"):
     shapes = [s_ for s_ in shapes if os.environ["ONLY"] in s_[0]]
 cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1]
