@@ -109,24 +109,18 @@ int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross,
  *   y[g]     : (T, rows, 2H) out; direction 1 runs t = T-1 .. 0; zero initial state
  *   gates[g] : (T, rows, 2, 4, H) out: r, z, n and W_hn h + b_hn (saved for backward)
  * H must be 100 (the reference hard-codes D_e = 100).
- * mask / ym (arrays of ngroups pointers, or both NULL; entries may be NULL): the inter-layer dropout of
- *   nn.GRU(num_layers=2, dropout=p) (model.py:866,868) folded into the output stage: mask[g] (T, rows, 2H) holds 0 / 1
- *   keep flags and ym[g] receives y (.) mask * mscale (mscale = 1/(1-p)), the next layer's input; y stays unmasked
- *   (it is the recurrence's own state history).
  * ------------------------------------------------------------------------- */
 int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const float* const* w_hh,
                       const float* const* b_hh, float* const* y, float* const* gates,
-                      const float* const* mask, float* const* ym, float mscale,
                       const int* rows, const int* T, int H, void* stream);
 
 /* Backward through time of the same recurrence: given dy[g] (T, rows, 2H) writes
  *   dgi[g], dgh[g] : (T, rows, 2, 3H)  gradients of the input-side / hidden-side gate
  *   pre-activations (they differ only in the n gate: dgh_n = dgi_n * r).
- * Weight gradients are dense contractions of these done by the caller.
- * mask (array, or NULL; entries may be NULL): dy[g] is the gradient of ym[g], i.e. dy (.) mask * mscale reaches y. */
+ * Weight gradients are dense contractions of these done by the caller. */
 int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const float* const* y,
                       const float* const* gates, const float* const* w_hh,
-                      float* const* dgi, float* const* dgh, const float* const* mask, float mscale,
+                      float* const* dgi, float* const* dgh,
                       const int* rows, const int* T, int H, void* stream);
 
 /* ---------------------------------------------------------------------------
@@ -188,6 +182,15 @@ int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const 
 int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, const int64_t* flat_idx,
                             float* const* dbase, float* dE, const float* weights,
                             int L, int B, int P, int N, int H, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Dropout as a multiply by precomputed keep flags, several tensors per launch (the inter-layer dropout of
+ * nn.GRU(num_layers=2, dropout=p) for the context and the party encoder, model.py:866,868, one launch each way):
+ *   out[g][i] = x[g][i] * mask[g][i] * scale,  i < n[g]   (n[g] % 4 == 0, 16-byte aligned buffers, ngroups <= 4).
+ * The backward pass is the same call on the incoming gradients.  x, mask, out: HOST arrays of device pointers.
+ * ------------------------------------------------------------------------- */
+int mmdfn_mask_scale(int ngroups, const float* const* x, const float* const* mask, float* const* out,
+                     const int64_t* n, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K1  dense projection, fp32 in / fp32 out (replaces nn.Linear / F.linear / torch.mm on the hot path:

@@ -22,8 +22,8 @@ SIGNATURES = {
     "mmdfn_tile_outer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_adj_build": [_P] * 8 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
     "mmdfn_adj_build_bwd": [_P] * 15 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
-    "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P],
-    "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P],
+    "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "mmdfn_lstm_pointwise_fwd": [_P, _P, _P, _P, _L, _I, _P],
     "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
@@ -52,6 +52,7 @@ SIGNATURES = {
     "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_party_combine": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mmdfn_mask_scale": [_I, _P, _P, _P, _P, _F, _P],
 }
 
 ABI_VERSION = 7
@@ -133,6 +134,10 @@ def ptr_array(tensors):
 
 def int_array(values):
     return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def long_array(values):
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
 
 
 def float_array(values):

@@ -183,6 +183,29 @@ inline int grid_for(int64_t total) {
     return (int)b;
 }
 
+struct MaskScaleGroups {
+    const float* x[MAXMOD];
+    const float* mask[MAXMOD];
+    float* out[MAXMOD];
+    int64_t start4[MAXMOD + 1];      // prefix sums of n[g] / 4
+};
+
+// out = x * mask * scale over the concatenation of up to MAXMOD tensors (16-byte chunks, grid-stride)
+__global__ void mask_scale_kernel(MaskScaleGroups G, int ngroups, float scale) {
+    const int64_t total = G.start4[ngroups];
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        // (selects, not indexed loads: a per-thread index into the kernel-argument arrays would go through scratch)
+        const int g = (idx >= G.start4[1]) + (idx >= G.start4[2]) + (idx >= G.start4[3]);
+        const int64_t o = idx - (g == 0 ? G.start4[0] : g == 1 ? G.start4[1] : g == 2 ? G.start4[2] : G.start4[3]);
+        const float* xp = g == 0 ? G.x[0] : g == 1 ? G.x[1] : g == 2 ? G.x[2] : G.x[3];
+        const float* mp = g == 0 ? G.mask[0] : g == 1 ? G.mask[1] : g == 2 ? G.mask[2] : G.mask[3];
+        float* op = g == 0 ? G.out[0] : g == 1 ? G.out[1] : g == 2 ? G.out[2] : G.out[3];
+        const float4 v = reinterpret_cast<const float4*>(xp)[o];
+        const float4 m = reinterpret_cast<const float4*>(mp)[o];
+        reinterpret_cast<float4*>(op)[o] = make_float4(v.x * m.x * scale, v.y * m.y * scale, v.z * m.z * scale, v.w * m.w * scale);
+    }
+}
+
 }  // namespace
 
 extern "C" int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, const float* bias, float* S,
@@ -242,6 +265,27 @@ extern "C" int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t*
     }
     hipLaunchKernelGGL(party_combine_bwd_kernel, dim3(grid_for((int64_t)Mn * N * (H / 4))), dim3(256), 0,
                        (hipStream_t)stream, dout, rank, flat_idx, x, dE, w[0], w[1], w[2], w[3], L, B, P, Mn, N, H);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_mask_scale(int ngroups, const float* const* x, const float* const* mask, float* const* out,
+                                const int64_t* n, float scale, void* stream) {
+    if (ngroups <= 0 || ngroups > MAXMOD) return -1;
+    MaskScaleGroups G;
+    int64_t acc = 0;
+    for (int g = 0; g < MAXMOD; ++g) {
+        G.start4[g] = acc;
+        G.x[g] = G.mask[g] = nullptr;
+        G.out[g] = nullptr;
+        if (g < ngroups) {
+            if (n[g] <= 0 || (n[g] & 3)) return -1;
+            G.x[g] = x[g]; G.mask[g] = mask[g]; G.out[g] = out[g];
+            acc += n[g] / 4;
+        }
+    }
+    for (int g = ngroups; g <= MAXMOD; ++g) G.start4[g] = acc;
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for(acc)), dim3(256), 0, (hipStream_t)stream, G, ngroups, scale);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -32,9 +32,6 @@ struct FwdGroups {
     const float* b_hh[2 * MAXG];
     float* y[MAXG];
     float* gates[MAXG];
-    const float* mask[MAXG];       // optional inter-layer dropout of nn.GRU: 0 / 1 keep flags (T, rows, 2H) ...
-    float* ym[MAXG];               // ... and the dropped-out copy y (.) mask * mscale the next layer reads
-    float mscale;
     int rows[MAXG];
     int T[MAXG];
     int slice0[MAXG + 1];
@@ -48,8 +45,6 @@ struct BwdGroups {
     const float* w_hh[2 * MAXG];
     float* dgi[MAXG];
     float* dgh[MAXG];
-    const float* mask[MAXG];       // dy arrives as the gradient of ym = y (.) mask * mscale (NULL: of y itself)
-    float mscale;
     int rows[MAXG];
     int T[MAXG];
     int slice0[MAXG + 1];
@@ -92,11 +87,9 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     constexpr int IN4 = 3 * GH / 4;                 // float4 per (step, row) of staged input  (gi: r, z, n)
     constexpr int OUT4 = 5 * GH / 4;                // float4 per (step, row) of staged output (y, r, z, n, ghn)
     constexpr int NIN = (TB * R * IN4 + NT - 1) / NT;
-    constexpr int NM4 = TB * R * GH / 4;            // float4 of dropout flags per block (200 <= NT: one per thread)
     __shared__ __attribute__((aligned(16))) float hs[2][R][GH + 4];
     __shared__ __attribute__((aligned(16))) float in_s[2][TB][R][3 * GH];
     __shared__ __attribute__((aligned(16))) float out_s[TB][R][5 * GH];
-    __shared__ __attribute__((aligned(16))) float mask_s[2][TB][R][GH];
 
     int gidx = 0;
     while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
@@ -109,9 +102,6 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
     float* __restrict__ y = G.y[gidx];
     float* __restrict__ gates = G.gates[gidx];
-    const float* __restrict__ mask = G.mask[gidx];
-    float* __restrict__ ym = G.ym[gidx];
-    const float mscale = G.mscale;
 
     const int tid = threadIdx.x;
     const int u = tid >> 1;
@@ -144,7 +134,6 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
 
     const int nblocks = (T + TB - 1) / TB;
     float4 stage[NIN];
-    float4 mstage = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_block = [&](int b) {            // global -> registers (raw; out-of-range slots are never consumed)
 #pragma unroll
         for (int e = 0; e < NIN; ++e) {
@@ -160,17 +149,6 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
                 stage[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + row0 + r) * (6 * GH) + dir * 3 * GH + 4 * c4);
             }
         }
-        if (mask && tid < NM4) {                // the block's dropout flags travel the same way, one block ahead
-            const int sl = tid / (R * (GH / 4));
-            const int rem = tid - sl * (R * (GH / 4));
-            const int r = rem / (GH / 4);
-            const int c4 = rem - r * (GH / 4);
-            const int sidx = b * TB + sl;
-            if (sidx < T && row0 + r < rows) {
-                const int t = dir ? T - 1 - sidx : sidx;
-                mstage = *reinterpret_cast<const float4*>(mask + ((int64_t)t * rows + row0 + r) * (2 * GH) + dir * GH + 4 * c4);
-            }
-        }
     };
     auto stash_block = [&](int buf) {          // registers -> LDS
 #pragma unroll
@@ -178,7 +156,6 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             const int idx = tid + e * NT;
             if (idx < TB * R * IN4) *reinterpret_cast<float4*>(&in_s[buf][0][0][0] + 4 * idx) = stage[e];
         }
-        if (mask && tid < NM4) *reinterpret_cast<float4*>(&mask_s[buf][0][0][0] + 4 * tid) = mstage;
     };
     auto flush_block = [&](int b) {            // LDS -> global, nobody waits for these stores
         for (int idx = tid; idx < TB * R * OUT4; idx += NT) {
@@ -191,14 +168,9 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             const int t = dir ? T - 1 - sidx : sidx;
             const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][r][4 * c4]);
             const int64_t o = ((int64_t)t * rows + row0 + r);
-            if (c4 < GH / 4) {
+            if (c4 < GH / 4)
                 *reinterpret_cast<float4*>(y + o * (2 * GH) + dir * GH + 4 * c4) = v;
-                if (mask) {
-                    const float4 mk = *reinterpret_cast<const float4*>(&mask_s[b & 1][sl][r][4 * c4]);
-                    *reinterpret_cast<float4*>(ym + o * (2 * GH) + dir * GH + 4 * c4) =
-                        make_float4(v.x * mk.x * mscale, v.y * mk.y * mscale, v.z * mk.z * mscale, v.w * mk.w * mscale);
-                }
-            } else
+            else
                 *reinterpret_cast<float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4)) = v;
         }
     };
@@ -275,8 +247,6 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     constexpr int IN4 = 6 * GH / 4;     // staged per (step,row): dy (GH) | r z n ghn (4 GH) | h_prev (GH)
     constexpr int OUT4 = 6 * GH / 4;    // dgi (3 GH) | dgh (3 GH)
     constexpr int NIN = (TB * R * IN4 + NT - 1) / NT;
-    constexpr int NM4 = TB * R * GH / 4;
-    __shared__ uint32_t mask_s[2][TB][R][GH / 4];     // keep flags packed to bytes (the float staging would not fit 64 KB)
     __shared__ __attribute__((aligned(16))) float dghs[2][R][3 * GH + 4];
     __shared__ __attribute__((aligned(16))) float in_s[2][TB][R][6 * GH];
     __shared__ __attribute__((aligned(16))) float out_s[TB][R][6 * GH];
@@ -293,8 +263,6 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
     float* __restrict__ dgi = G.dgi[gidx];
     float* __restrict__ dgh = G.dgh[gidx];
-    const float* __restrict__ mask = G.mask[gidx];
-    const float mscale = G.mscale;
 
     const int tid = threadIdx.x;
     const int u = tid >> 1;
@@ -318,7 +286,6 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     // step index s runs in the REVERSE of the forward order: t(s) = dir ? s : T-1-s
     const int nblocks = (T + TB - 1) / TB;
     float4 stage[NIN];
-    float4 mstage = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_block = [&](int b) {
 #pragma unroll
         for (int e = 0; e < NIN; ++e) {
@@ -344,17 +311,6 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
                 }
             }
         }
-        if (mask && tid < NM4) {                // dropout flags of the dy chunk (same addressing as dy)
-            const int sl = tid / (R * (GH / 4));
-            const int rem = tid - sl * (R * (GH / 4));
-            const int r = rem / (GH / 4);
-            const int c4 = rem - r * (GH / 4);
-            const int sidx = b * TB + sl;
-            if (sidx < T && row0 + r < rows) {
-                const int t = dir ? sidx : T - 1 - sidx;
-                mstage = *reinterpret_cast<const float4*>(mask + ((int64_t)t * rows + row0 + r) * (2 * GH) + dir * GH + 4 * c4);
-            }
-        }
     };
     auto stash_block = [&](int buf) {
 #pragma unroll
@@ -362,9 +318,6 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
             const int idx = tid + e * NT;
             if (idx < TB * R * IN4) *reinterpret_cast<float4*>(&in_s[buf][0][0][0] + 4 * idx) = stage[e];
         }
-        if (mask && tid < NM4)
-            (&mask_s[buf][0][0][0])[tid] = (mstage.x != 0.f ? 1u : 0u) | (mstage.y != 0.f ? 1u << 8 : 0u) |
-                                           (mstage.z != 0.f ? 1u << 16 : 0u) | (mstage.w != 0.f ? 1u << 24 : 0u);
     };
     auto flush_block = [&](int b) {
         for (int idx = tid; idx < TB * R * OUT4; idx += NT) {
@@ -413,8 +366,7 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
                 rec += pair_swap(rec);
                 if (mine[r]) {
                     const float* ip = &in_s[buf][sl][r][u];
-                    const float dyv = !mask ? ip[0] : ((mask_s[buf][sl][r][u >> 2] >> (8 * (u & 3))) & 0xffu) ? ip[0] * mscale : 0.f;
-                    const float dh = dyv + carry[r] + rec;
+                    const float dh = ip[0] + carry[r] + rec;
                     const float rr = ip[GH], zz = ip[2 * GH], nn = ip[3 * GH], ghn = ip[4 * GH], hprev = ip[5 * GH];
                     const float dn = dh * (1.0f - zz);
                     const float dz = dh * (hprev - nn);
@@ -456,17 +408,11 @@ int pick_r(int ngroups, const int* rows) {
 }  // namespace
 
 extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const float* const* w_hh,
-                                 const float* const* b_hh, float* const* y, float* const* gates, const float* const* mask,
-                                 float* const* ym, float mscale, const int* rows, const int* T, int H, void* stream) {
-    if (ngroups <= 0 || ngroups > MAXG || H != GH || ((mask == nullptr) != (ym == nullptr))) return -1;
+                                 const float* const* b_hh, float* const* y, float* const* gates, const int* rows,
+                                 const int* T, int H, void* stream) {
+    if (ngroups <= 0 || ngroups > MAXG || H != GH) return -1;
     FwdGroups G;
     G.n = ngroups;
-    G.mscale = mscale;
-    for (int g = 0; g < MAXG; ++g) {
-        G.mask[g] = (mask && g < ngroups) ? mask[g] : nullptr;
-        G.ym[g] = (ym && g < ngroups) ? ym[g] : nullptr;
-        if ((G.mask[g] == nullptr) != (G.ym[g] == nullptr)) return -1;
-    }
     const int R = pick_r(ngroups, rows);
     int sl = 0;
     for (int g = 0; g < ngroups; ++g) {
@@ -489,13 +435,10 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
 
 extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const float* const* y,
                                  const float* const* gates, const float* const* w_hh, float* const* dgi,
-                                 float* const* dgh, const float* const* mask, float mscale, const int* rows, const int* T,
-                                 int H, void* stream) {
+                                 float* const* dgh, const int* rows, const int* T, int H, void* stream) {
     if (ngroups <= 0 || ngroups > MAXG || H != GH) return -1;
     BwdGroups G;
     G.n = ngroups;
-    G.mscale = mscale;
-    for (int g = 0; g < MAXG; ++g) G.mask[g] = (mask && g < ngroups) ? mask[g] : nullptr;
     const int R = pick_r(ngroups, rows);
     int sl = 0;
     for (int g = 0; g < ngroups; ++g) {

@@ -16,13 +16,10 @@ H = 100
 class _GruRecurrence(torch.autograd.Function):
     """args = per group (gi, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev), flattened -> (y_0, y_1, ...).  The recurrent
     weights are the module's own parameters (no stack / cat per step): the kernels take one pointer per direction
-    and the gradients come back per parameter.  ``masks`` (one (T, rows, 2H) tensor of 0 / 1 keep flags per group, or
-    None): nn.GRU's inter-layer dropout folded into the kernels -- the outputs are then y (.) mask * mscale, written by
-    the recurrence next to its own unmasked state history, and the backward pass masks the incoming gradient as it
-    stages it (no dropout / mask-scale launches)."""
+    and the gradients come back per parameter."""
 
     @staticmethod
-    def forward(ctx, masks, mscale, *args):
+    def forward(ctx, *args):
         n = len(args) // 5
         gis = [args[5 * g].contiguous() for g in range(n)]
         whh = [args[5 * g + 1 + d].contiguous() for g in range(n) for d in range(2)]
@@ -36,25 +33,14 @@ class _GruRecurrence(torch.autograd.Function):
             gates.append(torch.empty(T, R, 2, 4, H, dtype=torch.float32, device=gi.device))
             rows.append(R)
             Ts.append(T)
-        yms = None
-        if masks is not None:
-            masks = [m.contiguous() for m in masks]
-            _hip.require_f32(*masks)
-            for m, y in zip(masks, ys):
-                if m.shape != y.shape:
-                    raise ValueError("dropout flags must have the output's shape (T, rows, 2H)")
-            yms = [torch.empty_like(y) for y in ys]
         rc = _hip.lib().mmdfn_gru_seq_fwd(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
-                                          _hip.ptr_array(ys), _hip.ptr_array(gates),
-                                          None if masks is None else _hip.ptr_array(masks),
-                                          None if masks is None else _hip.ptr_array(yms), float(mscale),
-                                          _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
+                                          _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
+                                          _hip.int_array(Ts), H, _hip.stream())
         _hip.check(rc, "mmdfn_gru_seq_fwd")
         ctx.n = n
-        ctx.masks, ctx.mscale = masks, float(mscale)
         ctx.refs = [args[5 * g + 1 + k] for g in range(n) for k in range(4)]   # the parameter objects (leaf test)
         ctx.save_for_backward(*ys, *gates, *whh)
-        return tuple(ys if masks is None else yms)
+        return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
@@ -68,7 +54,6 @@ class _GruRecurrence(torch.autograd.Function):
         Ts = [y.shape[0] for y in ys]
         rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
                                           _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
-                                          None if ctx.masks is None else _hip.ptr_array(ctx.masks), ctx.mscale,
                                           _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
         _hip.check(rc, "mmdfn_gru_seq_bwd")
         # recurrent-weight gradients of every group and direction join the step's weight-gradient batch:
@@ -92,7 +77,7 @@ class _GruRecurrence(torch.autograd.Function):
                     ops.gemm_tn_grouped([dict(A=A, B=B, C=dw, colsum=db, shift=shift)])
                     res.append((dw, db))
             out += [dgi[g], res[0][0], res[1][0], res[0][1], res[1][1]]
-        return (None, None) + tuple(out)
+        return tuple(out)
 
 
 def _layer_params(gru, layer):
@@ -138,7 +123,7 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
     cur = list(xs)
     # [W_ih_fwd; W_ih_rev] of every (module, layer) as ONE (600, K) operand for the input-gradient GEMMs of the backward
-    # pass.  The two parameters are kept adjacent in memory (pair_direction_weights), so this is a view; parameters some
+    # pass.  The two parameters are kept adjacent in memory (_stacked_view), so this is a view; parameters some
     # other owner has laid out differently are copied instead (one multi-tensor copy launch per step).
     wcat = None
     if torch.is_grad_enabled():
@@ -163,12 +148,9 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
         args = []
         for gi, p in zip(gis, prm):
             args += [gi] + p[2]
-        masks, mscale = None, 1.0
+        cur = list(_GruRecurrence.apply(*args))
         if layer == 0 and training and dropout > 0:
-            # nn.GRU's dropout between the layers: 0 / 1 keep flags from the step's flag pool (one generator launch for
-            # every dropout site of the step), applied inside the recurrence kernels
-            masks = [ops.keep_flags(gi.shape[0] * gi.shape[1] * 2 * H, dropout, gi.device).view(gi.shape[0], gi.shape[1], 2 * H)
-                     for gi in gis]
-            mscale = 1.0 / (1.0 - dropout)
-        cur = list(_GruRecurrence.apply(masks, mscale, *args))
+            # nn.GRU's dropout between the layers: 0 / 1 keep flags from the step's flag pool (no generator launch of its
+            # own) applied to every group's output by ONE launch each way
+            cur = list(ops.mask_scale(cur, [ops.keep_flags(y.numel(), dropout, y.device) for y in cur], 1.0 / (1.0 - dropout)))
     return cur

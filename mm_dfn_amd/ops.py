@@ -891,6 +891,49 @@ def keep_flags(n, p, device):
     return out
 
 
+class _MaskScale(torch.autograd.Function):
+    """outs[g] = xs[g] * masks[g] * scale for up to 4 tensors in ONE launch (csrc/encoder_glue.hip); the backward pass is
+    the same launch on the incoming gradients.  masks: flat 0 / 1 keep flags (ops.keep_flags)."""
+
+    @staticmethod
+    def forward(ctx, scale, masks, *xs):
+        _hip.require_cuda(*xs)
+        _hip.require_f32(*xs, *masks)
+        xs = [x.contiguous() for x in xs]
+        outs = [torch.empty_like(x) for x in xs]
+        ctx.masks, ctx.scale = list(masks), float(scale)
+        _MaskScale._launch(xs, ctx.masks, outs, ctx.scale)
+        return tuple(outs)
+
+    @staticmethod
+    def _launch(xs, masks, outs, scale):
+        for x, m in zip(xs, masks):
+            if m.numel() != x.numel() or x.numel() % 4 or x.data_ptr() % 16 or m.data_ptr() % 16:
+                raise _hip.HipLibraryError("mask_scale: flags must match the tensor (multiple of 4 elements, 16-byte aligned)")
+        rc = _hip.lib().mmdfn_mask_scale(len(xs), _hip.ptr_array(xs), _hip.ptr_array(masks), _hip.ptr_array(outs),
+                                         _hip.long_array([x.numel() for x in xs]), scale, _hip.stream())
+        _hip.check(rc, "mmdfn_mask_scale")
+
+    @staticmethod
+    def backward(ctx, *douts):
+        live = [i for i, d in enumerate(douts) if d is not None]
+        grads = [None] * len(douts)
+        if live:
+            ds = [douts[i].contiguous() for i in live]
+            outs = [torch.empty_like(d) for d in ds]
+            _MaskScale._launch(ds, [ctx.masks[i] for i in live], outs, ctx.scale)
+            for i, o in zip(live, outs):
+                grads[i] = o
+        return (None, None) + tuple(grads)
+
+
+def mask_scale(xs, masks, scale):
+    """Dropout as a multiply by precomputed keep flags for a list of (<= 4) tensors, one launch each way."""
+    if len(xs) > 4:
+        return tuple(o for k in range(0, len(xs), 4) for o in mask_scale(xs[k:k + 4], masks[k:k + 4], scale))
+    return _MaskScale.apply(scale, list(masks), *xs)
+
+
 class _Head(torch.autograd.Function):
     """log_softmax(relu(F (.) mask * mscale) W^T + b): the classifier head of model.py:1328-1337 as one launch each way
     (csrc/head.hip); mask = 0 / 1 keep flags of the head dropout or None.  ``Fm``: (N, W), or the (M, N, Wm) output of

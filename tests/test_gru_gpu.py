@@ -109,39 +109,21 @@ def test_party_gather_combine_kernels_match_index_composition(P, lengths, w, pas
         assert rel_err(Xk[i].grad, Xr[i].grad) < 1e-6
 
 
-@pytest.mark.parametrize("shapes", [[(9, 3)], [(110, 16), (110, 64)], [(13, 300)], [(6, 700), (11, 5)]])
-def test_inter_layer_dropout_inside_the_recurrence_kernels(shapes):
-    """nn.GRU(dropout=p) between the layers (model.py:866,868): the forward kernel writes y (.) mask * 1/(1-p) next to its
-    own unmasked history, the backward kernel masks the incoming gradient while staging it -- against the unfused
-    composition (recurrence, then torch multiply) on the same keep flags, for every rows-per-workgroup variant."""
-    rs = np.random.RandomState(17 + len(shapes) + shapes[0][1])
-    H = fused.H
+@pytest.mark.parametrize("shapes", [[(9, 3, 200)], [(110, 16, 200), (110, 64, 200)], [(1, 1, 4), (3, 5, 8), (2, 2, 12), (7, 1, 4)]])
+def test_multi_tensor_mask_scale_is_dropout_on_given_flags(shapes):
+    """nn.GRU(dropout=p) between the layers (model.py:866,868) for every encoder group in one launch each way:
+    out = x * flags / (1-p), exactly torch's multiply on the same keep flags, and so is its backward."""
+    from mm_dfn_amd import ops
+    rs = np.random.RandomState(17 + len(shapes))
     p = 0.5
-    ms = 1.0 / (1.0 - p)
-
-    def leaves():
-        out = []
-        r2 = np.random.RandomState(3)
-        for T, R in shapes:
-            out += [torch.from_numpy(r2.randn(T, R, 6 * H).astype(np.float32)).to(DEV).requires_grad_(True)]
-            out += [torch.from_numpy((r2.randn(3 * H, H) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True) for _ in range(2)]
-            out += [torch.from_numpy((r2.randn(3 * H) * 0.1).astype(np.float32)).to(DEV).requires_grad_(True) for _ in range(2)]
-        return out
-
-    masks = [torch.from_numpy((rs.uniform(size=(T, R, 2 * H)) > p).astype(np.float32)).to(DEV) for T, R in shapes]
-    ws = [torch.from_numpy(rs.randn(T, R, 2 * H).astype(np.float32)).to(DEV) for T, R in shapes]
-    a = leaves()
-    got = fused._GruRecurrence.apply(masks, ms, *a)
+    xs = [torch.from_numpy(rs.randn(*sh).astype(np.float32)).to(DEV).requires_grad_(True) for sh in shapes]
+    masks = [torch.from_numpy((rs.uniform(size=int(np.prod(sh))) > p).astype(np.float32)).to(DEV) for sh in shapes]
+    ws = [torch.from_numpy(rs.randn(*sh).astype(np.float32)).to(DEV) for sh in shapes]
+    got = ops.mask_scale(xs, masks, 1.0 / (1.0 - p))
     sum((y * w).sum() for y, w in zip(got, ws)).backward()
-    b = leaves()
-    plain = fused._GruRecurrence.apply(None, 1.0, *b)
-    want = [y * m * ms for y, m in zip(plain, masks)]
-    sum((y * w).sum() for y, w in zip(want, ws)).backward()
-    for g in range(len(shapes)):
-        assert torch.equal(got[g], want[g])
-        assert rel_err(a[5 * g].grad, b[5 * g].grad) < 1e-6          # d(gate pre-activations)
-        for k in range(1, 5):                                       # recurrent weights / biases (end-of-backward batch)
-            assert rel_err(a[5 * g + k].grad, b[5 * g + k].grad) < 1e-5, (g, k)
+    for x, m, w, y in zip(xs, masks, ws, got):
+        assert torch.equal(y, x.detach() * m.view_as(x) * 2.0)
+        assert torch.equal(x.grad, w * m.view_as(x) * 2.0)
 
 
 def test_train_mode_dropout_through_bigru2_is_unbiased_and_reaches_the_gradients():
