@@ -49,8 +49,8 @@ def shard_dialogues(lengths, world, rank):
 
 
 def bucket_order(model, live):
-    """Flat-buffer order of the live parameters: model order, except that every ``weight_ih_l*_reverse`` directly follows
-    its forward twin -- the fused GRU path reads the two as one stacked (600, K) operand (gru._stacked_view), and FlatAdam
+    """Flat-buffer order of the live parameters: model order, except that every ``weight_ih_l*_reverse`` / ``bias_ih_l*_reverse`` directly
+    follows its forward twin -- the fused GRU path reads the two as one stacked (600, K) operand (gru._stacked_view), and FlatAdam
     lays the parameters out in this order."""
     names = {id(p): n for n, p in model.named_parameters()}
     by_name = {names[id(p)]: p for p in live}
@@ -61,7 +61,7 @@ def bucket_order(model, live):
         out.append(p)
         placed.add(id(p))
         n = names[id(p)]
-        if ".weight_ih_l" in "." + n and not n.endswith("_reverse"):
+        if (".weight_ih_l" in "." + n or ".bias_ih_l" in "." + n) and not n.endswith("_reverse"):
             twin = by_name.get(n + "_reverse")
             if twin is not None and id(twin) not in placed:
                 out.append(twin)

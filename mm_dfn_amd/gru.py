@@ -110,6 +110,8 @@ def _stacked_view(wf, wr):
             buf = torch.cat([wf.detach().reshape(-1), wr.detach().reshape(-1)])
             wf.data = buf[:wf.numel()].view(wf.shape)
             wr.data = buf[wf.numel():].view(wr.shape)
+    if wf.dim() == 1:
+        return torch.as_strided(wf.detach(), (2 * wf.shape[0],), (1,))
     return torch.as_strided(wf.detach(), (2 * wf.shape[0], wf.shape[1]), (wf.shape[1], 1))
 
 
@@ -125,10 +127,13 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
     # [W_ih_fwd; W_ih_rev] of every (module, layer) as ONE (600, K) operand for the input-gradient GEMMs of the backward
     # pass.  The two parameters are kept adjacent in memory (_stacked_view), so this is a view; parameters some
     # other owner has laid out differently are copied instead (one multi-tensor copy launch per step).
-    wcat = None
+    wcat = bcat = None
     if torch.is_grad_enabled():
         pairs = [_layer_params(gru, layer)[0] for layer in range(2) for gru in grus]
         wcat = [_stacked_view(wf, wr) for wf, wr in pairs]
+        # the stacked input biases [b_ih; b_ih_reverse] the same way (views only: used by the forward pass of launches
+        # with few rows, which is a library GEMM on the stacked views)
+        bcat = [_stacked_view(bf, br) for bf, br in (_layer_params(gru, layer)[1] for layer in range(2) for gru in grus)]
         if any(w is None for w in wcat):
             halves = [w for pair in pairs for w in pair]
             with torch.no_grad():
@@ -143,7 +148,8 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
         pre = gi0 if (layer == 0 and gi0 is not None) else [None] * len(grus)
         gis = [pre[g] if pre[g] is not None else
                ops.linear2(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1],
-                           None if wcat is None else wcat[layer * len(grus) + g])
+                           None if wcat is None else wcat[layer * len(grus) + g],
+                           None if bcat is None else bcat[layer * len(grus) + g])
                for g in range(len(grus))]
         args = []
         for gi, p in zip(gis, prm):

@@ -795,7 +795,7 @@ class _Linear2(torch.autograd.Function):
     concatenated copy per step (csrc/linear.hip, mmdfn_linear2)."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, b1, b2, wcat):
+    def forward(ctx, x, w1, w2, b1, b2, wcat, bcat):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         _hip.require_cuda(x2, w1, w2)
@@ -805,10 +805,16 @@ class _Linear2(torch.autograd.Function):
         w1c, w2c = w1.contiguous(), w2.contiguous()
         R, K = x2.shape
         n1, N = w1.shape[0], w1.shape[0] + w2.shape[0]
-        y = torch.empty(R, N, dtype=torch.float32, device=x2.device)
-        rc = _hip.lib().mmdfn_linear2(_hip.ptr(x2), _hip.ptr(w1c), _hip.ptr(w2c), n1, _hip.ptr(b1), _hip.ptr(b2), _hip.ptr(y),
-                                      R, K, N, x2.stride(0), N, 0, 0, _hip.stream())
-        _hip.check(rc, "mmdfn_linear2")
+        if wcat is not None and R < LINEAR2_LIBRARY_ROWS and (bcat is not None or b1 is None):
+            # few rows: a plain library GEMM on the stacked views beats the hand-written kernel (measured,
+            # profiles/r02_linear_vs_hipblaslt.txt: 1 760 x 200 -> 600 in 10.3 us vs 16.0 us; at 3 520 rows and above
+            # the library's kernel selection collapses -- 45 us vs 23 us -- so the switch is on the row count only)
+            y = torch.addmm(bcat, x2, wcat.t()) if bcat is not None else torch.mm(x2, wcat.t())
+        else:
+            y = torch.empty(R, N, dtype=torch.float32, device=x2.device)
+            rc = _hip.lib().mmdfn_linear2(_hip.ptr(x2), _hip.ptr(w1c), _hip.ptr(w2c), n1, _hip.ptr(b1), _hip.ptr(b2), _hip.ptr(y),
+                                          R, K, N, x2.stride(0), N, 0, 0, _hip.stream())
+            _hip.check(rc, "mmdfn_linear2")
         ctx.refs = (w1, w2, b1, b2)
         ctx.save_for_backward(x2, w1c, w2c, wcat)
         return y.view(*shp[:-1], N)
@@ -827,14 +833,18 @@ class _Linear2(torch.autograd.Function):
             dx = (dy2 @ wcat if wcat is not None else torch.addmm(d1 @ w1, d2, w2)).view(*dy.shape[:-1], w1.shape[1])
         dw1, db1 = _wgrad(d1, x2, p1, b1)
         dw2, db2 = _wgrad(d2, x2, p2, b2)
-        return dx, dw1, dw2, db1, db2, None
+        return dx, dw1, dw2, db1, db2, None, None
 
 
-def linear2(x, w1, w2, b1, b2, wcat=None):
-    """``wcat``: optional (n1 + n2, K) stacked copy of [w1; w2] (no gradient flows through it) used for the input gradient."""
+LINEAR2_LIBRARY_ROWS = 2048
+
+
+def linear2(x, w1, w2, b1, b2, wcat=None, bcat=None):
+    """``wcat`` / ``bcat``: optional stacked views (or copies) of [w1; w2] (n1 + n2, K) and [b1; b2] -- no gradient flows
+    through them; wcat serves the input gradient, and both serve the forward pass of launches with few rows."""
     if w1.shape[1] % 4 or w1.shape[1] < 4:
         raise ValueError("linear2: the contraction width must be a multiple of 4")
-    return _Linear2.apply(x, w1, w2, b1, b2, wcat)
+    return _Linear2.apply(x, w1, w2, b1, b2, wcat, bcat)
 
 
 # ---- dropout keep flags: one generator launch per step -----------------------------------------------------------------

@@ -470,6 +470,10 @@ def test_two_block_projection(R, K, n1, n2):
     assert rel_err(x2.grad, xr.grad) < 1e-5
     for p, g0 in zip((w1, w2, b1, b2), g_before):
         assert rel_err(p.grad, 2 * g0.double().cpu()) < 1e-5          # accumulated into the existing .grad
+    # stacked weight AND bias given: launches with few rows run as one library GEMM on the stacked operands, the others
+    # on the two-block kernel -- same result either way
+    y3 = ops.linear2(x.detach(), w1, w2, b1, b2, torch.cat([w1, w2], 0).detach(), torch.cat([b1, b2], 0).detach())
+    assert rel_err(y3, yr) < 2e-6
     # no biases (the project-then-gather path adds the bias after the gather)
     y0 = ops.linear2(x.detach(), w1, w2, None, None)
     assert rel_err(y0, yr - torch.cat([pr[2], pr[3]], 0)) < 2e-6

@@ -14,7 +14,7 @@ FAMILIES = [
     ("projections_hand_written", r"linear_kernel|linear_split"),
     ("projections_hipblaslt", r"^Cijk_"),
     ("head_and_loss", r"head_|focal_loss"),
-    ("encoder_glue", r"party_"),
+    ("encoder_glue", r"party_|mask_scale"),
     ("optimizer", r"adam_step"),
     ("aten_and_runtime", r"at::native|rocclr|rocprim|elementwise_kernel_with_index"),
 ]
