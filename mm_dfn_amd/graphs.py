@@ -26,7 +26,7 @@ class CapturedStep:
         self._step_fn = step_fn
 
         def tail():
-            ops.join_weight_grads()          # side-stream branches rejoin here
+            ops.join_weight_grads()          # flush weight gradients still queued (normally the engine callback did)
             if bucket is not None:
                 bucket.flatten()
                 if reduce_in_graph:

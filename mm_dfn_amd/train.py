@@ -151,7 +151,7 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
             if train_flag:
                 backward(loss)
         if train_flag:
-            ops.join_weight_grads()       # weight gradients may have been computed on the side stream
+            ops.join_weight_grads()       # weight gradients still queued are written to .grad here
             if step_hook is not None:
                 step_hook(model)          # e.g. data-parallel gradient all-reduce
             optimizer.step()
