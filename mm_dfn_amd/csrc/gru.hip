@@ -18,6 +18,7 @@
 // Gate order r, z, n;  n = tanh(gi_n + r * (W_hn h + b_hn));  h = (1-z) n + z h_prev.
 #include "mmdfn_internal.h"
 #include "../../include/mmdfn_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -396,6 +397,375 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     }
 }
 
+// =====================================================================================================
+// One sequence per workgroup, contraction index PARTITIONED OVER THE WAVES, operands broadcast through SGPRs.
+//
+// The kernels above deliver the broadcast vector (h / dgh) to every lane through LDS: 13 (forward) and 38 (backward)
+// ds_read_b128 per lane and step, i.e. 4 waves x 38 KB = 152 KB through the CU's 128 B/clk LDS return path per backward
+// step -- half of the measured step time -- and with the weight slices taking 156 VGPRs the compiler keeps only two of
+// those loads in flight.  Here each wave owns a quarter of the contraction index and produces its operands ITSELF:
+//   forward : wave w owns k in [25w, 25w+25).  Lane l accumulates the partial gate sums of rows j = l + 64q (q < 5,
+//             j < 300) over those 25 k -- h[k] comes from lane (k - 25w) of the same wave through v_readlane (an SGPR
+//             operand of the FMA: no LDS traffic, no load latency) -- and drops them in LDS; after ONE barrier lanes
+//             0..24 of wave w add the four partials of "their" units 25w + l, apply the gate math and keep h_new in a
+//             register, which is exactly what the wave's next matvec reads.
+//   backward: wave w owns gate rows j in [75w, 75w+75); lane l accumulates the partial dh_prev of units l and l + 64;
+//             after the barrier lane l < 75 rebuilds dh of unit (75w + l) mod 100 from the four partials and computes
+//             the one pre-activation gradient dgh[75w + l] its wave needs next (the carry dh z is replicated in the up
+//             to three lanes that share a unit: same inputs, same order, bit-identical).
+// LDS traffic per step: 1.2 KB (forward) / 0.5 KB (backward) of partials per wave instead of 13 KB / 38 KB; weight
+// slices 125 / 150 VGPRs.  Same time-blocked global staging as above.  Used when every sequence gets its own workgroup
+// in one round (pick_r() == 1); larger batches keep the R = 2 / 4 kernels.
+// =====================================================================================================
+constexpr int PJ = 320;              // partial-sum row length, forward (300 gate rows, padded)
+constexpr int PU = 128;              // partial-sum row length, backward (100 units, padded)
+
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// A use of a freshly loaded weight pair BEFORE the time loop.  Without it the compiler sinks the weight loads to the loop
+// entry and plants their s_waitcnt vmcnt(N) inside the step loop, where -- vector memory operations retire in order and
+// the counter also counts stores -- every later trip would wait for the previous block's result stores.
+__device__ __forceinline__ void pin_loaded(f32x2& v) {
+    float a = v[0], b = v[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+    v[0] = a;
+    v[1] = b;
+}
+__device__ __forceinline__ void pin_loaded(float& v) { asm volatile("" : "+v"(v)); }
+
+// NW waves per workgroup (4: one per SIMD; 8: two per SIMD, half the instructions per wave and a second wave to issue
+// from while the first waits on a dependent result)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gru_seq_fwd_kpart_kernel(FwdGroups G) {
+    constexpr int NTK = 64 * NW;
+    constexpr int KPW = (GH + NW - 1) / NW;         // contraction indices per wave (25 / 13)
+    constexpr int TB = 8;
+    constexpr int IN4 = 3 * GH / 4;
+    constexpr int OUT4 = 5 * GH / 4;
+    constexpr int NIN = (TB * IN4 + NTK - 1) / NTK;
+    __shared__ __attribute__((aligned(16))) float in_s[2][TB][3 * GH];
+    __shared__ __attribute__((aligned(16))) float out_s[TB][5 * GH];
+    __shared__ __attribute__((aligned(16))) float part[2][NW][PJ];
+
+    int gidx = 0;
+    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
+    const int dir = blockIdx.y;
+    const int rows = G.rows[gidx];
+    const int T = G.T[gidx];
+    const int row = (int)blockIdx.x - G.slice0[gidx];
+    const float* __restrict__ gi = G.gi[gidx];
+    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
+    const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
+    float* __restrict__ y = G.y[gidx];
+    float* __restrict__ gates = G.gates[gidx];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k0 = KPW * wv;
+    // W_hh[j][k0 + kk] for j = lane + 64 q: rows (q0, q1) and (q2, q3) as packed pairs, q4 (j < 300 for lane < 44) alone;
+    // contraction indices past H-1 (last wave when NW does not divide H) carry zero weights
+    f32x2 w01[KPW], w23[KPW];
+    float w4[KPW];
+    const bool has4 = lane + 256 < 3 * GH;
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+        const int k = k0 + kk;
+        const bool kok = k < GH;
+        const int kc = kok ? k : GH - 1;
+        w01[kk][0] = kok ? w_hh[(int64_t)(lane) * GH + kc] : 0.f;
+        w01[kk][1] = kok ? w_hh[(int64_t)(lane + 64) * GH + kc] : 0.f;
+        w23[kk][0] = kok ? w_hh[(int64_t)(lane + 128) * GH + kc] : 0.f;
+        w23[kk][1] = kok ? w_hh[(int64_t)(lane + 192) * GH + kc] : 0.f;
+        w4[kk] = (kok && has4) ? w_hh[(int64_t)(lane + 256) * GH + kc] : 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KPW; ++kk) {
+        pin_loaded(w01[kk]);
+        pin_loaded(w23[kk]);
+        pin_loaded(w4[kk]);
+    }
+    // gate stage: lanes 0..KPW-1 of wave wv own units k0 + lane
+    const bool owner = lane < KPW && k0 + lane < GH;
+    const int u = owner ? k0 + lane : 0;
+    float bhr = b_hh[u], bhz = b_hh[GH + u], bhn = b_hh[2 * GH + u];
+    pin_loaded(bhr);
+    pin_loaded(bhz);
+    pin_loaded(bhn);
+    float hv = 0.f;                       // h_{t-1}[u] of the owner lanes: the wave's matvec operand (via v_readlane)
+
+    const int nblocks = (T + TB - 1) / TB;
+    float4 stage[NIN];
+    auto load_block = [&](int b) {
+#pragma unroll
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NTK;
+            const int sl = idx / IN4;
+            const int c4 = idx - sl * IN4;
+            const int sidx = b * TB + sl;
+            stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sl < TB && sidx < T) {
+                const int t = dir ? T - 1 - sidx : sidx;
+                stage[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH + 4 * c4);
+            }
+        }
+    };
+    auto stash_block = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NTK;
+            if (idx < TB * IN4) *reinterpret_cast<float4*>(&in_s[buf][0][0] + 4 * idx) = stage[e];
+        }
+    };
+    auto flush_block = [&](int b) {
+        for (int idx = tid; idx < TB * OUT4; idx += NTK) {
+            const int sl = idx / OUT4;
+            const int c4 = idx - sl * OUT4;
+            const int sidx = b * TB + sl;
+            if (sidx >= T) continue;
+            const int t = dir ? T - 1 - sidx : sidx;
+            const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][4 * c4]);
+            const int64_t o = (int64_t)t * rows + row;
+            if (c4 < GH / 4)
+                *reinterpret_cast<float4*>(y + o * (2 * GH) + dir * GH + 4 * c4) = v;
+            else
+                *reinterpret_cast<float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4)) = v;
+        }
+    };
+
+    load_block(0);
+    stash_block(0);
+    if (nblocks > 1) load_block(1);
+    __syncthreads();
+
+    int step = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int buf = b & 1;
+        for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
+            const int pb = step & 1;
+            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            float a4 = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KPW; ++kk) {
+                const float hk = lane_bcast(hv, kk);           // h_{t-1}[k0 + kk]: wave-uniform, an SGPR operand
+                const f32x2 hh = {hk, hk};
+                a01 = __builtin_elementwise_fma(w01[kk], hh, a01);
+                a23 = __builtin_elementwise_fma(w23[kk], hh, a23);
+                a4 = __builtin_fmaf(w4[kk], hk, a4);
+            }
+            float* pp = &part[pb][wv][lane];
+            pp[0] = a01[0];
+            pp[64] = a01[1];
+            pp[128] = a23[0];
+            pp[192] = a23[1];
+            pp[256] = a4;                                      // (columns >= 300 are padding)
+            __syncthreads();
+            if (owner) {
+                float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {                 // fixed order: bit-reproducible
+                    const float* p0 = &part[pb][w][u];
+                    ar += p0[0];
+                    az += p0[GH];
+                    an += p0[2 * GH];
+                }
+                const float* gp = &in_s[buf][sl][u];
+                const float ghn = an + bhn;
+                const float rr = sigmoidf_(gp[0] + ar + bhr);
+                const float zz = sigmoidf_(gp[GH] + az + bhz);
+                const float nn = tanhf_(gp[2 * GH] + rr * ghn);
+                const float hnew = (1.0f - zz) * nn + zz * hv;
+                float* op = &out_s[sl][u];
+                op[0] = hnew;
+                op[GH] = rr;
+                op[2 * GH] = zz;
+                op[3 * GH] = nn;
+                op[4 * GH] = ghn;
+                hv = hnew;
+            }
+            // no second barrier: the next step writes the OTHER partial buffer, and nobody can be two steps ahead
+        }
+        __syncthreads();                                   // the block's results are complete in out_s
+        if (b + 1 < nblocks) stash_block(buf ^ 1);
+        flush_block(b);
+        if (b + 2 < nblocks) load_block(b + 2);
+        __syncthreads();
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G) {
+    constexpr int NTK = 64 * NW;
+    constexpr int JPW = (3 * GH + NW - 1) / NW;     // gate rows per wave (75 / 38)
+    constexpr int NGR = (JPW + 63) / 64;            // gate rows per lane in the gate stage (2 / 1)
+    constexpr int TB = 8;
+    constexpr int IN4 = 6 * GH / 4;     // staged per step: dy (GH) | r z n ghn (4 GH) | h_prev (GH)
+    constexpr int OUT4 = 6 * GH / 4;    // dgi (3 GH) | dgh (3 GH)
+    constexpr int NIN = (TB * IN4 + NTK - 1) / NTK;
+    __shared__ __attribute__((aligned(16))) float in_s[2][TB][6 * GH];
+    __shared__ __attribute__((aligned(16))) float out_s[TB][6 * GH];
+    __shared__ __attribute__((aligned(16))) float part[2][NW][PU];
+
+    int gidx = 0;
+    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
+    const int dir = blockIdx.y;
+    const int rows = G.rows[gidx];
+    const int T = G.T[gidx];
+    const int row = (int)blockIdx.x - G.slice0[gidx];
+    const float* __restrict__ dy = G.dy[gidx];
+    const float* __restrict__ y = G.y[gidx];
+    const float* __restrict__ gates = G.gates[gidx];
+    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
+    float* __restrict__ dgi = G.dgi[gidx];
+    float* __restrict__ dgh = G.dgh[gidx];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = JPW * wv;
+    // W_hh[j0 + jj][u] for the lane's two units u = lane, lane + 64 (< 100 for lane < 36); rows past 3H-1 carry zeros
+    const bool has1 = lane + 64 < GH;
+    f32x2 w[JPW];
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) {
+        const bool jok = j0 + jj < 3 * GH;
+        const int jc = jok ? j0 + jj : 3 * GH - 1;
+        w[jj][0] = jok ? w_hh[(int64_t)jc * GH + lane] : 0.f;
+        w[jj][1] = (jok && has1) ? w_hh[(int64_t)jc * GH + lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int jj = 0; jj < JPW; ++jj) pin_loaded(w[jj]);
+    // gate stage: lane l handles gate row j0 + l (and j0 + 64 + l when a wave owns more than 64 rows)
+    int jr[NGR], gg[NGR], uu[NGR];
+    bool has[NGR];
+    float dv[NGR], carry[NGR];          // dgh[jr] of the previously processed step; dh z of unit uu
+#pragma unroll
+    for (int q = 0; q < NGR; ++q) {
+        const int jl = 64 * q + lane;
+        has[q] = jl < JPW && j0 + jl < 3 * GH;
+        jr[q] = has[q] ? j0 + jl : 0;
+        gg[q] = jr[q] / GH;
+        uu[q] = jr[q] - gg[q] * GH;
+        dv[q] = 0.f;
+        carry[q] = 0.f;
+    }
+
+    const int nblocks = (T + TB - 1) / TB;
+    float4 stage[NIN];
+    auto load_block = [&](int b) {
+#pragma unroll
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NTK;
+            const int sl = idx / IN4;
+            const int c4 = idx - sl * IN4;
+            const int sidx = b * TB + sl;
+            stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sl < TB && sidx < T) {
+                const int t = dir ? sidx : T - 1 - sidx;
+                const int64_t o = (int64_t)t * rows + row;
+                if (c4 < GH / 4) {
+                    stage[e] = *reinterpret_cast<const float4*>(dy + o * (2 * GH) + dir * GH + 4 * c4);
+                } else if (c4 < 5 * GH / 4) {
+                    stage[e] = *reinterpret_cast<const float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4));
+                } else {
+                    const int tp = dir ? t + 1 : t - 1;   // the step that produced h_prev in the forward pass
+                    if (tp >= 0 && tp < T)
+                        stage[e] = *reinterpret_cast<const float4*>(y + ((int64_t)tp * rows + row) * (2 * GH) + dir * GH +
+                                                                    4 * (c4 - 5 * GH / 4));
+                }
+            }
+        }
+    };
+    auto stash_block = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < NIN; ++e) {
+            const int idx = tid + e * NTK;
+            if (idx < TB * IN4) *reinterpret_cast<float4*>(&in_s[buf][0][0] + 4 * idx) = stage[e];
+        }
+    };
+    auto flush_block = [&](int b) {
+        for (int idx = tid; idx < TB * OUT4; idx += NTK) {
+            const int sl = idx / OUT4;
+            const int c4 = idx - sl * OUT4;
+            const int sidx = b * TB + sl;
+            if (sidx >= T) continue;
+            const int t = dir ? sidx : T - 1 - sidx;
+            const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][4 * c4]);
+            const int64_t o = ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH;
+            if (c4 < 3 * GH / 4)
+                *reinterpret_cast<float4*>(dgi + o + 4 * c4) = v;
+            else
+                *reinterpret_cast<float4*>(dgh + o + 4 * (c4 - 3 * GH / 4)) = v;
+        }
+    };
+
+    load_block(0);
+    stash_block(0);
+    if (nblocks > 1) load_block(1);
+    __syncthreads();
+
+    int step = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        const int buf = b & 1;
+        for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
+            const int pb = step & 1;
+            // dh_prev partials of units (lane, lane + 64) over this wave's gate rows; dgh[j0 + jj] sits in lane jj % 64 of
+            // THIS wave (register dv[jj / 64])
+            f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < JPW; ++jj) {
+                const float dj = lane_bcast(dv[jj / 64], jj % 64);
+                const f32x2 dd = {dj, dj};
+                if (jj & 1) acc1 = __builtin_elementwise_fma(w[jj], dd, acc1);
+                else acc0 = __builtin_elementwise_fma(w[jj], dd, acc0);
+            }
+            part[pb][wv][lane] = acc0[0] + acc1[0];
+            part[pb][wv][lane + 64] = acc0[1] + acc1[1];       // (units >= 100 are padding)
+            __syncthreads();
+            const float* ip = &in_s[buf][sl][0];
+            float* orow = &out_s[sl][0];
+#pragma unroll
+            for (int q = 0; q < NGR; ++q) {
+                if (!has[q]) continue;
+                const int un = uu[q];
+                float rec = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) rec += part[pb][w2][un];     // fixed order
+                // the pre-activation gradient of gate row (g, u) from dh of unit u (every lane that shares the unit
+                // rebuilds the same dh and carries the same dh z)
+                const float dh = ip[un] + carry[q] + rec;
+                const float rr = ip[GH + un], zz = ip[2 * GH + un], nn = ip[3 * GH + un], ghn = ip[4 * GH + un], hprev = ip[5 * GH + un];
+                const float dn = dh * (1.0f - zz);
+                const float dz = dh * (hprev - nn);
+                carry[q] = dh * zz;
+                const float dnpre = dn * (1.0f - nn * nn);
+                const float drpre = dnpre * ghn * rr * (1.0f - rr);
+                const float dzpre = dz * zz * (1.0f - zz);
+                const float dghn = dnpre * rr;
+                const float gi_v = gg[q] == 0 ? drpre : (gg[q] == 1 ? dzpre : dnpre);
+                const float gh_v = gg[q] == 0 ? drpre : (gg[q] == 1 ? dzpre : dghn);
+                orow[jr[q]] = gi_v;
+                orow[3 * GH + jr[q]] = gh_v;
+                dv[q] = gh_v;
+            }
+        }
+        __syncthreads();
+        if (b + 1 < nblocks) stash_block(buf ^ 1);
+        flush_block(b);
+        if (b + 2 < nblocks) load_block(b + 2);
+        __syncthreads();
+    }
+}
+
+// one sequence per workgroup: waves per workgroup of the wave-partitioned kernels, 0 = the lane-pair kernels.  Measured
+// at cfg2 (profiles/r02_gru_kernels.md): forward lane-pair 80 us / 4 waves 102 / 8 waves 104; backward lane-pair 110 us /
+// 4 waves 126 / 8 waves 84.  The tuning build can force any of them (MMDFN_GRU_KPART_FWD / MMDFN_GRU_KPART_BWD).
+int kpart_waves(bool backward) {
+#ifdef MMDFN_TUNING
+    const char* e = getenv(backward ? "MMDFN_GRU_KPART_BWD" : "MMDFN_GRU_KPART_FWD");
+    if (e != nullptr) return atoi(e);
+#endif
+    return backward ? 8 : 0;
+}
+
 int pick_r(int ngroups, const int* rows) {
     for (int R : {1, 2, 4}) {
         int wg = 0;
@@ -426,7 +796,10 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
+    const int kw = R == 1 ? kpart_waves(false) : 0;
+    if (kw == 8) hipLaunchKernelGGL(gru_seq_fwd_kpart_kernel<8>, grid, dim3(512), 0, s, G);
+    else if (kw == 4) hipLaunchKernelGGL(gru_seq_fwd_kpart_kernel<4>, grid, dim3(256), 0, s, G);
+    else if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_fwd_kernel<4>, grid, block, 0, s, G);
     MMDFN_CHECK_LAUNCH();
@@ -451,7 +824,11 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
+    const int kw = R == 1 ? kpart_waves(true) : 0;
+    if (kw == 16) hipLaunchKernelGGL(gru_seq_bwd_kpart_kernel<16>, grid, dim3(1024), 0, s, G);
+    else if (kw == 8) hipLaunchKernelGGL(gru_seq_bwd_kpart_kernel<8>, grid, dim3(512), 0, s, G);
+    else if (kw == 4) hipLaunchKernelGGL(gru_seq_bwd_kpart_kernel<4>, grid, dim3(256), 0, s, G);
+    else if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_bwd_kernel<4>, grid, block, 0, s, G);
     MMDFN_CHECK_LAUNCH();
