@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_fwd_kpart_kernel(FwdGroups G)
     }
 }
 
-template <int NW>
+template <int NW, int GRP>
 __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G) {
     constexpr int NTK = 64 * NW;
     constexpr int JPW = (3 * GH + NW - 1) / NW;     // gate rows per wave (75 / 38)
@@ -709,13 +709,22 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
             const int pb = step & 1;
             // dh_prev partials of units (lane, lane + 64) over this wave's gate rows; dgh[j0 + jj] sits in lane jj % 64 of
             // THIS wave (register dv[jj / 64])
+            // (operands fetched four at a time: back-to-back v_readlane into distinct SGPRs, then the four FMAs -- a
+            // readlane directly followed by its consumer costs two wait states and serialises on one SGPR)
             f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
-            for (int jj = 0; jj < JPW; ++jj) {
-                const float dj = lane_bcast(dv[jj / 64], jj % 64);
-                const f32x2 dd = {dj, dj};
-                if (jj & 1) acc1 = __builtin_elementwise_fma(w[jj], dd, acc1);
-                else acc0 = __builtin_elementwise_fma(w[jj], dd, acc0);
+            for (int j4 = 0; j4 < JPW; j4 += GRP) {
+                float dj[GRP];
+#pragma unroll
+                for (int e = 0; e < GRP; ++e) dj[e] = (j4 + e < JPW) ? lane_bcast(dv[(j4 + e) / 64], (j4 + e) % 64) : 0.f;
+                if (GRP == 4) asm volatile("" : "+s"(dj[0]), "+s"(dj[GRP > 1 ? 1 : 0]), "+s"(dj[GRP > 2 ? 2 : 0]), "+s"(dj[GRP > 3 ? 3 : 0]));
+#pragma unroll
+                for (int e = 0; e < GRP; ++e) {
+                    if (j4 + e >= JPW) continue;
+                    const f32x2 dd = {dj[e], dj[e]};
+                    if ((j4 + e) & 1) acc1 = __builtin_elementwise_fma(w[j4 + e], dd, acc1);
+                    else acc0 = __builtin_elementwise_fma(w[j4 + e], dd, acc0);
+                }
             }
             part[pb][wv][lane] = acc0[0] + acc1[0];
             part[pb][wv][lane + 64] = acc0[1] + acc1[1];       // (units >= 100 are padding)
@@ -726,9 +735,14 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
             for (int q = 0; q < NGR; ++q) {
                 if (!has[q]) continue;
                 const int un = uu[q];
-                float rec = 0.f;
+                float pr[NW];
 #pragma unroll
-                for (int w2 = 0; w2 < NW; ++w2) rec += part[pb][w2][un];     // fixed order
+                for (int w2 = 0; w2 < NW; ++w2) pr[w2] = part[pb][w2][un];
+#pragma unroll
+                for (int sp = 1; sp < NW; sp *= 2)                         // fixed tree: bit-reproducible
+#pragma unroll
+                    for (int w2 = 0; w2 + sp < NW; w2 += 2 * sp) pr[w2] += pr[w2 + sp];
+                const float rec = pr[0];
                 // the pre-activation gradient of gate row (g, u) from dh of unit u (every lane that shares the unit
                 // rebuilds the same dh and carries the same dh z)
                 const float dh = ip[un] + carry[q] + rec;
@@ -825,9 +839,10 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
     const int kw = R == 1 ? kpart_waves(true) : 0;
-    if (kw == 16) hipLaunchKernelGGL(gru_seq_bwd_kpart_kernel<16>, grid, dim3(1024), 0, s, G);
-    else if (kw == 8) hipLaunchKernelGGL(gru_seq_bwd_kpart_kernel<8>, grid, dim3(512), 0, s, G);
-    else if (kw == 4) hipLaunchKernelGGL(gru_seq_bwd_kpart_kernel<4>, grid, dim3(256), 0, s, G);
+    if (kw == 16) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<16, 1>), grid, dim3(1024), 0, s, G);
+    else if (kw == 8) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
+    else if (kw == 81) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 1>), grid, dim3(512), 0, s, G);
+    else if (kw == 4) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<4, 1>), grid, dim3(256), 0, s, G);
     else if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_bwd_kernel<4>, grid, block, 0, s, G);
