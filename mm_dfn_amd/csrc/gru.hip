@@ -398,26 +398,21 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
 }
 
 // =====================================================================================================
-// One sequence per workgroup, contraction index PARTITIONED OVER THE WAVES, operands broadcast through SGPRs.
+// Backward pass, one sequence per workgroup: gate rows PARTITIONED OVER THE WAVES, operands broadcast through SGPRs.
 //
-// The kernels above deliver the broadcast vector (h / dgh) to every lane through LDS: 13 (forward) and 38 (backward)
-// ds_read_b128 per lane and step, i.e. 4 waves x 38 KB = 152 KB through the CU's 128 B/clk LDS return path per backward
-// step -- half of the measured step time -- and with the weight slices taking 156 VGPRs the compiler keeps only two of
-// those loads in flight.  Here each wave owns a quarter of the contraction index and produces its operands ITSELF:
-//   forward : wave w owns k in [25w, 25w+25).  Lane l accumulates the partial gate sums of rows j = l + 64q (q < 5,
-//             j < 300) over those 25 k -- h[k] comes from lane (k - 25w) of the same wave through v_readlane (an SGPR
-//             operand of the FMA: no LDS traffic, no load latency) -- and drops them in LDS; after ONE barrier lanes
-//             0..24 of wave w add the four partials of "their" units 25w + l, apply the gate math and keep h_new in a
-//             register, which is exactly what the wave's next matvec reads.
-//   backward: wave w owns gate rows j in [75w, 75w+75); lane l accumulates the partial dh_prev of units l and l + 64;
-//             after the barrier lane l < 75 rebuilds dh of unit (75w + l) mod 100 from the four partials and computes
-//             the one pre-activation gradient dgh[75w + l] its wave needs next (the carry dh z is replicated in the up
-//             to three lanes that share a unit: same inputs, same order, bit-identical).
-// LDS traffic per step: 1.2 KB (forward) / 0.5 KB (backward) of partials per wave instead of 13 KB / 38 KB; weight
-// slices 125 / 150 VGPRs.  Same time-blocked global staging as above.  Used when every sequence gets its own workgroup
-// in one round (pick_r() == 1); larger batches keep the R = 2 / 4 kernels.
+// The lane-pair kernel above delivers the 300-entry dgh vector to every lane through LDS: 38 ds_read_b128 per lane and
+// step, i.e. 4 waves x 38 KB = 152 KB through the CU's 128 B/clk LDS return path -- half of the measured step time -- and
+// with the weight slices taking 152 VGPRs the compiler keeps only two of those loads in flight.  Here each wave owns a
+// slice of the gate rows and produces its operands ITSELF: wave w owns rows j in [38w, 38w+38); lane l accumulates the
+// partial dh_prev of units l and l + 64 over those rows -- dgh[j] comes from lane (j - 38w) of the same wave through
+// v_readlane (an SGPR operand of the FMA: no LDS traffic, no load latency) -- and drops the two partials in LDS; after ONE
+// barrier lane l < 38 rebuilds dh of unit (38w + l) mod 100 from the eight partials and computes the one pre-activation
+// gradient dgh[38w + l] its wave needs next (the carry dh z is replicated in the up to three lanes that share a unit:
+// same inputs, same order, bit-identical).  LDS traffic per step: 0.5 KB of partials per wave; weight slices 76 VGPRs;
+// eight waves = two per SIMD (one wave per SIMD runs at ~10 cycles per instruction on this chain whatever the mix).
+// Same time-blocked global staging as above.  Used when every sequence gets its own workgroup in one round
+// (pick_r() == 1); larger batches keep the R = 2 / 4 kernels.  Variants and measurements: profiles/r02_gru_kernels.md.
 // =====================================================================================================
-constexpr int PJ = 320;              // partial-sum row length, forward (300 gate rows, padded)
 constexpr int PU = 128;              // partial-sum row length, backward (100 units, padded)
 
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
@@ -435,164 +430,8 @@ __device__ __forceinline__ void pin_loaded(f32x2& v) {
 }
 __device__ __forceinline__ void pin_loaded(float& v) { asm volatile("" : "+v"(v)); }
 
-// NW waves per workgroup (4: one per SIMD; 8: two per SIMD, half the instructions per wave and a second wave to issue
-// from while the first waits on a dependent result)
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void gru_seq_fwd_kpart_kernel(FwdGroups G) {
-    constexpr int NTK = 64 * NW;
-    constexpr int KPW = (GH + NW - 1) / NW;         // contraction indices per wave (25 / 13)
-    constexpr int TB = 8;
-    constexpr int IN4 = 3 * GH / 4;
-    constexpr int OUT4 = 5 * GH / 4;
-    constexpr int NIN = (TB * IN4 + NTK - 1) / NTK;
-    __shared__ __attribute__((aligned(16))) float in_s[2][TB][3 * GH];
-    __shared__ __attribute__((aligned(16))) float out_s[TB][5 * GH];
-    __shared__ __attribute__((aligned(16))) float part[2][NW][PJ];
-
-    int gidx = 0;
-    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-    const int dir = blockIdx.y;
-    const int rows = G.rows[gidx];
-    const int T = G.T[gidx];
-    const int row = (int)blockIdx.x - G.slice0[gidx];
-    const float* __restrict__ gi = G.gi[gidx];
-    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
-    const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
-    float* __restrict__ y = G.y[gidx];
-    float* __restrict__ gates = G.gates[gidx];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int k0 = KPW * wv;
-    // W_hh[j][k0 + kk] for j = lane + 64 q: rows (q0, q1) and (q2, q3) as packed pairs, q4 (j < 300 for lane < 44) alone;
-    // contraction indices past H-1 (last wave when NW does not divide H) carry zero weights
-    f32x2 w01[KPW], w23[KPW];
-    float w4[KPW];
-    const bool has4 = lane + 256 < 3 * GH;
-#pragma unroll
-    for (int kk = 0; kk < KPW; ++kk) {
-        const int k = k0 + kk;
-        const bool kok = k < GH;
-        const int kc = kok ? k : GH - 1;
-        w01[kk][0] = kok ? w_hh[(int64_t)(lane) * GH + kc] : 0.f;
-        w01[kk][1] = kok ? w_hh[(int64_t)(lane + 64) * GH + kc] : 0.f;
-        w23[kk][0] = kok ? w_hh[(int64_t)(lane + 128) * GH + kc] : 0.f;
-        w23[kk][1] = kok ? w_hh[(int64_t)(lane + 192) * GH + kc] : 0.f;
-        w4[kk] = (kok && has4) ? w_hh[(int64_t)(lane + 256) * GH + kc] : 0.f;
-    }
-#pragma unroll
-    for (int kk = 0; kk < KPW; ++kk) {
-        pin_loaded(w01[kk]);
-        pin_loaded(w23[kk]);
-        pin_loaded(w4[kk]);
-    }
-    // gate stage: lanes 0..KPW-1 of wave wv own units k0 + lane
-    const bool owner = lane < KPW && k0 + lane < GH;
-    const int u = owner ? k0 + lane : 0;
-    float bhr = b_hh[u], bhz = b_hh[GH + u], bhn = b_hh[2 * GH + u];
-    pin_loaded(bhr);
-    pin_loaded(bhz);
-    pin_loaded(bhn);
-    float hv = 0.f;                       // h_{t-1}[u] of the owner lanes: the wave's matvec operand (via v_readlane)
-
-    const int nblocks = (T + TB - 1) / TB;
-    float4 stage[NIN];
-    auto load_block = [&](int b) {
-#pragma unroll
-        for (int e = 0; e < NIN; ++e) {
-            const int idx = tid + e * NTK;
-            const int sl = idx / IN4;
-            const int c4 = idx - sl * IN4;
-            const int sidx = b * TB + sl;
-            stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sl < TB && sidx < T) {
-                const int t = dir ? T - 1 - sidx : sidx;
-                stage[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH + 4 * c4);
-            }
-        }
-    };
-    auto stash_block = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < NIN; ++e) {
-            const int idx = tid + e * NTK;
-            if (idx < TB * IN4) *reinterpret_cast<float4*>(&in_s[buf][0][0] + 4 * idx) = stage[e];
-        }
-    };
-    auto flush_block = [&](int b) {
-        for (int idx = tid; idx < TB * OUT4; idx += NTK) {
-            const int sl = idx / OUT4;
-            const int c4 = idx - sl * OUT4;
-            const int sidx = b * TB + sl;
-            if (sidx >= T) continue;
-            const int t = dir ? T - 1 - sidx : sidx;
-            const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][4 * c4]);
-            const int64_t o = (int64_t)t * rows + row;
-            if (c4 < GH / 4)
-                *reinterpret_cast<float4*>(y + o * (2 * GH) + dir * GH + 4 * c4) = v;
-            else
-                *reinterpret_cast<float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4)) = v;
-        }
-    };
-
-    load_block(0);
-    stash_block(0);
-    if (nblocks > 1) load_block(1);
-    __syncthreads();
-
-    int step = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        const int buf = b & 1;
-        for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
-            const int pb = step & 1;
-            f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-            float a4 = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < KPW; ++kk) {
-                const float hk = lane_bcast(hv, kk);           // h_{t-1}[k0 + kk]: wave-uniform, an SGPR operand
-                const f32x2 hh = {hk, hk};
-                a01 = __builtin_elementwise_fma(w01[kk], hh, a01);
-                a23 = __builtin_elementwise_fma(w23[kk], hh, a23);
-                a4 = __builtin_fmaf(w4[kk], hk, a4);
-            }
-            float* pp = &part[pb][wv][lane];
-            pp[0] = a01[0];
-            pp[64] = a01[1];
-            pp[128] = a23[0];
-            pp[192] = a23[1];
-            pp[256] = a4;                                      // (columns >= 300 are padding)
-            __syncthreads();
-            if (owner) {
-                float ar = 0.f, az = 0.f, an = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {                 // fixed order: bit-reproducible
-                    const float* p0 = &part[pb][w][u];
-                    ar += p0[0];
-                    az += p0[GH];
-                    an += p0[2 * GH];
-                }
-                const float* gp = &in_s[buf][sl][u];
-                const float ghn = an + bhn;
-                const float rr = sigmoidf_(gp[0] + ar + bhr);
-                const float zz = sigmoidf_(gp[GH] + az + bhz);
-                const float nn = tanhf_(gp[2 * GH] + rr * ghn);
-                const float hnew = (1.0f - zz) * nn + zz * hv;
-                float* op = &out_s[sl][u];
-                op[0] = hnew;
-                op[GH] = rr;
-                op[2 * GH] = zz;
-                op[3 * GH] = nn;
-                op[4 * GH] = ghn;
-                hv = hnew;
-            }
-            // no second barrier: the next step writes the OTHER partial buffer, and nobody can be two steps ahead
-        }
-        __syncthreads();                                   // the block's results are complete in out_s
-        if (b + 1 < nblocks) stash_block(buf ^ 1);
-        flush_block(b);
-        if (b + 2 < nblocks) load_block(b + 2);
-        __syncthreads();
-    }
-}
-
+// NW waves per workgroup (8: two per SIMD, half the instructions per wave and a second wave to issue from while the
+// first waits on a dependent result); GRP operands are fetched per group of FMAs
 template <int NW, int GRP>
 __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G) {
     constexpr int NTK = 64 * NW;
@@ -769,15 +608,16 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     }
 }
 
-// one sequence per workgroup: waves per workgroup of the wave-partitioned kernels, 0 = the lane-pair kernels.  Measured
-// at cfg2 (profiles/r02_gru_kernels.md): forward lane-pair 80 us / 4 waves 102 / 8 waves 104; backward lane-pair 110 us /
-// 4 waves 126 / 8 waves 84.  The tuning build can force any of them (MMDFN_GRU_KPART_FWD / MMDFN_GRU_KPART_BWD).
-int kpart_waves(bool backward) {
+// one sequence per workgroup, backward pass: the wave-partitioned kernel (8 waves) unless the tuning build asks for the
+// lane-pair one (MMDFN_GRU_KPART_BWD=0) for A/B runs.  Measured at cfg2 (profiles/r02_gru_kernels.md): lane-pair 110 us,
+// partitioned over 4 waves 126, over 8 waves 84, over 16 waves ~125.  The forward pass keeps the lane-pair kernel (80 us;
+// its wave-partitioned forms 102-104 us, a lane-quad form on 8 waves 80 us).
+bool use_kpart_bwd() {
 #ifdef MMDFN_TUNING
-    const char* e = getenv(backward ? "MMDFN_GRU_KPART_BWD" : "MMDFN_GRU_KPART_FWD");
-    if (e != nullptr) return atoi(e);
+    const char* e = getenv("MMDFN_GRU_KPART_BWD");
+    if (e != nullptr) return e[0] != '0';
 #endif
-    return backward ? 8 : 0;
+    return true;
 }
 
 int pick_r(int ngroups, const int* rows) {
@@ -810,10 +650,7 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    const int kw = R == 1 ? kpart_waves(false) : 0;
-    if (kw == 8) hipLaunchKernelGGL(gru_seq_fwd_kpart_kernel<8>, grid, dim3(512), 0, s, G);
-    else if (kw == 4) hipLaunchKernelGGL(gru_seq_fwd_kpart_kernel<4>, grid, dim3(256), 0, s, G);
-    else if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
+    if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_fwd_kernel<4>, grid, block, 0, s, G);
     MMDFN_CHECK_LAUNCH();
@@ -838,11 +675,7 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    const int kw = R == 1 ? kpart_waves(true) : 0;
-    if (kw == 16) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<16, 1>), grid, dim3(1024), 0, s, G);
-    else if (kw == 8) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
-    else if (kw == 81) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 1>), grid, dim3(512), 0, s, G);
-    else if (kw == 4) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<4, 1>), grid, dim3(256), 0, s, G);
+    if (R == 1 && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
     else if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_bwd_kernel<4>, grid, block, 0, s, G);
