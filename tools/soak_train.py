@@ -1,4 +1,4 @@
-"""Soak: many eager training steps on ragged synthetic data (every batch a new shape): finite losses, decreasing
+"""Soak (SOAK_FLAT_ADAM=1: fused optimizer; SOAK_GRAPH=1: captured-step cache): many training steps on ragged synthetic data (every batch a new shape): finite losses, decreasing
 training loss, bounded device memory (no per-shape leak: DialogueLayout cache is capped, graph pools are not used)."""
 import os, sys, time, tempfile
 import torch
@@ -19,7 +19,8 @@ hist = []
 def log(msg):
     hist.append(msg)
 out = T.fit(m, FocalLoss(gamma=0.5), opt, D.DevicePrefetcher(tr), D.DevicePrefetcher(va), D.DevicePrefetcher(te),
-            n_epochs=epochs, patience=10 ** 6, valid_rate=0.1, log=log)
+            n_epochs=epochs, patience=10 ** 6, valid_rate=0.1, log=log,
+            graph_cache=True if os.environ.get("SOAK_GRAPH") else None)
 torch.cuda.synchronize()
 h = out["history"]
 mem = torch.cuda.max_memory_allocated() / 2 ** 20
