@@ -71,6 +71,9 @@ class _EdgeAttentionParams(nn.Module):
         self.att = _MlpAttention(dim)
 
 
+PROJECT_THEN_GATHER_ROWS = 12000
+
+
 class DialogueGNNModel(nn.Module):
 
     def __init__(self, base_model, D_m, D_g, D_p, D_e, D_h, D_a, graph_hidden_size, n_speakers, max_seq_len,
@@ -171,12 +174,13 @@ class DialogueGNNModel(nn.Module):
             Xs = [Xa, Xv, Xl]
             act = [x for x, w in zip(Xs, self.speaker_weights) if w != 0.0]
             P = qmask.shape[2]
-            if act and (len(act) * L * B * P >= 12000 or P >= 4):
+            if act and (len(act) * L * B * P >= PROJECT_THEN_GATHER_ROWS or P >= 4):
                 # first party-GRU layer: gather(X) W_ih^T + b == gather(X W_ih^T) + b (padding rows = b), so the input
                 # contraction runs over the n_act*L*B projected utterances, not over the n_act*L*P*B party rows of
                 # which all but one in P are zero (the reference projects every padded party row, model.py:1082).
                 # Pays off once the party batch is large (measured: cfg4 2.27 -> 2.22 ms, cfg3 2.25 -> 2.19 ms; at
-                # cfg2's 7040 party rows the three extra small launches cost more than the halved GEMMs save)
+                # cfg2's 7040 party rows the extra small launches cost more than the halved GEMMs save: 1.146 vs
+                # 1.125 ms per step, tools/ab_project_then_gather.py, round 2)
                 w_ih, b_ih, _ = fused_gru._layer_params(self.rnn_parties, 0)
                 G = ops.linear2(torch.stack(act, 0), w_ih[0], w_ih[1], None, None)
                 gi_p, rank = ops.party_gather(G, qmask, bias=torch.cat(b_ih))

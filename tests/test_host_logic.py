@@ -225,3 +225,55 @@ def test_flag_pool_shares_one_draw_per_step():
         x = ops.keep_flags(1001, 0.5, dev)
         big = ops.keep_flags(5000, 0.5, dev)
     assert big.shape == (5000,) and big.untyped_storage().data_ptr() != x.untyped_storage().data_ptr()
+
+
+def test_bucket_order_keeps_gru_direction_pairs_adjacent_and_flat_views_stack():
+    """distributed.bucket_order: every weight_ih / bias_ih parameter of a bidirectional GRU is directly followed by its
+    *_reverse twin (FlatAdam lays its flat buffer out in this order), so gru._stacked_view can hand the fused path ONE
+    (600, K) operand without a copy; non-adjacent CPU parameters are never re-pointed (None -> the copying path)."""
+    import torch
+    from mm_dfn_amd import distributed, gru, synthetic
+    cfg = dict(synthetic.CONFIGS["cfg1"]) if "cfg1" in synthetic.CONFIGS else dict(B=2, L=8, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+    m = synthetic.build_model(dropout=0.0, **cfg)
+    live = [p for p in m.parameters()]
+    order = distributed.bucket_order(m, live)
+    names = {id(p): n for n, p in m.named_parameters()}
+    ns = [names[id(p)] for p in order]
+    assert sorted(ns) == sorted(names.values()) and len(set(ns)) == len(ns)
+    pairs = 0
+    for i, n in enumerate(ns):
+        if (".weight_ih_l" in "." + n or ".bias_ih_l" in "." + n) and not n.endswith("_reverse") and n + "_reverse" in ns:
+            assert ns[i + 1] == n + "_reverse", (n, ns[i + 1])
+            pairs += 1
+    assert pairs >= 8            # two GRUs x two layers x (weight, bias)
+    # a flat buffer in that order makes the pairs adjacent
+    flat = torch.cat([p.detach().reshape(-1) for p in order])
+    off = 0
+    views = {}
+    for p in order:
+        views[names[id(p)]] = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    wf, wr = views["lstm_l.weight_ih_l0"], views["lstm_l.weight_ih_l0_reverse"]
+    assert gru._adjacent(wf, wr)
+    sv = gru._stacked_view(wf, wr)
+    assert sv.shape == (600, wf.shape[1]) and torch.equal(sv, torch.cat([wf, wr], 0)) and sv.data_ptr() == wf.data_ptr()
+    bf, br = views["lstm_l.bias_ih_l0"], views["lstm_l.bias_ih_l0_reverse"]
+    assert torch.equal(gru._stacked_view(bf, br), torch.cat([bf, br], 0))
+    # the module's own (separately allocated, CPU) parameters: not adjacent, and not re-pointed on the CPU
+    before = m.lstm_l.weight_ih_l0.data_ptr()
+    assert gru._stacked_view(m.lstm_l.weight_ih_l0, m.lstm_l.weight_ih_l0_reverse) is None
+    assert m.lstm_l.weight_ih_l0.data_ptr() == before
+
+
+def test_backward_with_cached_unit_seed_matches_plain_backward():
+    import torch
+    from mm_dfn_amd import train
+    w = torch.randn(5, requires_grad=True)
+    (w * w).sum().backward()
+    g0 = w.grad.clone()
+    w.grad = None
+    train.backward((w * w).sum())
+    assert torch.equal(w.grad, g0)
+    w.grad = None
+    train.backward((w * w).sum())            # second call: the cached seed
+    assert torch.equal(w.grad, g0)
