@@ -441,6 +441,17 @@ def test_weight_gradient_batch_kernel():
     out = torch.empty(100, 200, device=DEV)
     ops._launch_wgrad_batch([(dict(M=100, N=200), out, [], 0, [(a2, b2, -16)])])
     assert rel_err(out, a2[16:].double().cpu().t() @ b2[:-16].double().cpu()) < 1e-5
+    # ragged sizes: partial tiles on both axes, row counts that are not multiples of the 32-row chunk, shifts, column
+    # sums from the first column tile only
+    for (Mo, No, Rr, sh) in [(36, 36, 70, 0), (100, 104, 333, 3), (52, 112, 1, 0), (300, 116, 257, -2), (64, 212, 999, 0),
+                             (600, 224, 2050, 5), (44, 228, 96, 0)]:
+        a3, b3 = t(Rr, Mo + 8)[:, 4:4 + Mo], t(Rr, No)
+        o3, c3 = torch.empty(Mo, No, device=DEV), torch.empty(Mo, device=DEV)
+        ops._launch_wgrad_batch([(dict(M=Mo, N=No), o3, [c3], 0, [(a3, b3, sh)])])
+        Ad, Bd = a3.double().cpu(), b3.double().cpu()
+        want = (Ad[:Rr - sh].t() @ Bd[sh:]) if sh >= 0 else (Ad[-sh:].t() @ Bd[:Rr + sh])
+        assert rel_err(o3, want) < 1e-5, (Mo, No, Rr, sh)
+        assert rel_err(c3, Ad.sum(0)) < 1e-5, (Mo, No, Rr, sh)
 
 
 @pytest.mark.parametrize("R,K,n1,n2", [(300, 200, 300, 300), (7040, 200, 300, 300), (129, 36, 4, 100), (2000, 100, 260, 52)])
