@@ -89,12 +89,14 @@ int mmdfn_adj_build(const float* feats, float* unit, float* norm, float* cosg, f
 /* Backward of mmdfn_adj_build: given dtiles / dcross (gradients of the stored
  * entries) produce dfeats (M, N, D).  `wsym` (tile-shaped), `etile`
  * (tile-shaped), `ecross` (npairs, N), `ddeg` (M, N) and `dunit` (M, N, D) are
- * caller-provided scratch. */
+ * caller-provided scratch.  * addend (mmdfn_adj_build_bwd, may be NULL): (M, N, D) gradient reaching the same features on another path (they are
+ *   also the input of the GCN stack); dfeats = adjacency gradient + addend, so no separate accumulation launch runs.
+ */
 int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross,
                         const float* unit, const float* norm, const float* cosg, const float* cdot,
                         const float* rdeg, const float* tiles, const float* cross,
                         float* wsym, float* etile, float* ecross, float* ddeg, float* dunit,
-                        float* dfeats,
+                        float* dfeats, const float* addend,
                         const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                         int B, int M, int N, int D, int max_len, float modal_weight, void* stream);
 

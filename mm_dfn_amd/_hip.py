@@ -21,7 +21,7 @@ SIGNATURES = {
     "mmdfn_propagate": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_tile_outer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_adj_build": [_P] * 8 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
-    "mmdfn_adj_build_bwd": [_P] * 15 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
+    "mmdfn_adj_build_bwd": [_P] * 16 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
     "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "mmdfn_lstm_pointwise_fwd": [_P, _P, _P, _P, _L, _I, _P],
@@ -55,7 +55,7 @@ SIGNATURES = {
     "mmdfn_mask_scale": [_I, _P, _P, _P, _P, _F, _P],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipLibraryError(RuntimeError):

@@ -263,10 +263,10 @@ __global__ __launch_bounds__(256) void bwd_etile_kernel(const float* __restrict_
     }
 }
 
-// dX = (du - u (u.du)) / ||x||   -- one wave per (m, row)
+// dX = (du - u (u.du)) / ||x||  (+ addend)   -- one wave per (m, row)
 __global__ __launch_bounds__(256) void unit_bwd_kernel(const float* __restrict__ unit, const float* __restrict__ norm,
-                                                       const float* __restrict__ dunit, float* __restrict__ dfeats,
-                                                       int64_t rows, int D) {
+                                                       const float* __restrict__ dunit, const float* __restrict__ addend,
+                                                       float* __restrict__ dfeats, int64_t rows, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -276,7 +276,12 @@ __global__ __launch_bounds__(256) void unit_bwd_kernel(const float* __restrict__
     for (int k = lane; k < D; k += 64) s += u[k] * du[k];
     s = wave_sum(s);
     const float inv = 1.0f / norm[row];
-    for (int k = lane; k < D; k += 64) dfeats[row * D + k] = (du[k] - u[k] * s) * inv;
+    // addend: the gradient that reaches the same features on their other path (they are also the input of the GCN
+    // stack); added here instead of by an autograd accumulation launch
+    if (addend)
+        for (int k = lane; k < D; k += 64) dfeats[row * D + k] = (du[k] - u[k] * s) * inv + addend[row * D + k];
+    else
+        for (int k = lane; k < D; k += 64) dfeats[row * D + k] = (du[k] - u[k] * s) * inv;
 }
 
 }  // namespace
@@ -307,9 +312,9 @@ extern "C" int mmdfn_adj_build(const float* feats, float* unit, float* norm, flo
 extern "C" int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross, const float* unit, const float* norm,
                                    const float* cosg, const float* cdot, const float* rdeg, const float* tiles,
                                    const float* cross, float* wsym, float* etile, float* ecross, float* ddeg,
-                                   float* dunit, float* dfeats, const int32_t* dia_len, const int32_t* row_start,
-                                   const int64_t* tile_base, int B, int M, int N, int D, int max_len,
-                                   float modal_weight, void* stream) {
+                                   float* dunit, float* dfeats, const float* addend, const int32_t* dia_len,
+                                   const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int D,
+                                   int max_len, float modal_weight, void* stream) {
     (void)tiles;
     (void)cross;
     if (B <= 0 || M <= 0 || M > MAXM || N <= 0 || D <= 0 || (D & 3) || max_len <= 0) return -1;
@@ -329,7 +334,7 @@ extern "C" int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross, con
                                     0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(unit_bwd_kernel, dim3((unsigned)(((int64_t)M * N + 3) / 4)), dim3(256), 0, s, unit, norm,
-                       dunit, dfeats, (int64_t)M * N, D);
+                       dunit, addend, dfeats, (int64_t)M * N, D);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -83,9 +83,9 @@ def propagate(adj, H):
 
 class _BuildAdjacency(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, lay, modal_weight):
-        _hip.require_cuda(feats)
-        feats = feats.contiguous()
+    def forward(ctx, feats_in, lay, modal_weight):
+        _hip.require_cuda(feats_in)
+        feats = feats_in.contiguous()
         M, N, D = feats.shape
         dev = feats.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -104,11 +104,16 @@ class _BuildAdjacency(torch.autograd.Function):
         ctx.lay = lay
         ctx.modal_weight = float(modal_weight)
         ctx.save_for_backward(unit, norm, cosg, cdot, rdeg, tiles, cross)
-        return tiles, cross
+        ctx.set_materialize_grads(False)
+        # the features come back as a third output (an identity): the GCN stack reads THAT, so the features have one
+        # consumer and their two gradient paths meet inside this node's backward kernel instead of in an autograd add
+        return tiles, cross, feats_in
 
     @staticmethod
-    def backward(ctx, dtiles, dcross):
+    def backward(ctx, dtiles, dcross, dalias):
         unit, norm, cosg, cdot, rdeg, tiles, cross = ctx.saved_tensors
+        if dtiles is None and dcross is None:
+            return dalias, None, None
         lay = ctx.lay
         M, N, D = unit.shape
         f32 = dict(dtype=torch.float32, device=unit.device)
@@ -120,10 +125,12 @@ class _BuildAdjacency(torch.autograd.Function):
         ddeg = torch.empty(M, N, **f32)
         dunit = torch.empty_like(unit)
         dfeats = torch.empty_like(unit)
+        addend = dalias.contiguous() if dalias is not None else None
         rc = _hip.lib().mmdfn_adj_build_bwd(_hip.ptr(dtiles), _hip.ptr(dcross), _hip.ptr(unit), _hip.ptr(norm),
                                             _hip.ptr(cosg), _hip.ptr(cdot), _hip.ptr(rdeg), _hip.ptr(tiles),
                                             _hip.ptr(cross), _hip.ptr(wsym), _hip.ptr(etile), _hip.ptr(ecross),
-                                            _hip.ptr(ddeg), _hip.ptr(dunit), _hip.ptr(dfeats), *_lay_args(lay),
+                                            _hip.ptr(ddeg), _hip.ptr(dunit), _hip.ptr(dfeats), _hip.ptr(addend),
+                                            *_lay_args(lay),
                                             lay.B, M, N, D, lay.max_len, ctx.modal_weight, _hip.stream())
         _hip.check(rc, "mmdfn_adj_build_bwd")
         return dfeats, None, None
@@ -137,7 +144,7 @@ def build_adjacency(feats, lengths, modal_weight=1.0):
         raise ValueError("sum(dia_len)=%d does not match %d feature rows" % (lay.N, feats.shape[1]))
     if feats.shape[2] % 4:
         raise ValueError("feature width must be a multiple of 4 for the HIP path")
-    tiles, cross = _BuildAdjacency.apply(feats, lay, modal_weight)
+    tiles, cross, feats = _BuildAdjacency.apply(feats, lay, modal_weight)
     return BlockTileAdjacency(lay, tiles, cross, symmetric=True, stacked_feats=feats)
 
 
