@@ -675,7 +675,9 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    if (R == 1 && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
+    // (the 8-wave kernel runs one workgroup per CU: it wins while all sequences fit in one round; beyond that the lane-pair
+    // kernel, two workgroups per CU, keeps the batch in one round -- cfg4: 320 workgroups, 1.75 vs 1.69 ms per step)
+    if (R == 1 && 2 * sl <= 256 && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
     else if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_bwd_kernel<4>, grid, block, 0, s, G);
