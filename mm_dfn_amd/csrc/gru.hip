@@ -60,6 +60,17 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// A use of a freshly loaded register BEFORE the time loop.  Without it the compiler sinks loop-invariant global loads to
+// their first use and plants their s_waitcnt vmcnt(N) inside the step loop, where -- vector memory operations retire in
+// order and the counter also counts stores -- every later trip would wait for the previous block's result stores.
+__device__ __forceinline__ void pin_loaded(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_loaded(f32x2& v) {
+    float a = v[0], b = v[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+    v[0] = a;
+    v[1] = b;
+}
+
 // exchange with the other lane of the pair (lane ^ 1): one DPP quad_perm [1,0,3,2] move instead of a
 // ds_bpermute round trip through the LDS crossbar
 __device__ __forceinline__ float pair_swap(float v) {
@@ -123,7 +134,16 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
         wz[k >> 1][k & 1] = ok ? w_hh[(int64_t)(1 * GH + uu) * GH + kk] : 0.f;
         wn[k >> 1][k & 1] = ok ? w_hh[(int64_t)(2 * GH + uu) * GH + kk] : 0.f;
     }
-    const float bhr = b_hh[uu], bhz = b_hh[GH + uu], bhn = b_hh[2 * GH + uu];
+#pragma unroll
+    for (int k = 0; k < KW / 2; ++k) {
+        pin_loaded(wr[k]);
+        pin_loaded(wz[k]);
+        pin_loaded(wn[k]);
+    }
+    float bhr = b_hh[uu], bhz = b_hh[GH + uu], bhn = b_hh[2 * GH + uu];
+    pin_loaded(bhr);
+    pin_loaded(bhz);
+    pin_loaded(bhn);
 
     float hprev[R];
     bool mine[R];
@@ -182,11 +202,42 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     if (nblocks > 1) load_block(1);
     __syncthreads();
 
+    // LDS traffic of a step that is NOT the recurrence itself is kept off its critical path (timing ablations,
+    // profiles/r02_gru_kernels.md: these eight accesses cost as much as the 78 packed FMAs when they sit between the matvec
+    // and the barrier):
+    //   * the step's three input-gate operands are read at the TOP of the step, under the matvec, not behind it;
+    //   * the five result values (y, r, z, n, W_hn h) of step s are written AFTER the barrier of step s, at the top of
+    //     step s + 1 (they stay in registers across the barrier), so the barrier only waits for the one write it exists
+    //     for (h -> LDS).  The block's last step writes them before the block-boundary barrier.
+    float pend[R][5];
+    bool have_pend = false;
+    int pend_sl = 0;
+    auto write_pending = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (mine[r]) {
+                float* op = &out_s[pend_sl][r][u];
+                op[0] = pend[r][0];
+                op[GH] = pend[r][1];
+                op[2 * GH] = pend[r][2];
+                op[3 * GH] = pend[r][3];
+                op[4 * GH] = pend[r][4];
+            }
+    };
     int step = 0;
     for (int b = 0; b < nblocks; ++b) {
         const int buf = b & 1;
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int cur = step & 1;
+            if (have_pend) write_pending();
+            float g0[R], g1[R], g2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float* gp = &in_s[buf][sl][r][uu];
+                g0[r] = gp[0];
+                g1[r] = gp[GH];
+                g2[r] = gp[2 * GH];
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 f32x2 ar0 = {0.f, 0.f}, az0 = {0.f, 0.f}, an0 = {0.f, 0.f}, ar1 = {0.f, 0.f}, az1 = {0.f, 0.f}, an1 = {0.f, 0.f};
@@ -209,25 +260,28 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
                 ar += pair_swap(ar);
                 az += pair_swap(az);
                 an += pair_swap(an);
-                if (mine[r]) {
-                    const float* gp = &in_s[buf][sl][r][u];
+                {   // (every lane does the gate math -- a conditional would pull the operand reads back behind the matvec)
                     const float ghn = an + bhn;
-                    const float rr = sigmoidf_(gp[0] + ar + bhr);
-                    const float zz = sigmoidf_(gp[GH] + az + bhz);
-                    const float nn = tanhf_(gp[2 * GH] + rr * ghn);
+                    const float rr = sigmoidf_(g0[r] + ar + bhr);
+                    const float zz = sigmoidf_(g1[r] + az + bhz);
+                    const float nn = tanhf_(g2[r] + rr * ghn);
                     const float hnew = (1.0f - zz) * nn + zz * hprev[r];
-                    float* op = &out_s[sl][r][u];
-                    op[0] = hnew;
-                    op[GH] = rr;
-                    op[2 * GH] = zz;
-                    op[3 * GH] = nn;
-                    op[4 * GH] = ghn;
-                    hs[cur ^ 1][r][u] = hnew;
+                    if (mine[r]) hs[cur ^ 1][r][u] = hnew;
                     hprev[r] = hnew;
+                    pend[r][0] = hnew;
+                    pend[r][1] = rr;
+                    pend[r][2] = zz;
+                    pend[r][3] = nn;
+                    pend[r][4] = ghn;
                 }
             }
+            have_pend = true;
+            pend_sl = sl;
             __syncthreads();
         }
+        if (have_pend) write_pending();
+        have_pend = false;
+        __syncthreads();                        // the block's results are complete in out_s
         // block boundary: next block's operands (loaded a block ago) drop into LDS, this block's results
         // leave, and the loads of block b+2 are issued
         if (b + 1 < nblocks) stash_block(buf ^ 1);
@@ -275,6 +329,8 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     f32x2 w[JW / 2];
 #pragma unroll
     for (int j = 0; j < JW; ++j) w[j >> 1][j & 1] = (j < jlen) ? w_hh[(int64_t)(jbase + (j < jlen ? j : 0)) * GH + uu] : 0.f;
+#pragma unroll
+    for (int j = 0; j < JW / 2; ++j) pin_loaded(w[j]);
 
     bool mine[R];
     float carry[R];
@@ -419,16 +475,6 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// A use of a freshly loaded weight pair BEFORE the time loop.  Without it the compiler sinks the weight loads to the loop
-// entry and plants their s_waitcnt vmcnt(N) inside the step loop, where -- vector memory operations retire in order and
-// the counter also counts stores -- every later trip would wait for the previous block's result stores.
-__device__ __forceinline__ void pin_loaded(f32x2& v) {
-    float a = v[0], b = v[1];
-    asm volatile("" : "+v"(a), "+v"(b));
-    v[0] = a;
-    v[1] = b;
-}
-__device__ __forceinline__ void pin_loaded(float& v) { asm volatile("" : "+v"(v)); }
 
 // NW waves per workgroup (8: two per SIMD, half the instructions per wave and a second wave to issue from while the
 // first waits on a dependent result); GRP operands are fetched per group of FMAs
@@ -548,6 +594,13 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
             const int pb = step & 1;
             // dh_prev partials of units (lane, lane + 64) over this wave's gate rows; dgh[j0 + jj] sits in lane jj % 64 of
             // THIS wave (register dv[jj / 64])
+            // the step's staged operands of this lane's gate rows, read under the matvec instead of behind the barrier
+            const float* ip = &in_s[buf][sl][0];
+            float iv[NGR][6];
+#pragma unroll
+            for (int q = 0; q < NGR; ++q)
+#pragma unroll
+                for (int e = 0; e < 6; ++e) iv[q][e] = ip[e * GH + uu[q]];
             // (operands fetched four at a time: back-to-back v_readlane into distinct SGPRs, then the four FMAs -- a
             // readlane directly followed by its consumer costs two wait states and serialises on one SGPR)
             f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
@@ -568,11 +621,9 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
             part[pb][wv][lane] = acc0[0] + acc1[0];
             part[pb][wv][lane + 64] = acc0[1] + acc1[1];       // (units >= 100 are padding)
             __syncthreads();
-            const float* ip = &in_s[buf][sl][0];
             float* orow = &out_s[sl][0];
 #pragma unroll
             for (int q = 0; q < NGR; ++q) {
-                if (!has[q]) continue;
                 const int un = uu[q];
                 float pr[NW];
 #pragma unroll
@@ -584,8 +635,8 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
                 const float rec = pr[0];
                 // the pre-activation gradient of gate row (g, u) from dh of unit u (every lane that shares the unit
                 // rebuilds the same dh and carries the same dh z)
-                const float dh = ip[un] + carry[q] + rec;
-                const float rr = ip[GH + un], zz = ip[2 * GH + un], nn = ip[3 * GH + un], ghn = ip[4 * GH + un], hprev = ip[5 * GH + un];
+                const float dh = iv[q][0] + carry[q] + rec;
+                const float rr = iv[q][1], zz = iv[q][2], nn = iv[q][3], ghn = iv[q][4], hprev = iv[q][5];
                 const float dn = dh * (1.0f - zz);
                 const float dz = dh * (hprev - nn);
                 carry[q] = dh * zz;
@@ -595,8 +646,10 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
                 const float dghn = dnpre * rr;
                 const float gi_v = gg[q] == 0 ? drpre : (gg[q] == 1 ? dzpre : dnpre);
                 const float gh_v = gg[q] == 0 ? drpre : (gg[q] == 1 ? dzpre : dghn);
-                orow[jr[q]] = gi_v;
-                orow[3 * GH + jr[q]] = gh_v;
+                if (has[q]) {                 // (the math runs on every lane: a branch would pull the reads back down)
+                    orow[jr[q]] = gi_v;
+                    orow[3 * GH + jr[q]] = gh_v;
+                }
                 dv[q] = gh_v;
             }
         }
