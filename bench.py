@@ -211,12 +211,15 @@ def streamed_leg(cfgname, dropout, nbatches=32, passes=2):
     n_utt = sum(int(b[4].sum()) for b in batches)
     loss_f = FocalLoss(gamma=0.5)
     res = {}
-    for mode in ("eager", "captured"):
+    from mm_dfn_amd.optim import FlatAdam
+    for mode in ("eager", "captured", "captured_flat_adam"):
         model = synthetic.build_model(dropout=dropout, **cfg)
         model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
         model = model.to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=1e-4)
-        cache = train.StepGraphCache(model, loss_f, max_entries=nbatches + 4) if mode == "captured" else None
+        # torch.optim.Adam as the reference uses it, or this package's fused flat Adam (same update, one launch)
+        opt = (FlatAdam(model, lr=3e-4, weight_decay=1e-4) if mode == "captured_flat_adam" else
+               torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=1e-4))
+        cache = train.StepGraphCache(model, loss_f, max_entries=nbatches + 4) if mode != "eager" else None
         times = []
         for _ in range(passes + 1):
             torch.cuda.synchronize()
@@ -229,7 +232,8 @@ def streamed_leg(cfgname, dropout, nbatches=32, passes=2):
                      "utterances_per_s": n_utt / min(times[1:]), "ms_per_step": min(times[1:]) / nbatches * 1e3}
         del model, opt, cache
     return {"workload": "%s ragged, %d different batches streamed through train_or_eval_graph_model (fwd + loss + bwd + "
-                        "torch Adam step, metrics, pinned-host prefetch)" % (cfgname, nbatches),
+                        "Adam step [torch.optim.Adam; captured_flat_adam: mm_dfn_amd.optim.FlatAdam], metrics, pinned-host "
+                        "prefetch)" % (cfgname, nbatches),
             "utterances_per_pass": n_utt, **res}
 
 

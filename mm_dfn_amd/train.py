@@ -114,7 +114,16 @@ class StepGraphCache:
             for dst, src in zip(ent["static"], inputs):
                 dst.copy_(src, non_blocking=True)
         cap = ent["cap"]
-        loss = cap.replay()
+        try:
+            loss = cap.replay()
+        except RuntimeError as exc:
+            if "storage moved" not in str(exc):
+                raise
+            # the parameters were re-pointed after this entry was captured (FlatAdam lays them out in its flat buffer
+            # at its first step; .to(); load_state_dict(assign=True)): the entry is stale, capture the signature again
+            del self.entries[key]
+            self.recaptures = getattr(self, "recaptures", 0) + 1
+            return self.step(inputs, lengths, train_flag, test_label)
         if train_flag:
             for name, p in self.model.named_parameters():
                 p.grad = cap.grads.get(name)

@@ -182,6 +182,32 @@ def test_pass_loop_with_captured_step_cache_equals_eager(tmp_path):
     assert cache.hits == n_tr + n_te
 
 
+def test_captured_step_cache_with_flat_adam_recaptures_after_the_flat_layout(tmp_path):
+    """StepGraphCache + FlatAdam: the optimizer re-points every parameter into its flat buffer at its first step, which
+    makes the entries captured before that stale; the cache notices (CapturedStep checks the storages), captures those
+    signatures again and training continues on the same trajectory as torch.optim.Adam in the eager loop."""
+    from mm_dfn_amd.optim import FlatAdam
+    p = D.write_synthetic_pickle(str(tmp_path / "f.pkl"), n_train=14, n_test=5, max_len=24, seed=9)
+    loss_f = FocalLoss(gamma=0.5)
+    runs = []
+    for flat in (False, True):
+        m = _model(22)
+        opt = FlatAdam(m, lr=1e-3, weight_decay=1e-5) if flat else torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr, _, _ = D.get_IEMOCAP_loaders(p, batch_size=4, valid_rate=0.0)
+        cache = T.StepGraphCache(m, loss_f) if flat else None
+        losses = []
+        for e in range(3):
+            r = T.train_or_eval_graph_model(m, loss_f, D.DevicePrefetcher(tr), e, True, opt, False, 'avl', None, graph_cache=cache)
+            losses.append(r[2])
+        runs.append((m, losses, cache))
+    (m0, l0, _), (m1, l1, cache) = runs
+    assert all(abs(a - b) < 3e-4 for a, b in zip(l0, l1)), (l0, l1)
+    for (k, x), (_, y) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert float((x - y).abs().max()) < 5e-5, k
+    assert getattr(cache, "recaptures", 0) >= 1           # the entry captured before the first optimizer step
+    assert cache.hits >= 2 * 4 - 1                         # epochs 2 and 3 replay
+
+
 def test_real_model_gradient_bucket_through_rccl_and_flat_adam():
     """The data-parallel machinery on the real model and device tensors, world size 1 over RCCL (backend "nccl"):
     captured step -> flat bucket pack -> all-reduce (also as a node of the captured graph) -> FlatAdam, against
