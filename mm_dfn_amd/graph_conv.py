@@ -109,7 +109,7 @@ class GCNII_lyc(nn.Module):
         if self.training and self.dropout > 0:
             # the 0 / 1 keep flags of x, h0 and every layer: one slice of the step's flag pool; the kernels scale by 1/(1-p)
             masks = ops.keep_flags(R * nfeat + (1 + len(self.convs)) * R * H, self.dropout, x.device)
-            mscale = 1.0 / (1.0 - self.dropout)
+            mscale = ops.keep_scale(self.dropout)
         cur = gcn_stack.gcn_stack(x, adj, masks, mscale, self.lamda, self.alpha, self.reason_flag, self.use_residue,
                                   self.fcs[0].weight, self.fcs[0].bias, self.rnn, [c.weight for c in self.convs])
         if not self.return_feature:

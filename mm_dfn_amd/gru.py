@@ -158,5 +158,5 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
         if layer == 0 and training and dropout > 0:
             # nn.GRU's dropout between the layers: 0 / 1 keep flags from the step's flag pool (no generator launch of its
             # own) applied to every group's output by ONE launch each way
-            cur = list(ops.mask_scale(cur, [ops.keep_flags(y.numel(), dropout, y.device) for y in cur], 1.0 / (1.0 - dropout)))
+            cur = list(ops.mask_scale(cur, [ops.keep_flags(y.numel(), dropout, y.device) for y in cur], ops.keep_scale(dropout)))
     return cur

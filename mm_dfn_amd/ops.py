@@ -887,6 +887,12 @@ class flag_pool:
         return False
 
 
+def keep_scale(p):
+    """The factor dropout multiplies the kept elements by, 1 / (1 - p); p = 1 drops everything (all flags are 0), and the
+    factor is 0 rather than inf so that 0 * inf never appears."""
+    return 0.0 if p >= 1.0 else 1.0 / (1.0 - p)
+
+
 def keep_flags(n, p, device):
     """n fp32 keep flags (1 with probability 1 - p), 16-byte aligned."""
     n = int(n)
@@ -1021,7 +1027,7 @@ def head(Fm, weight, bias, p=0.0, training=False):
     if training and p > 0:
         N = Fm.shape[1] if Fm.dim() == 3 else Fm.shape[0]
         mask = keep_flags(N * _head_width(Fm), p, Fm.device).view(N, _head_width(Fm))
-        mscale = 1.0 / (1.0 - p)
+        mscale = keep_scale(p)
     return _Head.apply(Fm, mask, mscale, weight, bias)
 
 
