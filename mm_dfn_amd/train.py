@@ -69,7 +69,7 @@ class StepGraphCache:
         self.model, self.loss_f = model, loss_f
         self.max_entries, self.warmup = max_entries, warmup
         self.entries = OrderedDict()
-        self.hits = self.misses = 0
+        self.hits = self.misses = self.recaptures = 0
 
     def step(self, inputs, lengths, train_flag, test_label=False):
         """inputs = (textf, visuf, acouf, qmask, umask, label) on the device.  Returns (loss, log_prob, flat_labels):
@@ -122,7 +122,7 @@ class StepGraphCache:
             # the parameters were re-pointed after this entry was captured (FlatAdam lays them out in its flat buffer
             # at its first step; .to(); load_state_dict(assign=True)): the entry is stale, capture the signature again
             del self.entries[key]
-            self.recaptures = getattr(self, "recaptures", 0) + 1
+            self.recaptures += 1
             return self.step(inputs, lengths, train_flag, test_label)
         if train_flag:
             for name, p in self.model.named_parameters():

@@ -204,7 +204,7 @@ def test_captured_step_cache_with_flat_adam_recaptures_after_the_flat_layout(tmp
     assert all(abs(a - b) < 3e-4 for a, b in zip(l0, l1)), (l0, l1)
     for (k, x), (_, y) in zip(m0.named_parameters(), m1.named_parameters()):
         assert float((x - y).abs().max()) < 5e-5, k
-    assert getattr(cache, "recaptures", 0) >= 1           # the entry captured before the first optimizer step
+    assert cache.recaptures >= 1                          # the entry captured before the first optimizer step
     assert cache.hits >= 2 * 4 - 1                         # epochs 2 and 3 replay
 
 
