@@ -665,6 +665,15 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
 // lane-pair one (MMDFN_GRU_KPART_BWD=0) for A/B runs.  Measured at cfg2 (profiles/r02_gru_kernels.md): lane-pair 110 us,
 // partitioned over 4 waves 126, over 8 waves 84, over 16 waves ~125.  The forward pass keeps the lane-pair kernel (80 us;
 // its wave-partitioned forms 102-104 us, a lane-quad form on 8 waves 80 us).
+bool kpart_any_size() {
+#ifdef MMDFN_TUNING
+    const char* e = getenv("MMDFN_GRU_KPART_BWD");
+    return e != nullptr && e[0] == '2';        // A/B aid: the 8-wave kernel also for batches of several rounds
+#else
+    return false;
+#endif
+}
+
 bool use_kpart_bwd() {
 #ifdef MMDFN_TUNING
     const char* e = getenv("MMDFN_GRU_KPART_BWD");
@@ -674,10 +683,20 @@ bool use_kpart_bwd() {
 }
 
 int pick_r(int ngroups, const int* rows) {
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_R")) {        // A/B aid: force the rows per workgroup
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) return v;
+    }
+#endif
+    // One sequence per workgroup wins far beyond one round of workgroups: two lane-pair workgroups share a CU (two
+    // independent latency chains per SIMD), which hides more than putting R sequences behind each other in one wave
+    // (cfg3, ~900 sequences of <= 33 steps: R = 1 1.45 ms per step, R = 2 1.50, R = 4 1.73).  More rows per workgroup only
+    // amortise the 120 KB weight prologue, which matters for very many short sequences.
     for (int R : {1, 2, 4}) {
         int wg = 0;
         for (int g = 0; g < ngroups; ++g) wg += (rows[g] + R - 1) / R;
-        if (2 * wg <= 512) return R;
+        if (2 * wg <= 4096) return R;
     }
     return 4;
 }
@@ -730,7 +749,7 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     hipStream_t s = (hipStream_t)stream;
     // (the 8-wave kernel runs one workgroup per CU: it wins while all sequences fit in one round; beyond that the lane-pair
     // kernel, two workgroups per CU, keeps the batch in one round -- cfg4: 320 workgroups, 1.75 vs 1.69 ms per step)
-    if (R == 1 && 2 * sl <= 256 && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
+    if (R == 1 && (2 * sl <= 256 || kpart_any_size()) && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
     else if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_bwd_kernel<4>, grid, block, 0, s, G);

@@ -70,6 +70,31 @@ def test_one_sequence_per_workgroup_backward_kernels_agree(shapes, kernel_varian
             assert rel_err(res["1"][1][i][k], res["0"][1][i][k]) < 5e-5, k
 
 
+@pytest.mark.parametrize("R", [2, 4])
+def test_rows_per_workgroup_variants_agree(R, kernel_variants):
+    """The dispatcher gives every sequence its own workgroup up to 2048 sequences; the R = 2 / 4 instantiations (several
+    sequences behind each other in one workgroup: only for very many short sequences) are forced here and must give the
+    same results and gradients."""
+    rs = np.random.RandomState(41)
+    shapes = [(17, 9), (33, 70)]
+    xs = [torch.from_numpy(rs.randn(T, n, 200).astype(np.float32)).to(DEV) for T, n in shapes]
+    ws = [torch.from_numpy(rs.randn(T, n, 200).astype(np.float32)).to(DEV) for T, n in shapes]
+    res = {}
+    for mode in ("1", str(R)):
+        kernel_variants.setenv("MMDFN_GRU_R", mode)
+        grus = [make_gru(80 + i).to(DEV) for i in range(len(shapes))]
+        xg = [x.clone().requires_grad_(True) for x in xs]
+        ys = fused.bigru2(xg, grus, 0.0, True)
+        sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+        res[mode] = ([y.detach() for y in ys], [x.grad for x in xg], [dict((k, p.grad) for k, p in g.named_parameters()) for g in grus])
+    a, b = res["1"], res[str(R)]
+    for i in range(len(shapes)):
+        assert abs_err(a[0][i], b[0][i]) < 2e-6
+        assert rel_err(a[1][i], b[1][i]) < 2e-5
+        for k in a[2][i]:
+            assert rel_err(a[2][i][k], b[2][i][k]) < 5e-5, k
+
+
 def test_matches_torch_gru_module_eval():
     g = make_gru(3)
     x = torch.randn(40, 9, 200)

@@ -18,6 +18,7 @@ def _t(rs, *shape, scale=1.0):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_fused_stack_random_shapes_equal_the_op_by_op_path(seed):
+    torch.manual_seed(1000 + seed)               # (the weights below come from torch's generator)
     rs = np.random.RandomState(1000 + seed)
     M = int(rs.choice([1, 2, 3, 6]))
     lengths = [int(x) for x in rs.randint(1, 70, size=rs.randint(1, 5))]
@@ -48,11 +49,12 @@ def test_fused_stack_random_shapes_equal_the_op_by_op_path(seed):
     finally:
         gcn_stack.ROW_LIMIT = prev
     (yb * w).sum().backward()
-    assert rel_err(ya, yb) < 2e-5
-    assert rel_err(xa.grad, xb.grad) < 1e-4
+    # (two different fp32 evaluation orders of a stack up to four layers deep with N(0, 0.3) weights)
+    assert rel_err(ya, yb) < 5e-5
+    assert rel_err(xa.grad, xb.grad) < 2e-4
     for k, p in net.named_parameters():
         if p.grad is not None:
-            assert rel_err(ga[k], p.grad) < 2e-4, k
+            assert rel_err(ga[k], p.grad) < 5e-4, k
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -83,6 +85,7 @@ def test_head_random_shapes(seed):
 def test_gru_random_sequence_counts_and_lengths(seed, kernel_variants):
     """Forward against torch's nn.GRU (eval), backward of both one-sequence-per-workgroup kernels against each other and
     of the rows-per-workgroup kernels against autograd through torch's GRU."""
+    torch.manual_seed(3000 + seed)
     rs = np.random.RandomState(3000 + seed)
     ngroups = int(rs.randint(1, 4))
     shapes = [(int(rs.randint(1, 60)), int(rs.choice([1, 2, 7, 33, 90, 200]))) for _ in range(ngroups)]
