@@ -283,7 +283,8 @@ __global__ void gemm_tn_batch_reduce_kernel(const TnOuts oq) {
 
 }  // namespace
 
-extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) {
+// rows_target: rows per split aimed at while the problem is short enough for <= 16 splits
+static int tn_splits_for(int R, int M, int N, int rows_target) {
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_TN_SPLITS")) {   // tools/bench_gemm_tn.py
         const int v = atoi(e);
@@ -291,10 +292,10 @@ extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) {
     }
 #endif
     // measured on MI355X (tools/bench_gemm_tn.py): ~330-660 rows per split is the sweet spot for every hot-path
-    // shape (R = 1.7k .. 10.5k, outputs 100x200 .. 600x200); more splits only inflate the slab reduction.  Long
-    // reductions (cfg5: R = 98 304 rows into a 100 x 200 output = 8 tiles) need far more than 16 splits to put a
-    // workgroup on every CU: ~512 rows per split, at most ~1536 workgroups per problem.
-    int s = (R + 329) / 330;
+    // shape (R = 1.7k .. 10.5k, outputs 100x200 .. 600x200) launched on its own; more splits only inflate the slab
+    // reduction.  Long reductions (cfg5: R = 98 304 rows into a 100 x 200 output = 8 tiles) need far more than 16
+    // splits to put a workgroup on every CU: ~512 rows per split, at most ~1536 workgroups per problem.
+    int s = (R + rows_target - 1) / rows_target;
     if (s < 8) s = 8;
     if (s > 16) {
         const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
@@ -309,6 +310,8 @@ extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) {
     if (s < 1) s = 1;
     return s;
 }
+
+extern "C" int mmdfn_gemm_tn_splits(int R, int M, int N) { return tn_splits_for(R, M, N, 330); }
 
 extern "C" int mmdfn_gemm_tn(const float* A, const float* B, float* C, float* colsum, float* workspace, int R, int M,
                              int N, int lda, int ldb, int ldc, int splits, void* stream) {
@@ -383,8 +386,11 @@ extern "C" int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* 
 }
 
 // ---- batch form (see TnSegs / TnOuts above) ----------------------------------------------------------------------
+// In the batch form ~25 contractions share one launch, so no single one has to fill the chip: 8 splits each (~1000 rows
+// per split at the hot-path sizes) instead of 8-16 keeps as many workgroups in flight with half the slabs to write and to
+// reduce (cfg2 step 1.117 -> 1.109 ms; 4 or fewer splits lose again).
 static int batch_eff_splits(int R, int M, int N, int* rps_out) {
-    const int splits = mmdfn_gemm_tn_splits(R, M, N);
+    const int splits = tn_splits_for(R, M, N, 1000);
     const int rps = ((R + splits - 1) / splits + BR - 1) / BR * BR;
     if (rps_out) *rps_out = rps;
     return (R + rps - 1) / rps;
