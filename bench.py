@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)   # (a box that idled runs its first replays at a lower clock)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.5)
