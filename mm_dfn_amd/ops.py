@@ -837,7 +837,12 @@ class _Linear2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # the input gradient is one plain library GEMM over the stacked weight when the caller provides a stacked
             # copy (bigru2 packs all of a step's in one launch), two accumulating GEMMs on the parameters otherwise
-            dx = (dy2 @ wcat if wcat is not None else torch.addmm(d1 @ w1, d2, w2)).view(*dy.shape[:-1], w1.shape[1])
+            if wcat is not None and dy2.shape[0] >= 16384 and linear_preferred(dy2.shape[0], dy2.shape[1], w1.shape[1]):
+                # very many rows (cfg3's 19 008 party rows: 59 us against the library's 83 us,
+                # profiles/r02_linear_vs_hipblaslt.txt): the bf16-piece kernel on the transposed stacked weight
+                dx = linear_raw(dy2, wcat.t().contiguous(), None, 0).view(*dy.shape[:-1], w1.shape[1])
+            else:
+                dx = (dy2 @ wcat if wcat is not None else torch.addmm(d1 @ w1, d2, w2)).view(*dy.shape[:-1], w1.shape[1])
         dw1, db1 = _wgrad(d1, x2, p1, b1)
         dw2, db2 = _wgrad(d2, x2, p2, b2)
         return dx, dw1, dw2, db1, db2, None, None

@@ -454,7 +454,8 @@ def test_weight_gradient_batch_kernel():
         assert rel_err(c3, Ad.sum(0)) < 1e-5, (Mo, No, Rr, sh)
 
 
-@pytest.mark.parametrize("R,K,n1,n2", [(300, 200, 300, 300), (7040, 200, 300, 300), (129, 36, 4, 100), (2000, 100, 260, 52)])
+@pytest.mark.parametrize("R,K,n1,n2", [(300, 200, 300, 300), (7040, 200, 300, 300), (129, 36, 4, 100), (2000, 100, 260, 52),
+                                       (16640, 200, 300, 300)])      # (>= 16384 rows: the input gradient on the hand-written kernel)
 def test_two_block_projection(R, K, n1, n2):
     """mmdfn_linear2: output columns from two weight / bias parameters (the directions of a bidirectional GRU layer),
     forward vs torch, gradients of x / both weights / both biases vs autograd on the concatenated form."""

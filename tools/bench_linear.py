@@ -26,7 +26,9 @@ if os.environ.get("HOT"):
     # given pre-transposed, i.e. its best case: no transpose launch counted)
     shapes = [("linear_a / linear_l fwd", 1760, 100, 200), ("linear text fwd", 1760, 512, 200), ("ctx GRU dX", 1760, 600, 200),
               ("party GRU dX", 7040, 600, 200), ("party GRU gi (ours in production)", 7040, 200, 600),
-              ("ctx GRU gi (ours in production)", 1760, 200, 600), ("cfg4 ctx GRU gi", 3520, 200, 600)]
+              ("ctx GRU gi (ours in production)", 1760, 200, 600), ("cfg4 ctx GRU gi", 3520, 200, 600),
+              ("cfg4 linear_a fwd", 3520, 100, 200), ("cfg4 linear text fwd", 3520, 512, 200), ("cfg4 ctx GRU dX", 3520, 600, 200),
+              ("cfg4 party GRU dX", 14080, 600, 200), ("cfg3 text fwd", 1056, 600, 200), ("cfg3 party dX", 19008, 600, 200)]
 if os.environ.get("ONLY"):
     shapes = [s_ for s_ in shapes if os.environ["ONLY"] in s_[0]]
 cfgs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1]
