@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 3). */
+/* Library / device sanity: returns the ABI version (currently 8). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------

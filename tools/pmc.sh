@@ -1,23 +1,38 @@
 #!/bin/bash
-# usage: tools/pmc.sh <tag> "<counters>" <command...>  -> prints per-kernel counter sums (kernel-trace + pmc only)
-tag=$1; shift; ctr=$1; shift
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf /tmp/pmc_$tag
-rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$tag -o p -- "$@" > /tmp/pmc_$tag.log 2>&1
-mkdir -p gpurun_out
-python - <<PY
-import csv, collections, glob
-f = glob.glob('/tmp/pmc_$tag/*counter_collection.csv')
-if not f:
-    print(open('/tmp/pmc_$tag.log').read()[-2000:]); raise SystemExit
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-for r in csv.DictReader(open(f[0])):
-    k = r['Kernel_Name'][:70]
-    agg[k][r['Counter_Name']] += float(r['Counter_Value']); 
-    cnt[(k, r['Counter_Name'])] += 1
-with open('gpurun_out/${tag}_pmc.txt', 'w') as out:
-    for k, d in agg.items():
-        if '${FILTER:-}' and '${FILTER:-}' not in k: continue
-        line = k + ' | ' + ' '.join('%s=%.4g' % (c, v / cnt[(k, c)]) for c, v in sorted(d.items()))
-        print(line); out.write(line + '\n')
+# usage: tools/pmc.sh <outdir under gpurun_out> <kernel-name regex> -- <command...>
+# One rocprofv3 --pmc pass per counter group (separate passes, kernel-trace only), then the per-kernel averages.
+out=$1; shift; kre=$1; shift; shift
+root=$(pwd)
+mkdir -p $root/gpurun_out/$out
+cd /tmp && export TMPDIR=/tmp
+# groups come from $PMC_GROUPS (';'-separated) or the default list; every pass runs under its own `timeout` (a pass that
+# names a counter the tool cannot schedule aborts and then hangs)
+if [ -n "$PMC_GROUPS" ]; then IFS=';' read -ra groups <<< "$PMC_GROUPS"; else
+groups=(
+ "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU"
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS"
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+ "FETCH_SIZE"
+ "WRITE_SIZE"
+)
+fi
+i=0
+for g in "${groups[@]}"; do
+  timeout ${PMC_PASS_TIMEOUT:-120} rocprofv3 --pmc $g --kernel-trace -d $root/gpurun_out/$out/p$i -o p --output-format csv -- "$@" > $root/gpurun_out/$out/p$i.log 2>&1
+  i=$((i+1))
+done
+cd $root
+python - "$out" "$kre" <<'PY'
+import csv, glob, re, sys, collections
+out, kre = sys.argv[1], re.compile(sys.argv[2])
+acc = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/%s/p*/**/*counter_collection.csv" % out, recursive=True):
+    for row in csv.DictReader(open(f)):
+        if kre.search(row.get("Kernel_Name", "")):
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+with open("gpurun_out/%s/summary.txt" % out, "w") as fh:
+    for k in sorted(acc):
+        v = acc[k]
+        line = "%-40s n=%3d avg=%.6g" % (k, len(v), sum(v) / len(v))
+        print(line); fh.write(line + "\n")
 PY
