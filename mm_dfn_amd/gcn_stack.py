@@ -19,8 +19,9 @@ from . import _hip, ops
 ROW_LIMIT = 32768
 
 
-def eligible(x, nfeat, nhidden, nlayers, params):
-    return (x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= ROW_LIMIT and nlayers >= 1
+def eligible(x, nfeat, nhidden, nlayers, params, lamda=1.0):
+    # lamda > 0: theta_l = ln(lamda / l + 1) > 0, which the backward kernel divides by (c1 = (1-theta)(1-alpha)/theta)
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= ROW_LIMIT and nlayers >= 1 and lamda > 0
             and nhidden % 4 == 0 and 4 <= nhidden <= 100 and nfeat % 4 == 0 and 4 <= nfeat <= 256
             and (not torch.is_grad_enabled() or all(ops._leaf(p) for p in params)))
 
@@ -101,6 +102,27 @@ class _GcnStack(torch.autograd.Function):
         else:
             dcur, lddo, dxd, lddxd = dout, H, None, 0
         want_adj = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        # weight gradients: queued for the step's one-launch batch (ops.wgrad_batch scope, hook-free leaf parameters), or
+        # computed here and returned to autograd (plain loss.backward(), torch.autograd.grad, hooked parameters)
+        plist = [p for p in (W0, b0, w_ih, w_hh, b_ih, b_hh) if p is not None] + list(convW)
+        batched = ops.wgrad_batching() and not any(ops._hooked(p) for p in plist)
+        inline = {}                                    # id(param) -> gradient (in-line mode)
+
+        def wgrad(A, B, weight, biases=(), rows=None):
+            if batched:
+                ops.queue_wgrad(A, B, weight, biases, rows=rows)
+                return
+            dw, db = ops._wgrad_inline(A, B, bool(biases))
+            if rows is not None:
+                g = inline.get(id(weight))
+                if g is None:
+                    g = inline[id(weight)] = torch.zeros_like(weight)
+                g[rows[0]:rows[1]] += dw
+            else:
+                inline[id(weight)] = dw if id(weight) not in inline else inline[id(weight)] + dw
+            for b in biases:
+                inline[id(b)] = db if id(b) not in inline else inline[id(b)] + db
+
         dh0 = new(R, H)
         acc_h0 = 0
         dtiles = dcross = None
@@ -112,8 +134,8 @@ class _GcnStack(torch.autograd.Function):
                                                  m["alpha"], R, H, lddo, acc_h0, st), "mmdfn_gcnii_layer_bwd")
             acc_h0 = 1
             # dW_i = [hi | h0]^T dP: two row ranges of the (2H, H) parameter, the concatenated operand never exists
-            ops.queue_wgrad(L["hi"], dP, convW[i], rows=(0, H))
-            ops.queue_wgrad(m["h0"], dP, convW[i], rows=(H, 2 * H))
+            wgrad(L["hi"], dP, convW[i], rows=(0, H))
+            wgrad(m["h0"], dP, convW[i], rows=(H, 2 * H))
             dz = ops.propagate_raw(tiles, cross, dhi, lay, transpose=not m["symmetric"])
             if want_adj:
                 dtiles, dcross = ops.tile_outer_raw(dhi, L["zin"], lay, dtiles, dcross)
@@ -125,9 +147,9 @@ class _GcnStack(torch.autograd.Function):
                 _hip.check(lib.mmdfn_lstm_gate_bwd(P(L["gates"]), P(L["c_prev"]), P(L["c_new"]), P(dz), P(dh_carry),
                                                    P(dc_carry), P(w_ih), P(w_hh), P(dcur), P(dG), P(dc_prev), P(dq),
                                                    P(dh_prev), R, H, 1 if has_h else 0, lddo, st), "mmdfn_lstm_gate_bwd")
-                ops.queue_wgrad(dG, L["q"], w_ih, [b_ih, b_hh])
+                wgrad(dG, L["q"], w_ih, [b_ih, b_hh])
                 if has_h:
-                    ops.queue_wgrad(dG, L["h_prev"], w_hh)
+                    wgrad(dG, L["h_prev"], w_hh)
                 dcur, lddo = dq, H
                 dh_carry, dc_carry = dh_prev, dc_prev
             else:
@@ -136,8 +158,9 @@ class _GcnStack(torch.autograd.Function):
         _hip.check(lib.mmdfn_gcn_input_bwd(P(dcur), P(m["m0"]), P(dh0), P(m["h0"]), P(W0), P(dxd), P(m["mx"]), P(dpre), P(dx), R,
                                            F, H, lddxd, m["mscale"], st), "mmdfn_gcn_input_bwd")
         xd = m["xd"][:, :F] if m["use_residue"] else m["xd"]
-        ops.queue_wgrad(dpre, xd, W0, [b0] if b0 is not None else [])
-        return (dx, dtiles, dcross) + (None,) * (14 + len(convW))
+        wgrad(dpre, xd, W0, [b0] if b0 is not None else [])
+        pg = [None if p is None else inline.get(id(p)) for p in (W0, b0, w_ih, w_hh, b_ih, b_hh)]
+        return (dx, dtiles, dcross) + (None,) * 8 + tuple(pg) + tuple(inline.get(id(w)) for w in convW)
 
 
 def gcn_stack(x, adj, masks, mscale, lamda, alpha, reason_flag, use_residue, W0, b0, lstm, convs):

@@ -127,7 +127,7 @@ class GCNII_lyc(nn.Module):
         rows) and non-leaf parameters: per layer = gate GEMM(s) + fused LSTM-cell kernel + propagate (writes
         [A.x | h0] in place) + support GEMM + fused GCNII update kernel."""
         if (self.inner_dropout and not self.final_dropout
-                and gcn_stack.eligible(x, x.shape[1], con_width(self.convs), len(self.convs), self._stack_params())):
+                and gcn_stack.eligible(x, x.shape[1], con_width(self.convs), len(self.convs), self._stack_params(), self.lamda)):
             return self._forward_stack(x, adj)
         x = F.dropout(x, self.dropout, training=self.training)
         h0 = ops.linear(x, self.fcs[0].weight, self.fcs[0].bias, act=1)      # Linear + ReLU fused

@@ -31,6 +31,10 @@ class CapturedStep:
                 bucket.flatten()
                 if reduce_in_graph:
                     bucket.reduce_flat()
+        # the warm-up passes and the capture draw dropout flags: put the device generator back afterwards, so that building
+        # a captured step consumes no random numbers and its first replay draws what one eager step would have drawn
+        dev_index = torch.cuda.current_device()
+        rng_state = torch.cuda.get_rng_state(dev_index)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -51,6 +55,7 @@ class CapturedStep:
                 self.loss = step_fn()
                 tail()
         self._pinned = list(used)
+        torch.cuda.set_rng_state(rng_state, dev_index)
         self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
         # the parameter storages are baked in as well: a later re-pointing of p.data (FlatAdam._materialise, .to(),
         # load_state_dict(assign=True)) would make the graph update stale memory -- checked on every replay

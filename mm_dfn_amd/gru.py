@@ -99,7 +99,10 @@ def _adjacent(wf, wr):
 
 def _stacked_view(wf, wr):
     """[wf; wr] (2 * 3H, K) without a copy, or None.  Two leaf parameters that are not adjacent yet are moved into one
-    buffer first (``.data`` re-pointed, values kept) unless an owner of their storage forbids it (FlatAdam marks the
+    buffer first (``.data`` re-pointed, values kept: anything that aliased the OLD storage -- an EMA copy made with
+    ``.data`` views, a foreign flat-parameter optimizer, an earlier captured graph -- goes stale; ``pair_gru_weights(model)``
+    does this once, explicitly, at model / optimizer construction time, which is where it belongs) unless an owner of
+    their storage forbids it (FlatAdam marks the
     parameters it has laid out -- in an order that keeps the pairs adjacent, distributed.bucket_order) or the stream is
     being captured."""
     if not _adjacent(wf, wr):
@@ -115,6 +118,19 @@ def _stacked_view(wf, wr):
     return torch.as_strided(wf.detach(), (2 * wf.shape[0], wf.shape[1]), (wf.shape[1], 1))
 
 
+def pair_gru_weights(module):
+    """Lay the two directions' ``weight_ih`` / ``bias_ih`` of every fused nn.GRU of ``module`` out adjacently NOW (what the
+    first training forward would otherwise do lazily as a side effect): call it once after building / loading the model
+    and before anything takes aliases of the parameter storage.  Values are unchanged.  Returns the number of pairs."""
+    n = 0
+    for sub in module.modules():
+        if isinstance(sub, torch.nn.GRU) and sub.bidirectional and sub.num_layers == 2 and sub.hidden_size == H:
+            for layer in range(2):
+                w_ih, b_ih, _ = _layer_params(sub, layer)
+                n += int(_stacked_view(*w_ih) is not None) + int(_stacked_view(*b_ih) is not None)
+    return n
+
+
 def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
     """xs[g]: (T, rows_g, 200) -> ys[g]: (T, rows_g, 200); grus[g]: the nn.GRU holding group g's weights.
     gi0[g] (optional): the first layer's gate pre-activations X W_ih^T + b_ih (T, rows_g, 600) computed by the caller
@@ -123,6 +139,9 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
     for gru in grus:
         if gru.hidden_size != H or gru.num_layers != 2 or not gru.bidirectional or gru.batch_first:
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
+        if gru.input_size != 2 * H:
+            # (both layers then share one (600, 200) stacked-weight shape: the copy fallback below relies on it)
+            raise NotImplementedError("fused GRU path supports input_size == 2 * hidden_size (200) only, got %d" % gru.input_size)
     cur = list(xs)
     # [W_ih_fwd; W_ih_rev] of every (module, layer) as ONE (600, K) operand for the input-gradient GEMMs of the backward
     # pass.  The two parameters are kept adjacent in memory (_stacked_view), so this is a view; parameters some

@@ -467,29 +467,68 @@ def gemm_tn_grouped(problems):
 # Weight-gradient queue.  dW / db of the dense layers, the GRU weights, the LSTM gate and the GCN layers feed
 # nothing else in the backward pass and each is far too small to fill the chip (cfg2: ~25 contractions of
 # 1.7k-7k rows into 100x200 .. 600x200 outputs, ten launch pairs and 300 us per step when issued one by one).
-# During backward they are only QUEUED; an autograd end-of-backward callback issues all of them as ONE launch pair
-# (csrc/gemm_tn.hip, batch form) that writes straight into the parameters' .grad -- no autograd accumulation
-# kernels, and the contributions of a parameter used several times (the layer-shared LSTM gate) are summed inside
-# the slab reduction.  Conditions: the weight (and bias) are leaf parameters; anything else takes the in-line path
-# and returns its gradient to autograd as usual.  torch.autograd.grad() callers never get leaf parameters here.
+# Inside a ``wgrad_batch()`` scope -- ``train.backward(loss)`` opens one around ``loss.backward()``, so do the captured
+# steps and the pass loop -- they are only QUEUED during backward; an autograd end-of-backward callback issues all of
+# them as ONE launch pair (csrc/gemm_tn.hip, batch form) that writes straight into the parameters' .grad: no autograd
+# accumulation kernels, and the contributions of a parameter used several times (the layer-shared LSTM gate) are summed
+# inside the slab reduction.  This bypasses autograd for those parameters (backward returns None for them), so it is
+# opt-in by scope and per parameter:
+#   * outside a scope (a plain ``loss.backward()``, ``torch.autograd.grad(...)``) every node computes its weight
+#     gradients in line and RETURNS them: autograd.grad sees them, nothing is written to .grad behind its back;
+#   * a parameter with tensor hooks or post-accumulate-grad hooks (DDP reducers, user hooks) always takes the in-line path;
+#   * non-leaf weights always take the in-line path.
+# The queue belongs to one backward pass: entering the outermost scope drops anything a failed backward left behind, and
+# leaving it flushes what the engine callback did not (or clears the queue when the backward raised).
 # ---------------------------------------------------------------------------------------------------
-_WGQ = {"segs": [], "outs": {}, "armed": False}
+_WGQ = {"segs": [], "outs": {}, "armed": False, "scope": 0}
 _WG_MAX = 40        # TN_MAXSEG / TN_MAXOUT of csrc/gemm_tn.hip
+
+
+class wgrad_batch:
+    """``with ops.wgrad_batch(): loss.backward()`` -- weight gradients of leaf parameters are batched into one launch pair
+    and written to ``.grad`` directly (see the comment above).  Re-entrant; exception-safe."""
+
+    def __enter__(self):
+        if _WGQ["scope"] == 0 and (_WGQ["outs"] or _WGQ["armed"]):
+            _WGQ["outs"], _WGQ["armed"] = {}, False        # stale entries of a backward that raised
+        _WGQ["scope"] += 1
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _WGQ["scope"] -= 1
+        if _WGQ["scope"] == 0:
+            if exc_type is None:
+                if _WGQ["outs"]:
+                    flush_queued_wgrads()                  # a backward driven without the engine callback
+            else:
+                _WGQ["outs"], _WGQ["armed"] = {}, False    # the callback never ran: drop the half-built batch
+        return False
+
+
+def wgrad_batching():
+    return _WGQ["scope"] > 0
 
 
 def _leaf(p):
     return p is not None and p.is_leaf and p.requires_grad
 
 
+def _hooked(p):
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 def _queueable(weight, biases, M, N):
-    return _leaf(weight) and all(_leaf(b) for b in biases) and gemm_tn_supported(M, N) and len(biases) <= 2
+    return (_WGQ["scope"] > 0 and _leaf(weight) and all(_leaf(b) for b in biases) and gemm_tn_supported(M, N)
+            and len(biases) <= 2 and not _hooked(weight) and not any(_hooked(b) for b in biases))
 
 
 def queue_wgrad(A, B, weight, biases=(), shift=0, rows=None):
     """weight.grad (M, N) += sum_r A[r]^T B[r + shift];  b.grad (M) += column sums of A for every b in ``biases``.
     ``rows = (r0, r1)``: the contraction fills rows r0..r1-1 of weight.grad only (GraphConvolution.weight takes its two
     halves from hi^T dP and h0^T dP, the concatenated operand [hi | h0] never exists).
-    Only valid inside a backward pass (the flush is an end-of-backward callback)."""
+    Only valid inside a backward pass under ``wgrad_batch()`` (the flush is an end-of-backward callback)."""
+    if _WGQ["scope"] <= 0:
+        raise RuntimeError("queue_wgrad outside a wgrad_batch() scope")
     A = _strided_rows(A)
     B = _strided_rows(B)
     r0, r1 = rows if rows is not None else (0, weight.shape[0])
@@ -589,9 +628,9 @@ def _launch_wgrad_batch(batch):
 
 
 def join_weight_grads():
-    """Kept for callers of earlier versions: the queue is flushed by the end-of-backward callback; this only covers a
-    backward driven outside the autograd engine."""
-    if _WGQ["outs"] and not _WGQ["armed"]:
+    """Kept for callers of earlier versions: the queue is flushed by the end-of-backward callback (or by the exit of the
+    ``wgrad_batch()`` scope); anything still queued here is issued now."""
+    if _WGQ["outs"] and _WGQ["scope"] == 0:
         flush_queued_wgrads()
 
 

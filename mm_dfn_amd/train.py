@@ -39,18 +39,21 @@ def flatten_labels(label, lengths):
     return label[keep]
 
 
-_UNIT_SEED = {}
+_UNIT_SEED = {}      # (device, dtype) -> scalar 1; entries are never replaced (captured graphs hold their addresses)
 
 
 def backward(loss):
-    """``loss.backward()`` seeded with a cached scalar 1 (autograd otherwise allocates and fills a fresh one: one more
-    launch per step)."""
-    one = _UNIT_SEED.get(loss.device)
-    if one is None or one.dtype != loss.dtype:
-        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
-            return loss.backward()               # a tensor created under capture belongs to that graph's pool
-        one = _UNIT_SEED[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    loss.backward(one)
+    """``loss.backward()`` under ``ops.wgrad_batch()`` (the weight gradients of the step leave as one launch pair that
+    writes ``.grad`` directly), seeded with a cached scalar 1 (autograd otherwise allocates and fills a fresh one: one
+    more launch per step)."""
+    key = (loss.device, loss.dtype)
+    one = _UNIT_SEED.get(key)
+    with ops.wgrad_batch():
+        if one is None:
+            if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+                return loss.backward()           # a tensor created under capture belongs to that graph's pool
+            one = _UNIT_SEED[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(one)
 
 
 class StepGraphCache:

@@ -267,3 +267,91 @@ def test_real_model_gradient_bucket_through_rccl_and_flat_adam():
         assert dist.get_backend() == "nccl"
     finally:
         dist.destroy_process_group()
+
+
+def _step_inputs(seed=11, lengths=(20, 13, 7)):
+    b = synthetic.make_batch(seed, lengths=list(lengths), device="cuda", B=len(lengths), L=max(lengths), **CFG)
+    return b, T.flatten_labels(b["label"], b["lengths"])
+
+
+def _loss(m, b, flat):
+    logp = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+    return FocalLoss(gamma=0.5)(logp, flat)
+
+
+def test_weight_gradient_batch_is_opt_in_and_matches_plain_autograd():
+    """The one-launch weight-gradient batch runs only under ops.wgrad_batch() (train.backward): a plain loss.backward()
+    and torch.autograd.grad() get every parameter gradient from autograd itself, with the same values, and
+    autograd.grad() writes no .grad behind the caller's back."""
+    from mm_dfn_amd import ops
+    m = _model().train()
+    b, flat = _step_inputs()
+    T.backward(_loss(m, b, flat))                       # batched: .grad written by the end-of-backward launch pair
+    live = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert "graph_model.graph_net.rnn.weight_ih_l0" in live and "lstm_l.weight_hh_l0" in live
+    m.zero_grad(set_to_none=True)
+    _loss(m, b, flat).backward()                        # plain autograd: in-line weight gradients
+    for n, p in m.named_parameters():
+        assert (p.grad is not None) == (n in live), n
+        if n in live:
+            scale = float(live[n].abs().max()) + 1e-12
+            assert float((p.grad - live[n]).abs().max()) / scale < 1e-5, n
+    m.zero_grad(set_to_none=True)
+    params = [p for n, p in m.named_parameters() if n in live]
+    grads = torch.autograd.grad(_loss(m, b, flat), params)
+    assert all(g is not None for g in grads)
+    assert all(p.grad is None for p in m.parameters())  # nothing written on the side
+    for g, (n, p) in zip(grads, [(n, p) for n, p in m.named_parameters() if n in live]):
+        assert float((g - live[n]).abs().max()) / (float(live[n].abs().max()) + 1e-12) < 1e-5, n
+    # input-only autograd.grad: no parameter gradient is computed or stored
+    x = b["textf"].clone().requires_grad_(True)
+    logp = m(x, b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+    (gx,) = torch.autograd.grad(logp.sum(), [x])
+    assert gx is not None and all(p.grad is None for p in m.parameters())
+    assert not ops._WGQ["outs"] and not ops._WGQ["armed"]
+
+
+def test_parameter_hooks_fire_under_the_weight_gradient_batch():
+    m = _model().train()
+    b, flat = _step_inputs()
+    seen = []
+    w = m.graph_model.graph_net.convs[0].weight
+    h = w.register_hook(lambda g: seen.append(tuple(g.shape)))
+    T.backward(_loss(m, b, flat))
+    h.remove()
+    assert seen == [tuple(w.shape)] and w.grad is not None
+    assert m.lstm_l.weight_hh_l0.grad is not None       # un-hooked parameters still went through the batch
+
+
+def test_weight_gradient_queue_survives_a_backward_that_raises():
+    """A backward pass that raises leaves queued segments behind (the engine never runs the end-of-backward callback);
+    the next step must not inherit them (every queued parameter silently lost its .grad for the rest of
+    the process)."""
+    from mm_dfn_amd import ops
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    m = _model().train()
+    b, flat = _step_inputs()
+    good = _model().train()
+    T.backward(_loss(good, b, flat))
+    want = {n: p.grad.clone() for n, p in good.named_parameters() if p.grad is not None}
+    # the failing pass: the head and the graph stack queue their segments, then the encoder side raises
+    x = b["textf"].clone().requires_grad_(True)
+    logp = m(Boom.apply(x), b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+    with pytest.raises(RuntimeError, match="boom"):
+        T.backward(FocalLoss(gamma=0.5)(logp, flat))
+    assert not ops._WGQ["outs"] and not ops._WGQ["armed"] and ops._WGQ["scope"] == 0
+    m.zero_grad(set_to_none=True)
+    T.backward(_loss(m, b, flat))
+    for n, p in m.named_parameters():
+        assert (p.grad is not None) == (n in want), n
+        if n in want:
+            assert float((p.grad - want[n]).abs().max()) / (float(want[n].abs().max()) + 1e-12) < 1e-5, n
