@@ -1,6 +1,11 @@
 """bench.py -- utterances/sec (fwd + loss + bwd) of the MM-DFN hot path on N MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--ragged]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfgK] [--ragged]
+
+Workload: BASELINE configs[1] (cfg2: 16 dialogues of 110 utterances) on one GPU; with --gpus N > 1 BASELINE configs[3]
+(cfg4: 32 dialogues per GPU = 256 at 8 GPUs), weak scaling.  --ragged at N > 1 draws ONE global batch of 32 N dialogues
+and shards it over the ranks by sum(L^2) (distributed.shard_dialogues); the JSON then carries the per-rank loads and step
+times.
 
 With --gpus N > 1 and no torch.distributed environment the script re-launches ITSELF under
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` (one rank per GPU over RCCL);
@@ -37,7 +42,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)   # (a box that idled runs its first replays at a lower clock)
-    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--config", default=None,
+                    help="default: cfg2 (BASELINE configs[1], 16 dialogues) at --gpus 1; cfg4 (BASELINE configs[3]: 32 dialogues per "
+                         "GPU, 256 at 8 GPUs) at --gpus N > 1")
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,14 +83,25 @@ def profile_json(name):
         return None
 
 
-def measured_traffic(key):
-    """HBM bytes per launch from the committed PMC passes: the counters need their own rocprofv3 --pmc runs
-    (FETCH_SIZE / WRITE_SIZE do not fit one pass), so they are not re-collected here."""
-    for name in ("r02_propagate_traffic.json", "r01_propagate_traffic.json"):
-        d = profile_json(name)
-        if d and key in d:
-            return d[key]["traffic_bytes"], "profiles/" + name
-    return None, None
+def measured_traffic(key, kernel):
+    """HBM bytes per launch from the committed PMC passes of THIS round (tools/collect_traffic.py: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --only-roofline`, FETCH x2 on gfx950; the file records the
+    commit it was collected at).  The counters cannot share a pass with the timing run, so they are not re-collected
+    here; a figure is attached only if the kernel it was measured on still exists, by name, in the library this process
+    loaded."""
+    d = profile_json("r03_propagate_traffic.json")
+    if not d or key not in d:
+        return None, None
+    ent = d[key]
+    from mm_dfn_amd import build as _b
+    try:
+        with open(_b.LIBPATH, "rb") as fh:
+            present = ent["kernel"].encode() in fh.read()
+    except OSError:
+        present = False
+    if not present:
+        return None, "profiles/r03_propagate_traffic.json names kernel %r, which is not in the current library: not attached" % ent["kernel"]
+    return ent["traffic_bytes"], "profiles/r03_propagate_traffic.json (commit %s, kernel %s)" % (d.get("commit", "?"), ent["kernel"])
 
 
 def time_propagate(make_set, nsets, iters, warm_replays=10, timed_replays=3):
@@ -288,6 +306,8 @@ def cpu_baseline(cfg, batch, state, threads, dropout, budget_s):
 
 def main():
     a = parse()
+    if a.config is None:
+        a.config = "cfg2" if a.gpus == 1 else "cfg4"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
     # stdout carries ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner
@@ -328,7 +348,19 @@ def main():
     model = synthetic.build_model(dropout=a.dropout, **cfg)
     model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
     model = model.to(dev).train()
-    batch = synthetic.make_batch(2021 + rank, ragged=a.ragged, device=dev, **cfg)
+    shard_info = None
+    if use_dp and world > 1 and a.ragged:
+        # ONE global ragged batch of B * world dialogues (the same on every rank: seeded), sharded by sum(L^2)
+        import numpy as np
+        glens = synthetic.make_lengths(np.random.RandomState(2021), cfg["B"] * world, cfg["L"], True)
+        mine = distributed.shard_dialogues(glens, world, rank)
+        batch = synthetic.make_batch(2021 + rank, lengths=[glens[i] for i in mine], device=dev, **cfg)
+        loads = [sum(glens[i] ** 2 for i in distributed.shard_dialogues(glens, world, r)) for r in range(world)]
+        shard_info = {"global_dialogues": len(glens), "global_utterances": sum(glens), "sumL2_max": max(loads),
+                      "sumL2_min": min(loads), "dialogues_per_rank": [len(distributed.shard_dialogues(glens, world, r))
+                                                                      for r in range(world)]}
+    else:
+        batch = synthetic.make_batch(2021 + rank, ragged=a.ragged, device=dev, **cfg)
     lengths = batch["lengths"]
     n_utt = sum(lengths)
     label = train.flatten_labels(batch["label"], lengths)
@@ -403,6 +435,8 @@ def main():
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     if use_dp:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, (dt / a.steps * 1e3, n_utt))
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -435,18 +469,24 @@ def main():
                           "three exact bf16 pieces per operand (six piece products): error vs fp64 at fp32 rounding level "
                           "(<= 4x the exact-f32 MFMA kernel's, tests/test_graph_kernels_gpu.py), not a reduced-precision mode",
             "data": "synthetic", "launch": launch_mode, "allreduce": allreduce_mode,
-            "config": {"workload": "%s: B=%d dialogues/GPU, L=%s, dims %d/%d/%d, %d GCN layers, P=%d, dropout %.2f"
-                                   % (a.config, cfg["B"], "ragged<=%d" % cfg["L"] if a.ragged else cfg["L"], cfg["D_t"],
+            "config": {"workload": "%s (BASELINE %s): B=%d dialogues/GPU, L=%s, dims %d/%d/%d, %d GCN layers, P=%d, dropout %.2f"
+                                   % (a.config, {"cfg1": "configs[0]", "cfg2": "configs[1]", "cfg3": "configs[2]",
+                                                 "cfg4": "configs[3], %d dialogues global" % (cfg["B"] * world)}.get(a.config, "-"),
+                                      cfg["B"], "ragged<=%d" % cfg["L"] if a.ragged else cfg["L"], cfg["D_t"],
                                       cfg["D_a"], cfg["D_v"], cfg["nlayers"], cfg["P"], a.dropout),
                        "utterances_per_gpu": n_utt, "parallelism": "dp%d" % world},
             "with_fused_adam_step": None if adam_ms is None else {"ms_per_step": adam_ms,
                                                                    "value": total_utt / (adam_ms * 1e-3)},
         }
+        if use_dp:
+            out["per_rank"] = {"ms_per_step": [x[0] for x in per_rank], "utterances": [x[1] for x in per_rank]}
+            if shard_info is not None:
+                out["shard"] = shard_info
         if dp is not None and dp.flat is not None:
             out["gradient_bucket"] = {"floats": dp.flat.numel(), "bytes": dp.flat.numel() * 4, "backend": a.backend}
         if not a.no_roofline:
             roofline_legs(out, a, dev, n_utt, lengths)
-        out["dominant"] = profile_json("r02_step_breakdown_%s.json" % a.config)
+        out["dominant"] = profile_json("r03_step_breakdown_%s.json" % a.config) or profile_json("r02_step_breakdown_%s.json" % a.config)
         if world == 1 and not a.no_extra and not use_dp:
             out["other_workloads"] = []
             legs = [lambda c=c, r=r: quick_leg(c, r, a.dropout) for c, r in
@@ -481,13 +521,13 @@ def roofline_legs(out, a, dev, n_utt, lengths):
     lay = ops.DialogueLayout.get(lengths, 3, dev)
     alg_bytes = lay.propagate_bytes(d)
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    traffic, src = measured_traffic("cfg2") if (a.config == "cfg2" and not a.ragged) else (None, None)
+    traffic, src = measured_traffic("cfg2", "propagate_v2_kernel") if (a.config == "cfg2" and not a.ragged) else (None, None)
     out["roofline"] = {"bound": "hbm", "kernel": "propagate_v2_kernel<2,4,2,16,1> (K6 fwd, d=100, exact-f32 MFMA)",
                        "role": "north-star target kernel (BASELINE.json: 'GCN scatter-propagate'); NOT the dominant cost of "
                                "this workload, see 'dominant'; its HBM-roofline figure of merit is 'roofline_cfg5'",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "algorithmic_bytes": alg_bytes, "avg_launch_us": ms * 1e3, "traffic": traffic,
-                       "traffic_source": None if src is None else src + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                       "traffic_source": src,
                        "buffers": "48 rotating (adjacency, H, out) sets = %.0f MB > 256 MB MALL" % (48 * (alg_bytes / 1e6))}
     # the same kernel on BASELINE config 5 (L=512, M=6, d=100, 32 dialogues), where one launch moves 282 MB and
     # the launch-latency floor no longer hides the kernel (the >=40 % HBM target is a cfg5 property)
@@ -502,7 +542,7 @@ def roofline_legs(out, a, dev, n_utt, lengths):
         ms5 = time_propagate(mk5, nsets=3, iters=21, warm_replays=15, timed_replays=5)
         lay5 = ops.DialogueLayout.get(l5, 6, dev)
         b5 = lay5.propagate_bytes(d)
-        t5, src5 = measured_traffic("cfg5_b32")
+        t5, src5 = measured_traffic("cfg5_b32", "propagate_split_kernel")
         out["roofline_cfg5"] = {"workload": "cfg5: B=32, L=512, M=6, d=100", "bound": "hbm",
                                 "kernel": "propagate_split_kernel (K6 fwd, bf16-piece MFMA, fp32-level error)",
                                 "traffic": t5, "traffic_source": src5,
@@ -541,6 +581,24 @@ def roofline_legs(out, a, dev, n_utt, lengths):
                                     "algorithmic_bytes": bb, "avg_us": msb * 1e3}
         del adj5, H5, dO5, gb
         torch.cuda.empty_cache()
+        # the d = 512 stress variant SURVEY 8d asks for next to the reference-faithful d = 100: 18.94 MB and 1.63 GFLOP per
+        # dialogue-layer = 86 flop/B, above the fp32 ridge (157 TFLOP/s / 8 TB/s = 20 flop/B): MFMA-bound, priced against
+        # the dense fp32 matrix peak (the kernel carries the fp32 product on bf16 pieces, 6 MFMA products per fp32 product)
+        l8 = [512] * 8
+
+        def mk512(i):
+            g = torch.Generator(device=dev).manual_seed(900 + i)
+            adj = ops.build_adjacency(torch.randn(6, sum(l8), 200, device=dev, generator=g), l8)
+            return adj, torch.randn(6 * sum(l8), 512, device=dev, generator=g)
+
+        ms512 = time_propagate(mk512, nsets=3, iters=12, warm_replays=8, timed_replays=4)
+        lay8 = ops.DialogueLayout.get(l8, 6, dev)
+        fl = lay8.propagate_flops(512)
+        out["roofline_cfg5_d512"] = {"workload": "cfg5 stress variant: B=8, L=512, M=6, d=512 (K6 fwd)", "bound": "mfma",
+                                     "note": "MFMA-bound, 86 flop/B", "achieved": fl / (ms512 * 1e-3) / 1e12,
+                                     "peak": 157.3, "unit": "TFLOP/s", "frac": fl / (ms512 * 1e-3) / 1e12 / 157.3,
+                                     "algorithmic_bytes": lay8.propagate_bytes(512), "avg_launch_us": ms512 * 1e3,
+                                     "hbm_frac": lay8.propagate_bytes(512) / (ms512 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     except Exception as exc:
         print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
 

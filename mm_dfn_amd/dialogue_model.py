@@ -225,6 +225,16 @@ class DialogueGNNModel(nn.Module):
             fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label, stacked)
         else:
             fused = self.graph_model.forward_stacked(feats, seq_lengths, qmask, test_label, stacked)
+        if test_label:
+            # model.py:1297-1301: the fused (N, 900) graph output of the inference pass, in the reference's column order
+            import os
+            import numpy as np
+            dump = fused.permute(1, 0, 2).reshape(fused.shape[1], -1) if fused.dim() == 3 else fused
+            index = 15
+            print('# deepGCN layer ' + str(index))
+            out_dir = self.graph_model.graph_net.test_output_dir
+            os.makedirs(out_dir, exist_ok=True)
+            np.save(os.path.join(out_dir, "1080_v2_test_output_multi_{}".format(index)), dump.detach().cpu().numpy())
         if self.att_type == 'mfn':
             # re-pad (N, 900) -> (L, B, 900), memory fusion over time, strip again (model.py:1303-1326)
             L, B = U.shape[0], U.shape[1]

@@ -88,7 +88,21 @@ class GCNII_lyc(nn.Module):
                                       "is outside the MM-DFN hot path; pass adj from MM_GCN.create_big_adj")
         _hip.require_cuda(x)                          # MI355X path only: no CPU fallback
         fused = isinstance(adj, BlockTileAdjacency) and all(c.variant and not c.residual for c in self.convs)
-        return self._forward_fused(x, adj) if fused else self._forward_generic(x, adj)
+        dump = self._dump_layer if test_label else None
+        return self._forward_fused(x, adj, dump) if fused else self._forward_generic(x, adj, dump)
+
+    # the reference's --test_label activation dump (model_GCN.py:474-480): every layer's output (after dropout and the
+    # residual q) is printed and saved as <test_output_dir>/1080_v1_test_output_layer_<i>.npy.  The dump needs the
+    # per-layer tensors, so a forward with test_label=True takes the op-by-op path instead of the fused stack node.
+    test_output_dir = "../outputs/iemocap/"
+
+    def _dump_layer(self, i, cur):
+        import os
+        import numpy as np
+        print('# deepGCN layer ' + str(i))
+        print(cur.size())
+        os.makedirs(self.test_output_dir, exist_ok=True)
+        np.save(os.path.join(self.test_output_dir, "1080_v1_test_output_layer_{}".format(i)), cur.detach().cpu().numpy())
 
     # where the reference applies dropout around the layer loop: GCNII_lyc after every layer (model_GCN.py:470),
     # GCNII once after the loop (model_GCN.py:273-278, the per-layer call is commented out there)
@@ -122,11 +136,11 @@ class GCNII_lyc(nn.Module):
             ps += [self.rnn.weight_ih_l0, self.rnn.weight_hh_l0, self.rnn.bias_ih_l0, self.rnn.bias_hh_l0]
         return ps
 
-    def _forward_fused(self, x, adj):
+    def _forward_fused(self, x, adj, dump=None):
         """MI355X path.  Dialogue-graph sizes: one fused autograd node (gcn_stack.py).  Long-dialogue batches (~10^5
         rows) and non-leaf parameters: per layer = gate GEMM(s) + fused LSTM-cell kernel + propagate (writes
         [A.x | h0] in place) + support GEMM + fused GCNII update kernel."""
-        if (self.inner_dropout and not self.final_dropout
+        if (dump is None and self.inner_dropout and not self.final_dropout
                 and gcn_stack.eligible(x, x.shape[1], con_width(self.convs), len(self.convs), self._stack_params(), self.lamda)):
             return self._forward_stack(x, adj)
         x = F.dropout(x, self.dropout, training=self.training)
@@ -153,6 +167,8 @@ class GCNII_lyc(nn.Module):
             P = ops.matmul_kn(S2, con.weight)
             cur = ops.gcnii_combine(P, S2, q if self.reason_flag else None, None if masks is None else masks[i], theta,
                                     self.alpha)
+            if dump is not None:
+                dump(i, cur)
         if self.final_dropout:
             cur = F.dropout(cur, self.dropout, training=self.training)
         if self.use_residue:
@@ -161,7 +177,7 @@ class GCNII_lyc(nn.Module):
             cur = F.log_softmax(self.fcs[-1](cur), dim=1)
         return cur
 
-    def _forward_generic(self, x, adj):
+    def _forward_generic(self, x, adj, dump=None):
         """Literal op-by-op composition (dense adjacency tensors, non-variant / residual layers)."""
         x = F.dropout(x, self.dropout, training=self.training)
         h0 = self.act_fn(self.fcs[0](x))
@@ -178,6 +194,8 @@ class GCNII_lyc(nn.Module):
                 cur = F.dropout(cur, self.dropout, training=self.training)
             if self.reason_flag:
                 cur = cur + q
+            if dump is not None:
+                dump(i, cur)
         if self.final_dropout:
             cur = F.dropout(cur, self.dropout, training=self.training)
         if self.use_residue:

@@ -103,3 +103,88 @@ def test_bucket_rejects_a_changing_live_parameter_set():
     model.a(x).sum().backward()                                            # 'b' gets no gradient this time
     with pytest.raises(RuntimeError, match="missing"):
         bucket.flatten()
+
+
+class TinySeq(torch.nn.Module):
+    """GRU-bearing stand-in with the parameter names of the real encoders (nn.GRU keys weight_ih_l*[ _reverse ]), so
+    that distributed.bucket_order's twin-adjacency rule and the live-set check run on the real ordering code."""
+
+    def __init__(self):
+        super().__init__()
+        self.proj = torch.nn.Linear(8, 8)
+        self.enc = torch.nn.GRU(8, 4, num_layers=2, bidirectional=True)
+        self.dead = torch.nn.Linear(3, 3)
+        self.head = torch.nn.Linear(8, 6)
+
+    def forward(self, xs):
+        outs = []
+        for x in xs:                                     # one dialogue at a time: (L_i, 8) -> (L_i, 6)
+            y, _ = self.enc(self.proj(x).unsqueeze(1))
+            outs.append(self.head(y.squeeze(1)))
+        return torch.log_softmax(torch.cat(outs), 1)
+
+
+def seq_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    distributed.init(backend="gloo")
+    torch.manual_seed(0)
+    model = TinySeq()
+    lengths, xs, ys = make_data()
+    mine = distributed.shard_dialogues(lengths, world, rank)
+    y = torch.cat([ys[i] for i in mine])
+    n_local = y.shape[0]
+    n_global = distributed.all_reduce_scalar(n_local, device="cpu")
+    bucket = distributed.GradientBucket(model)
+    loss_f = FocalLoss(gamma=0.5)
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        (loss_f(model([xs[i] for i in mine]), y) * (n_local * world / n_global)).backward()
+        bucket.all_reduce()
+    names = {id(p): n for n, p in model.named_parameters()}
+    order = [names[id(p)] for p in bucket.params]
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    # every gradient is a view of the one flat buffer, in bucket order
+    off, views_ok = 0, True
+    for p in bucket.params:
+        views_ok &= p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
+        off += p.numel()
+    # a parameter coming alive after the layout was frozen must raise on every rank (before any collective is issued)
+    model.zero_grad(set_to_none=True)
+    (loss_f(model([xs[i] for i in mine]), y) + model.dead(torch.ones(1, 3)).sum()).backward()
+    try:
+        bucket.all_reduce()
+        raised = ""
+    except RuntimeError as exc:
+        raised = str(exc)
+    torch.save({"grads": grads, "order": order, "views_ok": views_ok, "raised": raised, "bucket": bucket.flat.numel()},
+               out + ".%d" % rank)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bucket_order_keeps_gru_direction_pairs_adjacent(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "seq.pt")
+    mp.spawn(seq_worker, args=(2, port, out), nprocs=2, join=True)
+    got = [torch.load(out + ".%d" % r) for r in range(2)]
+    torch.manual_seed(0)
+    model = TinySeq()
+    lengths, xs, ys = make_data()
+    FocalLoss(gamma=0.5)(model(xs), torch.cat(ys)).backward()
+    for g in got:
+        order = g["order"]
+        assert g["views_ok"] and "dead" in g["raised"] and not any(n.startswith("dead") for n in order)
+        assert g["bucket"] == sum(p.numel() for n, p in model.named_parameters() if not n.startswith("dead"))
+        for layer in range(2):
+            for kind in ("weight_ih", "bias_ih"):
+                n = "enc.%s_l%d" % (kind, layer)
+                assert order.index(n + "_reverse") == order.index(n) + 1, order       # the fused GRU's stacked operand
+        # the recurrent weights keep model order (no pairing rule for them)
+        assert order.index("enc.weight_hh_l0") < order.index("enc.weight_hh_l0_reverse")
+        assert order == got[0]["order"]                                              # identical layout on every rank
+        for k, p in model.named_parameters():
+            if not k.startswith("dead"):
+                assert (g["grads"][k] - p.grad).abs().max() < 1e-6, k

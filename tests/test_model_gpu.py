@@ -329,3 +329,29 @@ def test_graph_convolution_module_against_reference_golden():
     for l in (1, 2, 16):
         with torch.no_grad():
             assert np.abs(conv(x, adj, h0, 0.5, 0.2, l).cpu().numpy() - g["gconv_l%d" % l]).max() < 1e-5
+
+
+def test_test_label_dumps_the_reference_activation_files(tmp_path, capsys):
+    """--test_label (reference model_GCN.py:474-480, model.py:1297-1301): per-layer outputs and the fused (N, 900)
+    features are saved under the reference's file names; the pass itself returns the same log-probabilities."""
+    cfg = dict(B=3, L=20, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+    model = synthetic.build_model(**cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 3))
+    model = model.to(DEV).eval()
+    model.graph_model.graph_net.test_output_dir = str(tmp_path) + "/"
+    b = synthetic.make_batch(4, lengths=[20, 11, 5], device=DEV, **cfg)
+    args = (b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])
+    with torch.no_grad():
+        plain = model(*args)[0]
+        dumped = model(*args, True)[0]
+    assert float((plain - dumped).abs().max()) < 1e-5
+    N = sum(b["lengths"])
+    multi = np.load(str(tmp_path / "1080_v2_test_output_multi_15.npy"))
+    assert multi.shape == (N, 900)
+    for i in range(2):
+        layer = np.load(str(tmp_path / ("1080_v1_test_output_layer_%d.npy" % i)))
+        assert layer.shape == (3 * N, 100)
+    # the last layer's output is the graph part of the fused features: columns 200:300 of every modality block
+    for m in range(3):
+        assert np.allclose(multi[:, 300 * m + 200:300 * (m + 1)], layer[m * N:(m + 1) * N], atol=1e-6)
+    assert "# deepGCN layer 0" in capsys.readouterr().out
