@@ -133,6 +133,8 @@ class _BuildAdjacency(torch.autograd.Function):
                                             *_lay_args(lay),
                                             lay.B, M, N, D, lay.max_len, ctx.modal_weight, _hip.stream())
         _hip.check(rc, "mmdfn_adj_build_bwd")
+        # the graph part of the backward pass ends here (the encoders' nodes follow): its queued weight gradients leave now
+        flush_queued_wgrads_early()
         return dfeats, None, None
 
 
@@ -480,7 +482,13 @@ def gemm_tn_grouped(problems):
 # The queue belongs to one backward pass: entering the outermost scope drops anything a failed backward left behind, and
 # leaving it flushes what the engine callback did not (or clears the queue when the backward raised).
 # ---------------------------------------------------------------------------------------------------
-_WGQ = {"segs": [], "outs": {}, "armed": False, "scope": 0}
+_WGQ = {"segs": [], "outs": {}, "armed": False, "scope": 0, "side": None, "held": [], "pending_join": False}
+# MMDFN_EARLY_WGRAD=1: issue the graph-side weight gradients (GCN stack, LSTM gate) on a second stream as soon as the graph
+# part of the backward pass is done, concurrently with the GRU backward recurrence.  OFF by default: measured slower at
+# cfg2 (1.133 vs 1.107 ms per step; the split batches cost 47.6 + 111.5 us against 140.3 us for one, and the concurrent
+# recurrence slows from 82.8 to 89.0 us -- timeline in profiles/r03_wgrad_overlap.md).  Kept because it is where a
+# two-part gradient bucket would start its first all-reduce on a multi-GPU node.
+EARLY_WGRAD = __import__("os").environ.get("MMDFN_EARLY_WGRAD", "0") == "1"
 _WG_MAX = 40        # TN_MAXSEG / TN_MAXOUT of csrc/gemm_tn.hip
 
 
@@ -502,6 +510,7 @@ class wgrad_batch:
                     flush_queued_wgrads()                  # a backward driven without the engine callback
             else:
                 _WGQ["outs"], _WGQ["armed"] = {}, False    # the callback never ran: drop the half-built batch
+            _join_side()
         return False
 
 
@@ -549,12 +558,38 @@ def queue_wgrad(A, B, weight, biases=(), shift=0, rows=None):
         torch.autograd.Variable._execution_engine.queue_callback(flush_queued_wgrads)
 
 
+def _join_side():
+    """The main stream waits for the side-stream batch (if one is in flight); its operands may be released afterwards."""
+    if _WGQ["pending_join"]:
+        torch.cuda.current_stream().wait_stream(_WGQ["side"])
+        _WGQ["pending_join"] = False
+    _WGQ["held"] = []
+
+
+def flush_queued_wgrads_early():
+    """Called where the graph part of the backward pass ends (the adjacency builder's backward): what is queued so far
+    leaves NOW on a side stream, concurrently with the encoder backward that follows on the main stream.  Gradient
+    buffers and the workspace are allocated on the main stream (the caching allocator's stream of record), the operands
+    stay referenced until the main stream has waited for the side stream (end-of-backward callback)."""
+    if not (EARLY_WGRAD and _WGQ["scope"] > 0 and _WGQ["outs"]):
+        return
+    outs = list(_WGQ["outs"].values())
+    _WGQ["outs"] = {}                        # 'armed' stays: the end-of-backward callback flushes the rest and joins
+    if _WGQ["side"] is None:
+        _WGQ["side"] = torch.cuda.Stream()
+    _flush_outs(outs, _WGQ["side"])
+
+
 def flush_queued_wgrads():
     """Issue every queued weight-gradient contraction (one launch pair per <= 40 segments) into the .grad fields."""
     outs = list(_WGQ["outs"].values())
     _WGQ["outs"], _WGQ["armed"] = {}, False
-    if not outs:
-        return
+    _join_side()             # first: a parameter may collect contributions from both batches (the later one accumulates)
+    if outs:
+        _flush_outs(outs, None)
+
+
+def _flush_outs(outs, side):
     dev = outs[0]["weight"].device
     # gradient destinations: fresh buffers handed to .grad (the usual case: backward runs with .grad = None), or the
     # existing .grad accumulated in place
@@ -591,18 +626,30 @@ def flush_queued_wgrads():
         segs = o["segs"]
         for i in range(0, len(segs), _WG_MAX):          # a parameter with > 40 contributions: later pieces accumulate
             work.append((o, C, cs, 1 if (acc_here or i > 0) else 0, segs[i:i + _WG_MAX]))
-    batch, nseg = [], 0
+    batches, batch, nseg = [], [], 0
     for item in work:
         if batch and (nseg + len(item[4]) > _WG_MAX or len(batch) >= _WG_MAX):
-            _launch_wgrad_batch(batch)
+            batches.append(batch)
             batch, nseg = [], 0
         batch.append(item)
         nseg += len(item[4])
     if batch:
-        _launch_wgrad_batch(batch)
+        batches.append(batch)
+    prepared = [_prepare_wgrad_batch(b) for b in batches]          # allocations (workspace) on the current stream
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())             # operands, zero fills and allocations are ordered before
+        _WGQ["held"].append((outs, prepared))
+        _WGQ["pending_join"] = True
+    stream = _hip.stream() if side is None else ctypes.c_void_p(side.cuda_stream)
+    for call in prepared:
+        call(stream)
 
 
 def _launch_wgrad_batch(batch):
+    _prepare_wgrad_batch(batch)(_hip.stream())
+
+
+def _prepare_wgrad_batch(batch):
     lib = _hip.lib()
     ia = _hip.int_array
     A, B, R, lda, ldb, sh, oi = [], [], [], [], [], [], []
@@ -622,9 +669,12 @@ def _launch_wgrad_batch(batch):
         raise _hip.HipLibraryError("mmdfn_gemm_tn_batch_workspace rejected the batch")
     ws = torch.empty(int(nws), dtype=torch.float32, device=A[0].device)
     pa = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
-    rc = lib.mmdfn_gemm_tn_batch(len(A), pa(A), pa(B), ia(R), ia(lda), ia(ldb), ia(sh), ia(oi), len(C), pa(C), pa(cs1),
-                                 pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), _hip.stream())
-    _hip.check(rc, "mmdfn_gemm_tn_batch")
+
+    def call(stream, _keep=(A, B, C, cs1, cs2, ws)):
+        rc = lib.mmdfn_gemm_tn_batch(len(A), pa(A), pa(B), ia(R), ia(lda), ia(ldb), ia(sh), ia(oi), len(C), pa(C), pa(cs1),
+                                     pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), stream)
+        _hip.check(rc, "mmdfn_gemm_tn_batch")
+    return call
 
 
 def join_weight_grads():
