@@ -36,6 +36,7 @@ struct FwdGroups {
     int rows[MAXG];
     int T[MAXG];
     int slice0[MAXG + 1];
+    int abl;                       // tuning build only (MMDFN_GRU_ABL): timing ablations of the forward step, wrong results
 };
 
 struct BwdGroups {
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     const int uu = active ? u : GH - 1;
     const int kbase = half ? KH0 : 0;
     const int klen = half ? GH - KH0 : KH0;
+#ifdef MMDFN_TUNING
+    const int abl = G.abl;         // 1 no matvec, 2 no transcendental gate math, 4 no block traffic (stash / flush / prefetch),
+                                   // 8 no deferred result writes, 16 no per-step barrier
+#else
+    constexpr int abl = 0;
+#endif
 
     // weights as packed pairs: v_pk_fma_f32 retires two FMAs per issue slot (a single wave per SIMD issues
     // one VALU instruction every ~4 cycles, so halving the instruction count halves the matvec time)
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
         const int buf = b & 1;
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int cur = step & 1;
-            if (have_pend) write_pending();
+            if (have_pend && !(abl & 8)) write_pending();
             float g0[R], g1[R], g2[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -242,17 +249,63 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             for (int r = 0; r < R; ++r) {
                 f32x2 ar0 = {0.f, 0.f}, az0 = {0.f, 0.f}, an0 = {0.f, 0.f}, ar1 = {0.f, 0.f}, az1 = {0.f, 0.f}, an1 = {0.f, 0.f};
                 const float4* hv = reinterpret_cast<const float4*>(&hs[cur][r][kbase]);
+                if (abl & 1) {
+                    ar0[0] = hs[cur][r][u & 63];
+                } else if constexpr (R == 1) {
+                    // The 13 broadcast loads of h_{t-1} run HLOOK groups ahead of their six packed FMAs, through a ring of
+                    // HLOOK float4 registers filled by inline-asm ds_read_b128 and retired with hand-counted lgkmcnt waits.
+                    // Left to itself hipcc keeps two loads in flight (the weights hold 156 of the 256 VGPRs), so every
+                    // group of FMAs (~25 cycles of issue) waited for an LDS round trip: ~9 exposed waits per step, the largest
+                    // single item of the step (profiles/r03_gru_kernels.md).  "memory" keeps the compiler's own LDS
+                    // operations (the gate operands above, the result writes) out of the counted window.
+                    constexpr int HLOOK = 6;
+                    const uint32_t haddr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const float*)(&hs[cur][0][kbase]));
+                    f32x4 hb[HLOOK];
+#define GRU_LDS_RD(J)                                                                                        \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(hb[(J) % HLOOK]) : "v"(haddr), "i"(16 * (J)) : "memory")
+#define GRU_LDS_WAIT(N, J) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(hb[(J) % HLOOK]) : : "memory")
+                    GRU_LDS_RD(0); GRU_LDS_RD(1); GRU_LDS_RD(2); GRU_LDS_RD(3); GRU_LDS_RD(4); GRU_LDS_RD(5);
+#define GRU_GROUP(K4)                                                                                        \
+    do {                                                                                                     \
+        const f32x4 h4 = hb[(K4) % HLOOK];                                                                   \
+        const f32x2 ha = {h4.x, h4.y}, hb2 = {h4.z, h4.w};                                                   \
+        ar0 = __builtin_elementwise_fma(wr[2 * (K4)], ha, ar0);                                              \
+        az0 = __builtin_elementwise_fma(wz[2 * (K4)], ha, az0);                                              \
+        an0 = __builtin_elementwise_fma(wn[2 * (K4)], ha, an0);                                              \
+        ar1 = __builtin_elementwise_fma(wr[2 * (K4) + 1], hb2, ar1);                                         \
+        az1 = __builtin_elementwise_fma(wz[2 * (K4) + 1], hb2, az1);                                         \
+        an1 = __builtin_elementwise_fma(wn[2 * (K4) + 1], hb2, an1);                                         \
+    } while (0)
+                    // group k waits until at most min(5, 12 - k) younger loads are outstanding, then its slot is reloaded
+                    GRU_LDS_WAIT(5, 0); GRU_GROUP(0); GRU_LDS_RD(6);
+                    GRU_LDS_WAIT(5, 1); GRU_GROUP(1); GRU_LDS_RD(7);
+                    GRU_LDS_WAIT(5, 2); GRU_GROUP(2); GRU_LDS_RD(8);
+                    GRU_LDS_WAIT(5, 3); GRU_GROUP(3); GRU_LDS_RD(9);
+                    GRU_LDS_WAIT(5, 4); GRU_GROUP(4); GRU_LDS_RD(10);
+                    GRU_LDS_WAIT(5, 5); GRU_GROUP(5); GRU_LDS_RD(11);
+                    GRU_LDS_WAIT(5, 6); GRU_GROUP(6); GRU_LDS_RD(12);
+                    GRU_LDS_WAIT(5, 7); GRU_GROUP(7);
+                    GRU_LDS_WAIT(4, 8); GRU_GROUP(8);
+                    GRU_LDS_WAIT(3, 9); GRU_GROUP(9);
+                    GRU_LDS_WAIT(2, 10); GRU_GROUP(10);
+                    GRU_LDS_WAIT(1, 11); GRU_GROUP(11);
+                    GRU_LDS_WAIT(0, 12); GRU_GROUP(12);
+#undef GRU_GROUP
+#undef GRU_LDS_WAIT
+#undef GRU_LDS_RD
+                } else {
 #pragma unroll
-                for (int k4 = 0; k4 < KW / 4; ++k4) {
-                    // the second half has 12 real float4 (48 floats); its 13th reads the 4 zero pad floats
-                    const float4 h4 = hv[k4];
-                    const f32x2 ha = {h4.x, h4.y}, hb = {h4.z, h4.w};
-                    ar0 = __builtin_elementwise_fma(wr[2 * k4], ha, ar0);
-                    az0 = __builtin_elementwise_fma(wz[2 * k4], ha, az0);
-                    an0 = __builtin_elementwise_fma(wn[2 * k4], ha, an0);
-                    ar1 = __builtin_elementwise_fma(wr[2 * k4 + 1], hb, ar1);
-                    az1 = __builtin_elementwise_fma(wz[2 * k4 + 1], hb, az1);
-                    an1 = __builtin_elementwise_fma(wn[2 * k4 + 1], hb, an1);
+                    for (int k4 = 0; k4 < KW / 4; ++k4) {
+                        // the second half has 12 real float4 (48 floats); its 13th reads the 4 zero pad floats
+                        const float4 h4 = hv[k4];
+                        const f32x2 ha = {h4.x, h4.y}, hb = {h4.z, h4.w};
+                        ar0 = __builtin_elementwise_fma(wr[2 * k4], ha, ar0);
+                        az0 = __builtin_elementwise_fma(wz[2 * k4], ha, az0);
+                        an0 = __builtin_elementwise_fma(wn[2 * k4], ha, an0);
+                        ar1 = __builtin_elementwise_fma(wr[2 * k4 + 1], hb, ar1);
+                        az1 = __builtin_elementwise_fma(wz[2 * k4 + 1], hb, az1);
+                        an1 = __builtin_elementwise_fma(wn[2 * k4 + 1], hb, an1);
+                    }
                 }
                 float ar = (ar0.x + ar0.y) + (ar1.x + ar1.y);
                 float az = (az0.x + az0.y) + (az1.x + az1.y);
@@ -262,9 +315,9 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
                 an += pair_swap(an);
                 {   // (every lane does the gate math -- a conditional would pull the operand reads back behind the matvec)
                     const float ghn = an + bhn;
-                    const float rr = sigmoidf_(g0[r] + ar + bhr);
-                    const float zz = sigmoidf_(g1[r] + az + bhz);
-                    const float nn = tanhf_(g2[r] + rr * ghn);
+                    const float rr = (abl & 2) ? (g0[r] + ar + bhr) * 0.01f : sigmoidf_(g0[r] + ar + bhr);
+                    const float zz = (abl & 2) ? (g1[r] + az + bhz) * 0.01f : sigmoidf_(g1[r] + az + bhz);
+                    const float nn = (abl & 2) ? (g2[r] + rr * ghn) * 0.01f : tanhf_(g2[r] + rr * ghn);
                     const float hnew = (1.0f - zz) * nn + zz * hprev[r];
                     if (mine[r]) hs[cur ^ 1][r][u] = hnew;
                     hprev[r] = hnew;
@@ -277,17 +330,258 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             }
             have_pend = true;
             pend_sl = sl;
-            __syncthreads();
+            if (!(abl & 16)) __syncthreads();
         }
         if (have_pend) write_pending();
         have_pend = false;
         __syncthreads();                        // the block's results are complete in out_s
         // block boundary: next block's operands (loaded a block ago) drop into LDS, this block's results
         // leave, and the loads of block b+2 are issued
-        if (b + 1 < nblocks) stash_block(buf ^ 1);
-        flush_block(b);
-        if (b + 2 < nblocks) load_block(b + 2);
+        if (!(abl & 4)) {
+            if (b + 1 < nblocks) stash_block(buf ^ 1);
+            flush_block(b);
+            if (b + 2 < nblocks) load_block(b + 2);
+        }
         __syncthreads();
+    }
+}
+
+// =====================================================================================================
+// Forward pass, one sequence per workgroup, with a FIFTH wave that does all the global-memory traffic.
+//
+// Ablations of the 4-wave kernel above (tools/ablate_gru_fwd.py, profiles/r03_gru_kernels.md): of a 0.90 us step the matvec
+// is 35 %, the block traffic (every 8 steps all four waves stop to move the next operands registers -> LDS, drain the
+// results LDS -> global and issue the next prefetch: two more barriers, index arithmetic, LDS round trips) 22 %, the
+// per-step barrier 14 %, the five scattered result writes per step 8 %, the transcendental gate math 6 %.  Here the four
+// recurrence waves never touch global memory inside the time loop: wave 4 prefetches the gate pre-activations of block
+// b+1 (TB steps) into the other half of a double-buffered LDS array and drains the results of block b-1 from the other half
+// of a double-buffered result array, one step's worth per step, and joins the same per-step barrier; the block boundary
+// needs no barrier of its own (the last step of a block writes its results before its barrier instead of after it).  A unit's
+// five results go to LDS as one 16-byte + one 4-byte write ([unit][8] layout) instead of five 4-byte writes.
+// =====================================================================================================
+// ABL (tuning build, timing only): 1 no matvec, 2 no transcendental gate math, 4 no result writes, 8 no h exchange wait
+// (the LDS write of h stays, the barrier goes), 16 no gate-operand reads
+template <int SCALAR_FMA, int ABL>
+__global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
+    constexpr int TB = 4;                          // steps per block
+    constexpr int NLD = (TB * 3 * GH / 4 + 63) / 64;   // float4 loads per I/O lane and block (5)
+    __shared__ __attribute__((aligned(16))) float hs[2][GH + 4];
+    __shared__ __attribute__((aligned(16))) float in_s[2][TB][3 * GH];
+    __shared__ __attribute__((aligned(16))) float out_s[2][TB][GH][8];     // y r z n | W_hn h + b_hn, 3 pad
+
+    int gidx = 0;
+    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
+    const int dir = blockIdx.y;
+    const int rows = G.rows[gidx];
+    const int T = G.T[gidx];
+    const int row = (int)blockIdx.x - G.slice0[gidx];
+    const float* __restrict__ gi = G.gi[gidx];
+    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
+    const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
+    float* __restrict__ y = G.y[gidx];
+    float* __restrict__ gates = G.gates[gidx];
+    const int tid = threadIdx.x;
+    const int nblocks = (T + TB - 1) / TB;
+
+    if (tid >= NT) {
+        // ---------------- the I/O wave ----------------
+        const int lane = tid - NT;
+        float4 gq[NLD];
+        auto load_block = [&](int b) {             // gi of block b: TB steps x 300 floats, 16 bytes per lane and load
+#pragma unroll
+            for (int e = 0; e < NLD; ++e) {
+                const int idx = lane + 64 * e;
+                const int sl = idx / (3 * GH / 4);
+                const int c4 = idx - sl * (3 * GH / 4);
+                const int sidx = b * TB + sl;
+                gq[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sl < TB && sidx < T) {
+                    const int t = dir ? T - 1 - sidx : sidx;
+                    gq[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH + 4 * c4);
+                }
+            }
+        };
+        auto stash_block = [&](int buf) {
+#pragma unroll
+            for (int e = 0; e < NLD; ++e) {
+                const int idx = lane + 64 * e;
+                if (idx < TB * 3 * GH / 4) *reinterpret_cast<float4*>(&in_s[buf][0][0] + 4 * idx) = gq[e];
+            }
+        };
+        auto flush_step = [&](int b, int sl) {     // results of step (b, sl): lanes = consecutive units (coalesced rows)
+            const int sidx = b * TB + sl;
+            if (sidx >= T) return;
+            const int t = dir ? T - 1 - sidx : sidx;
+            const int64_t o = (int64_t)t * rows + row;
+            float* yp = y + o * (2 * GH) + dir * GH;
+            float* gp = gates + (o * 2 + dir) * (4 * GH);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int u = lane + 64 * q;
+                if (u < GH) {
+                    const float4 v = *reinterpret_cast<const float4*>(&out_s[b & 1][sl][u][0]);
+                    const float g4 = out_s[b & 1][sl][u][4];
+                    yp[u] = v.x;
+                    gp[u] = v.y;
+                    gp[GH + u] = v.z;
+                    gp[2 * GH + u] = v.w;
+                    gp[3 * GH + u] = g4;
+                }
+            }
+        };
+        load_block(0);
+        stash_block(0);
+        __syncthreads();                           // (A) block 0 operands in LDS, h_0 = 0 written by the recurrence waves
+        int step = 0;
+        int fl = 0;                                // next step whose results are still to be drained
+        for (int b = 0; b < nblocks; ++b) {
+            if (b + 1 < nblocks) load_block(b + 1);
+            for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
+                if (fl < b * TB) {                 // one finished step of an earlier block per step (its block is complete)
+                    flush_step(fl / TB, fl % TB);
+                    ++fl;
+                }
+                const bool last = (sl == TB - 1) || (step == T - 1);
+                if (last && b + 1 < nblocks) stash_block((b + 1) & 1);
+                if (!(ABL & 8)) __syncthreads();   // the recurrence waves' per-step barrier
+            }
+        }
+        for (; fl < T; ++fl) flush_step(fl / TB, fl % TB);
+        return;
+    }
+
+    // ---------------- the four recurrence waves (lane pair (2u, 2u+1) = hidden unit u x half of the contraction) ----------------
+    const int u = tid >> 1;
+    const int half = tid & 1;
+    const bool active = u < GH;
+    const int uu = active ? u : GH - 1;
+    const int kbase = half ? KH0 : 0;
+    const int klen = half ? GH - KH0 : KH0;
+    f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const bool ok = k < klen;
+        const int kk = kbase + (ok ? k : 0);
+        wr[k >> 1][k & 1] = ok ? w_hh[(int64_t)(0 * GH + uu) * GH + kk] : 0.f;
+        wz[k >> 1][k & 1] = ok ? w_hh[(int64_t)(1 * GH + uu) * GH + kk] : 0.f;
+        wn[k >> 1][k & 1] = ok ? w_hh[(int64_t)(2 * GH + uu) * GH + kk] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < KW / 2; ++k) {
+        pin_loaded(wr[k]);
+        pin_loaded(wz[k]);
+        pin_loaded(wn[k]);
+    }
+    float bhr = b_hh[uu], bhz = b_hh[GH + uu], bhn = b_hh[2 * GH + uu];
+    pin_loaded(bhr);
+    pin_loaded(bhz);
+    pin_loaded(bhn);
+    const bool mine = active && half == 0;
+    float hprev = 0.f;
+    for (int i = tid; i < 2 * (GH + 4); i += NT) (&hs[0][0])[i] = 0.f;
+    __syncthreads();                               // (A)
+
+    __shared__ __attribute__((aligned(16))) float scratch[NT][8];      // write target of lanes that own no unit
+    const uint32_t scratch_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)(&scratch[tid][0]));
+    f32x4 pend4 = {0.f, 0.f, 0.f, 0.f};
+    float pend1 = 0.f;
+    uint32_t pend_addr = scratch_addr;
+    int step = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
+            const int cur = step & 1;
+            // LDS operations of a step in ISSUE order (a wave's LDS operations execute in order, so anything queued in front of
+            // the h loads delays the first FMA by its whole service time): six h loads, then the matvec with its reloads, and
+            // only behind the LAST h load the three gate operands of this step and the two result writes of the previous
+            // one -- all from inline asm, so the hand-counted lgkmcnt waits below are exact.  Lanes that own no unit write to
+            // a scratch slot (no exec-mask branch in the step).
+            const uint32_t gaddr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const float*)(&in_s[b & 1][sl][uu]));
+            float g0, g1, g2;
+            f32x2 ar0 = {0.f, 0.f}, az0 = {0.f, 0.f}, an0 = {0.f, 0.f}, ar1 = {0.f, 0.f}, az1 = {0.f, 0.f}, an1 = {0.f, 0.f};
+            if (ABL & 1) {
+                ar0[0] = hs[cur][u & 63];
+                const float* gp = &in_s[b & 1][sl][uu];
+                g0 = gp[0]; g1 = gp[GH]; g2 = gp[2 * GH];
+            } else {
+                // 13 broadcast loads of h_{t-1} through a ring of six float4 registers, six groups ahead of their FMAs
+                constexpr int HLOOK = 6;
+                const uint32_t haddr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const float*)(&hs[cur][kbase]));
+                f32x4 hb[HLOOK];
+#define GRU_LDS_RD(J)                                                                                        \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(hb[(J) % HLOOK]) : "v"(haddr), "i"(16 * (J)) : "memory")
+#define GRU_LDS_WAIT(N, J) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(hb[(J) % HLOOK]) : : "memory")
+#define GRU_FMA1(ACC, W, H) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(W), "v"(H))
+#define GRU_GROUP(K4)                                                                                        \
+    do {                                                                                                     \
+        const f32x4 h4 = hb[(K4) % HLOOK];                                                                   \
+        if (SCALAR_FMA) {   /* plain v_fma_f32 (not SLP-packed): A/B against v_pk_fma_f32 */                 \
+            GRU_FMA1(ar0[0], wr[2 * (K4)][0], h4.x); GRU_FMA1(az0[0], wz[2 * (K4)][0], h4.x); GRU_FMA1(an0[0], wn[2 * (K4)][0], h4.x); \
+            GRU_FMA1(ar0[1], wr[2 * (K4)][1], h4.y); GRU_FMA1(az0[1], wz[2 * (K4)][1], h4.y); GRU_FMA1(an0[1], wn[2 * (K4)][1], h4.y); \
+            GRU_FMA1(ar1[0], wr[2 * (K4) + 1][0], h4.z); GRU_FMA1(az1[0], wz[2 * (K4) + 1][0], h4.z); GRU_FMA1(an1[0], wn[2 * (K4) + 1][0], h4.z); \
+            GRU_FMA1(ar1[1], wr[2 * (K4) + 1][1], h4.w); GRU_FMA1(az1[1], wz[2 * (K4) + 1][1], h4.w); GRU_FMA1(an1[1], wn[2 * (K4) + 1][1], h4.w); \
+        } else {                                                                                             \
+            const f32x2 ha = {h4.x, h4.y}, hb2 = {h4.z, h4.w};                                               \
+            ar0 = __builtin_elementwise_fma(wr[2 * (K4)], ha, ar0);                                          \
+            az0 = __builtin_elementwise_fma(wz[2 * (K4)], ha, az0);                                          \
+            an0 = __builtin_elementwise_fma(wn[2 * (K4)], ha, an0);                                          \
+            ar1 = __builtin_elementwise_fma(wr[2 * (K4) + 1], hb2, ar1);                                     \
+            az1 = __builtin_elementwise_fma(wz[2 * (K4) + 1], hb2, az1);                                     \
+            an1 = __builtin_elementwise_fma(wn[2 * (K4) + 1], hb2, an1);                                     \
+        }                                                                                                    \
+    } while (0)
+                GRU_LDS_RD(0); GRU_LDS_RD(1); GRU_LDS_RD(2); GRU_LDS_RD(3); GRU_LDS_RD(4); GRU_LDS_RD(5);
+                GRU_LDS_WAIT(5, 0); GRU_GROUP(0); GRU_LDS_RD(6);
+                GRU_LDS_WAIT(5, 1); GRU_GROUP(1); GRU_LDS_RD(7);
+                GRU_LDS_WAIT(5, 2); GRU_GROUP(2); GRU_LDS_RD(8);
+                GRU_LDS_WAIT(5, 3); GRU_GROUP(3); GRU_LDS_RD(9);
+                GRU_LDS_WAIT(5, 4); GRU_GROUP(4); GRU_LDS_RD(10);
+                GRU_LDS_WAIT(5, 5); GRU_GROUP(5); GRU_LDS_RD(11);
+                GRU_LDS_WAIT(5, 6); GRU_GROUP(6); GRU_LDS_RD(12);
+                // five more LDS operations behind the last h load: g0 g1 g2 of this step, the previous step's results
+                if (ABL & 16) { g0 = 0.1f; g1 = 0.2f; g2 = 0.3f; }
+                asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:400\n\tds_read_b32 %2, %3 offset:800"
+                             : "=&v"(g0), "=&v"(g1), "=&v"(g2) : "v"(gaddr) : "memory");
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16" : : "v"(pend_addr), "v"(pend4), "v"(pend1) : "memory");
+                GRU_LDS_WAIT(10, 7); GRU_GROUP(7);
+                GRU_LDS_WAIT(9, 8); GRU_GROUP(8);
+                GRU_LDS_WAIT(8, 9); GRU_GROUP(9);
+                GRU_LDS_WAIT(7, 10); GRU_GROUP(10);
+                GRU_LDS_WAIT(6, 11); GRU_GROUP(11);
+                GRU_LDS_WAIT(5, 12); GRU_GROUP(12);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(g0), "+v"(g1), "+v"(g2) : : "memory");     // the two writes may still drain
+#undef GRU_GROUP
+#undef GRU_FMA1
+#undef GRU_LDS_WAIT
+#undef GRU_LDS_RD
+            }
+            float ar = (ar0.x + ar0.y) + (ar1.x + ar1.y);
+            float az = (az0.x + az0.y) + (az1.x + az1.y);
+            float an = (an0.x + an0.y) + (an1.x + an1.y);
+            ar += pair_swap(ar);
+            az += pair_swap(az);
+            an += pair_swap(an);
+            const float ghn = an + bhn;
+            const float rr = (ABL & 2) ? (g0 + ar + bhr) * 0.01f : sigmoidf_(g0 + ar + bhr);
+            const float zz = (ABL & 2) ? (g1 + az + bhz) * 0.01f : sigmoidf_(g1 + az + bhz);
+            const float nn = (ABL & 2) ? (g2 + rr * ghn) * 0.01f : tanhf_(g2 + rr * ghn);
+            const float hnew = (1.0f - zz) * nn + zz * hprev;
+            if (mine) hs[cur ^ 1][u] = hnew;
+            hprev = hnew;
+            // results: owners -> out_s[block][step][unit][0..4]; every other lane -> its private scratch slot.  Kept in
+            // registers across the barrier and written from the middle of the next step's matvec; the last step of a block
+            // (whose results the I/O wave drains right behind this barrier) writes them now.
+            const uint32_t oaddr = mine ? (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)(&out_s[b & 1][sl][u][0]))
+                                        : scratch_addr;
+            const bool last = (sl == TB - 1) || (step == T - 1);
+            pend4 = f32x4{hnew, rr, zz, nn};
+            pend1 = ghn;
+            pend_addr = oaddr;
+            if (last) {
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16" : : "v"(pend_addr), "v"(pend4), "v"(pend1) : "memory");
+                pend_addr = scratch_addr;          // (the next step's deferred write then lands in the scratch slot)
+            }
+            if (!(ABL & 8)) __syncthreads();
+        }
     }
 }
 
@@ -709,6 +1003,10 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     if (ngroups <= 0 || ngroups > MAXG || H != GH) return -1;
     FwdGroups G;
     G.n = ngroups;
+    G.abl = 0;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_ABL")) G.abl = atoi(e);
+#endif
     const int R = pick_r(ngroups, rows);
     int sl = 0;
     for (int g = 0; g < ngroups; ++g) {
@@ -722,7 +1020,22 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
+    bool io_wave = (R == 1);
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_IO")) io_wave = io_wave && e[0] != '0';      // A/B aid
+#endif
+    bool scalar_fma = false;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_SCALAR_FMA")) scalar_fma = e[0] == '1';
+#endif
+#ifdef MMDFN_TUNING
+#define GRU_IO_ABL(A) if (io_wave && G.abl == A) { hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, A>), grid, dim3(320), 0, s, G); MMDFN_CHECK_LAUNCH(); return 0; }
+    GRU_IO_ABL(1) GRU_IO_ABL(2) GRU_IO_ABL(4) GRU_IO_ABL(8) GRU_IO_ABL(16) GRU_IO_ABL(3) GRU_IO_ABL(11) GRU_IO_ABL(31) GRU_IO_ABL(23)
+#undef GRU_IO_ABL
+#endif
+    if (io_wave && scalar_fma) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<1, 0>), grid, dim3(320), 0, s, G);
+    else if (io_wave) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0>), grid, dim3(320), 0, s, G);
+    else if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_fwd_kernel<4>, grid, block, 0, s, G);
     MMDFN_CHECK_LAUNCH();

@@ -1,5 +1,6 @@
-"""Timing ablations of the forward GRU recurrence (tuning build, MMDFN_GRU_ABL bits: 1 no FMAs, 2 no transcendentals,
-4 no barrier, 8 no staged-operand reads / result writes).  cfg2 shapes: 16 + 64 sequences, T = 110."""
+"""Timing ablations of the forward GRU recurrence (tuning build, MMDFN_GRU_ABL bits: 1 no matvec, 2 no transcendental gate
+math, 4 no block traffic (stash / flush / prefetch of the 8-step blocks), 8 no deferred result writes, 16 no per-step
+barrier; wrong results).  cfg2 shapes: 16 + 64 sequences, T = 110."""
 import os, sys
 os.environ["MMDFN_TUNING_LIB"] = "1"
 import torch
@@ -22,7 +23,11 @@ def run():
     assert rc == 0
 
 
-for abl in (0, 1, 2, 3, 4, 7, 8, 11, 15, 0):
+variants = [("io", "1", "0", 0), ("io+scalar-fma", "1", "1", 0), ("4-wave", "0", "0", 0), ("io", "1", "0", 0), ("io+scalar-fma", "1", "1", 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "abl":
+    variants = [("io abl %d" % a, "1", "0", a) for a in (0, 1, 2, 4, 8, 16, 3, 11, 23, 31, 0)]
+for name, io, sf, abl in variants:
+    os.environ["MMDFN_GRU_IO"], os.environ["MMDFN_GRU_SCALAR_FMA"] = io, sf
     if abl:
         os.environ["MMDFN_GRU_ABL"] = str(abl)
     else:
@@ -40,4 +45,4 @@ for abl in (0, 1, 2, 3, 4, 7, 8, 11, 15, 0):
     for _ in range(5):
         g.replay()
     e1.record(); e1.synchronize()
-    print("abl %2d: %6.1f us per launch, %.3f us per step" % (abl, e0.elapsed_time(e1) * 1e3 / 50, e0.elapsed_time(e1) * 1e3 / 50 / 110), flush=True)
+    print("%-16s: %6.1f us per launch, %.3f us per step" % (name, e0.elapsed_time(e1) * 1e3 / 50, e0.elapsed_time(e1) * 1e3 / 50 / 110), flush=True)
