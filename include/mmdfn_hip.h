@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 8). */
+/* Library / device sanity: returns the ABI version (currently 9). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -213,6 +213,20 @@ int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, in
  * launch on the parameters themselves, without a concatenated copy per step.  N1 == N: W2 / bias2 unused. */
 int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const float* bias, const float* bias2,
                   float* Y, int R, int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
+
+/* A GROUP of few-row projections in one launch (linear_small.hip; n <= 8 problems, K <= 768, K % 4 == 0):
+ *   Y_p = act(X_p W_p^T + b_p) (+ Y_p)      X_p: R_p rows of K_p floats (stride ldx), Y_p: R_p x N_p (stride ldy)
+ *   kmajor[p] == 0: W_p is (N, K) with k-contiguous rows (row stride ldw), given as two row blocks W / W2 split at
+ *                   N1 (N1 == N: one block), biases likewise;
+ *   kmajor[p] != 0: W_p is (K, N) with n-contiguous rows (row stride ldw): the input gradient dX = dY . Wcat of a dense
+ *                   layer reads the stacked weight as stored.
+ * Replaces the modality projections model.py:1065,1094,1129, the hoisted GRU input contractions model.py:1082,1132
+ * and their autograd input gradients at BASELINE cfg2-cfg4 row counts.  mmdfn_linear_group_supported: 1 if covered. */
+int mmdfn_linear_group_supported(int R, int K, int N);
+int mmdfn_linear_group(int n, const float* const* X, const float* const* W, const float* const* W2, const int* N1,
+                       const float* const* bias, const float* const* bias2, float* const* Y, const int* R,
+                       const int* K, const int* N, const int* ldx, const int* ldw, const int* ldy,
+                       const int* kmajor, const int* accumulate, int act, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Weight-gradient contraction (autograd of the dense layers on the path: dW = dY^T X, db = sum_r dY):

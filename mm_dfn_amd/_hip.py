@@ -36,6 +36,8 @@ SIGNATURES = {
     "mmdfn_gcnii_layer_bwd": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _P],
     "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_linear_group_supported": [_I, _I, _I],
+    "mmdfn_linear_group": [_I] + [_P] * 15 + [_I, _P],
     "mmdfn_gemm_tn_splits": [_I, _I, _I],
     "mmdfn_gemm_tn": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_gemm_tn_grouped_workspace": [_I, _P, _P, _P],
@@ -55,7 +57,7 @@ SIGNATURES = {
     "mmdfn_mask_scale": [_I, _P, _P, _P, _P, _F, _P],
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipLibraryError(RuntimeError):

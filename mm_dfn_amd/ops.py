@@ -387,6 +387,52 @@ def linear_raw(x2d, weight, bias=None, act=0, out=None, accumulate=False):
     return out
 
 
+def linear_group_raw(problems, act=0):
+    """One launch for up to 8 few-row projections (csrc/linear_small.hip).  Each problem is a dict: x (R, K) fp32 rows,
+    either ``w`` (N, K) [+ ``w2`` (N2, K): second row block] with optional ``b`` / ``b2``, or ``wk`` (K, N) (n-contiguous:
+    y = x @ wk); optional ``out`` (+ ``accumulate``).  Returns the outputs."""
+    n = len(problems)
+    X, W, W2, B1, B2, Y = [], [], [], [], [], []
+    R, K, N, N1, ldx, ldw, ldy, km, acc = [], [], [], [], [], [], [], [], []
+    for q in problems:
+        x = q["x"]
+        if x.dtype != torch.float32 or x.dim() != 2:
+            raise ValueError("linear_group_raw: x must be an fp32 matrix")
+        if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+            x = x.contiguous()
+        if "wk" in q:
+            w = q["wk"]
+            w = w if (w.stride(1) == 1) else w.contiguous()
+            k_, n_ = w.shape
+            W.append(w); W2.append(None); B1.append(None); B2.append(None); N1.append(n_); km.append(1); ldw.append(w.stride(0))
+        else:
+            w, w2 = q["w"], q.get("w2")
+            w = w if w.is_contiguous() else w.contiguous()
+            if w2 is not None and not w2.is_contiguous():
+                w2 = w2.contiguous()
+            n_, k_ = w.shape[0] + (w2.shape[0] if w2 is not None else 0), w.shape[1]
+            W.append(w); W2.append(w2); B1.append(q.get("b")); B2.append(q.get("b2")); N1.append(w.shape[0]); km.append(0)
+            ldw.append(k_)
+        if x.shape[1] != k_:
+            raise ValueError("linear_group_raw: contraction widths differ")
+        out = q.get("out")
+        if out is None:
+            out = torch.empty(x.shape[0], n_, dtype=torch.float32, device=x.device)
+        X.append(x); Y.append(out); R.append(x.shape[0]); K.append(k_); N.append(n_); ldx.append(x.stride(0)); ldy.append(out.stride(0))
+        acc.append(1 if q.get("accumulate") else 0)
+    _hip.require_cuda(*X, *W)
+    _hip.require_f32(*X, *W)
+    ia, pa = _hip.int_array, _hip.ptr_array
+    rc = _hip.lib().mmdfn_linear_group(n, pa(X), pa(W), pa(W2), ia(N1), pa(B1), pa(B2), pa(Y), ia(R), ia(K), ia(N), ia(ldx),
+                                       ia(ldw), ia(ldy), ia(km), ia(acc), int(act), _hip.stream())
+    _hip.check(rc, "mmdfn_linear_group")
+    return Y
+
+
+def linear_group_supported(R, K, N):
+    return bool(_hip.lib().mmdfn_linear_group_supported(int(R), int(K), int(N)))
+
+
 def linear_supported(x, weight):
     return x.is_cuda and x.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 4
 
@@ -807,9 +853,16 @@ class _LinearGroup(torch.autograd.Function):
     def forward(ctx, act, n, *args):
         xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
         ys, saved = [], []
-        for x, w, b in zip(xs, ws, bs):
-            x2 = x.reshape(-1, x.shape[-1])
-            y = _linear_forward(x2, w, b, act)
+        x2s = [x.reshape(-1, x.shape[-1]) for x in xs]
+        if (1 < n <= 8 and all(x2.shape[0] <= GROUP_ROWS and linear_group_supported(x2.shape[0], w.shape[1], w.shape[0])
+                               and not linear_preferred(x2.shape[0], w.shape[1], w.shape[0]) for x2, w in zip(x2s, ws))):
+            # few rows (BASELINE cfg2 / cfg3 / cfg4: 1 056 .. 3 520): all projections of the group in ONE launch of the
+            # few-row kernel (csrc/linear_small.hip) instead of n library GEMMs (cfg2: 16.7 us against 18.3 us for three
+            # hipBLASLt launches, tools/bench_linear_group.py)
+            outs = linear_group_raw([dict(x=x2, w=w, b=b) for x2, w, b in zip(x2s, ws, bs)], act)
+        else:
+            outs = [_linear_forward(x2, w, b, act) for x2, w, b in zip(x2s, ws, bs)]
+        for x, x2, w, y in zip(xs, x2s, ws, outs):
             saved += [x2, w, y if act else None]
             ys.append(y.view(*x.shape[:-1], w.shape[0]))
         ctx.n, ctx.act = n, act
@@ -938,6 +991,7 @@ class _Linear2(torch.autograd.Function):
 
 
 LINEAR2_LIBRARY_ROWS = 2048
+GROUP_ROWS = 4096          # _LinearGroup: row count up to which a group of projections runs as one few-row launch
 
 
 def linear2(x, w1, w2, b1, b2, wcat=None, bcat=None):

@@ -736,3 +736,31 @@ def test_head_reads_the_stacked_graph_output_in_place(M, N, Wm, C, p):
     assert rel_err(ev, torch.log_softmax(z @ W.detach().double().cpu().t() + b.detach().double().cpu(), 1)) < 2e-6
     tr = ops.head(F3.detach(), W.detach(), b.detach(), 0.5, True)
     assert tr.shape == (N, C) and bool(torch.isfinite(tr).all())
+
+
+@pytest.mark.parametrize("shapes", [[(1760, 100, 200), (1760, 512, 200), (1760, 100, 200)], [(77, 600, 200)],
+                                    [(1056, 36, 33), (3, 768, 5), (130, 200, 600)]])
+def test_few_row_projection_group(shapes):
+    """csrc/linear_small.hip: a group of small projections in one launch (32 x 32 tiles, the four waves split K, fixed-order
+    LDS reduction) against the fp64 product; two-block weights, the K-major form, ReLU and accumulate."""
+    rs = np.random.RandomState(17)
+    t = lambda *s: torch.from_numpy(rs.randn(*s).astype(np.float32)).to(DEV)
+    probs, want = [], []
+    for R, K, N in shapes:
+        x, w, b = t(R, K), t(N, K), t(N)
+        probs.append(dict(x=x, w=w, b=b))
+        want.append(torch.relu(x.double() @ w.double().t() + b.double()))
+    got = ops.linear_group_raw(probs, act=1)
+    for g, wnt in zip(got, want):
+        assert rel_err(g, wnt) < 2e-6
+    # two weight blocks + accumulate into an existing output; K-major weight (y = x @ wk)
+    R, K, N = max(shapes, key=lambda q: q[2])
+    x, w1, w2, b1, b2, base, wk = t(R, K), t(N - 40, K), t(40, K), t(N - 40), t(40), t(R, N), t(K, N)
+    out = base.clone()
+    ops.linear_group_raw([dict(x=x, w=w1, w2=w2, b=b1, b2=b2, out=out, accumulate=True), dict(x=x, wk=wk)])
+    ref = base.double() + x.double() @ torch.cat([w1, w2]).double().t() + torch.cat([b1, b2]).double()
+    assert rel_err(out, ref) < 2e-6
+    y2 = ops.linear_group_raw([dict(x=x, wk=wk)])[0]
+    assert rel_err(y2, x.double() @ wk.double()) < 2e-6
+    # bit-reproducible (fixed summation order)
+    assert torch.equal(y2, ops.linear_group_raw([dict(x=x, wk=wk)])[0])
