@@ -229,6 +229,31 @@ int mmdfn_linear_group(int n, const float* const* X, const float* const* W, cons
                        const int* kmajor, const int* accumulate, int act, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Secondary fusion modules (fusion.hip); their dense projections go through mmdfn_linear_group.
+ *   MFN, reference model_fusion.py:62-120, per timestep and batch row:
+ *     softmax_scale: att = softmax(z, dim=1) (saved), out = att * c          (:96-97; z, c, att, out: R x W)
+ *     mfn_mem      : mem' = sigmoid(v1) mem + sigmoid(v2) tanh(u)            (:98-102; n elements; saved: 3 n floats)
+ *   MMGatedAttention 'general', reference model.py:761-781, per modality pair (m, n) and row:
+ *     gated_pair   : z = sigmoid(w . [x_m | x_n | x_m * x_n] + b) (w: 3 D floats, saved in zs),
+ *                    out = z tanh(p_m) + (1 - z) tanh(p_n)   (x: R x D, p / out: R x C);
+ *                    backward also writes dpre[r] = d loss / d (gate pre-activation)
+ *     rowscale_colsum: out[0:3D] = sum_r s[r] [x_m | x_n | x_m * x_n][r], out[3D] = sum_r s[r]   (gate weight / bias gradient)
+ * ------------------------------------------------------------------------- */
+int mmdfn_softmax_scale_fwd(const float* z, const float* c, float* att, float* out, int R, int W, void* stream);
+int mmdfn_softmax_scale_bwd(const float* att, const float* c, const float* dout, float* dz, float* dc, int R, int W,
+                            void* stream);
+int mmdfn_mfn_mem_fwd(const float* u, const float* v1, const float* v2, const float* mem, float* out, float* saved,
+                      int64_t n, void* stream);
+int mmdfn_mfn_mem_bwd(const float* saved, const float* mem, const float* dout, float* du, float* dv1, float* dv2,
+                      float* dmem, int64_t n, void* stream);
+int mmdfn_gated_pair_fwd(const float* xm, const float* xn, const float* w, const float* b, const float* pm,
+                         const float* pn, float* out, float* zs, int R, int D, int C, void* stream);
+int mmdfn_gated_pair_bwd(const float* xm, const float* xn, const float* w, const float* pm, const float* pn,
+                         const float* zs, const float* dout, float* dxm, float* dxn, float* dpm, float* dpn,
+                         float* dpre, int R, int D, int C, void* stream);
+int mmdfn_rowscale_colsum(const float* s, const float* xm, const float* xn, float* out, int R, int D, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Weight-gradient contraction (autograd of the dense layers on the path: dW = dY^T X, db = sum_r dY):
  *   C[m, n] = sum_r A[r, m] B[r, n]      A: R rows of M floats (stride lda), B: R rows of N floats (ldb)
  *   colsum[m] = sum_r A[r, m]            (optional, NULL to skip)

@@ -38,6 +38,13 @@ SIGNATURES = {
     "mmdfn_linear2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear_group_supported": [_I, _I, _I],
     "mmdfn_linear_group": [_I] + [_P] * 15 + [_I, _P],
+    "mmdfn_softmax_scale_fwd": [_P, _P, _P, _P, _I, _I, _P],
+    "mmdfn_softmax_scale_bwd": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "mmdfn_mfn_mem_fwd": [_P] * 6 + [_L, _P],
+    "mmdfn_mfn_mem_bwd": [_P] * 7 + [_L, _P],
+    "mmdfn_gated_pair_fwd": [_P] * 8 + [_I, _I, _I, _P],
+    "mmdfn_gated_pair_bwd": [_P] * 12 + [_I, _I, _I, _P],
+    "mmdfn_rowscale_colsum": [_P, _P, _P, _P, _I, _I, _P],
     "mmdfn_gemm_tn_splits": [_I, _I, _I],
     "mmdfn_gemm_tn": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_gemm_tn_grouped_workspace": [_I, _P, _P, _P],

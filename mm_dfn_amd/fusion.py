@@ -1,15 +1,21 @@
 """Secondary fusion modules named by the north star, reference signatures kept:
 
 * ``MFN`` (model_fusion.py:10-120): memory fusion network applied after the GDF graph when
-  ``--mm_fusion_mthd mfn`` (model.py:1303-1326).  Non-default.  Composed from torch-ROCm ops (the three
-  LSTM input projections are hoisted out of the time loop and the three recurrent projections are one batched
-  product); it is not one of the hand-written kernels.
+  ``--mm_fusion_mthd mfn`` (model.py:1303-1326).  Non-default.  Every dense product of a timestep (three recurrent
+  LSTM projections; the attention and gamma MLPs) is a grouped launch of the few-row MFMA kernel
+  (csrc/linear_small.hip, forward and input gradients; weight gradients through the step's gemm_tn batch), the LSTM
+  cells run on the fused gate kernel of the GCN stack (csrc/gcn_pointwise.hip) and the attention / memory update on
+  csrc/fusion.hip: per step 4 grouped GEMM launches + 3 pointwise launches, no library GEMM.  The three input
+  projections are hoisted out of the time loop (one grouped launch for all timesteps).
 * ``MMGatedAttention`` ('general', model.py:718-781): unreachable under graph_type='GDF' in the reference
-  (shape bug); provided at module level only, with the reference's state_dict keys.
+  (shape bug); provided at module level, with the reference's state_dict keys: one grouped launch
+  for the three transforms, one fused kernel per modality pair (gate dot product, sigmoid, tanh, blend) each way.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import ops
 
 
 class MFN(nn.Module):
@@ -46,30 +52,37 @@ class MFN(nn.Module):
         T, n = x.shape[0], x.shape[1]
         cells = (self.lstm_l, self.lstm_a, self.lstm_v)
         parts = (x[:, :, :self.d_l], x[:, :, self.d_l:self.d_l + self.d_a], x[:, :, self.d_l + self.d_a:])
-        # hoisted input projections for all timesteps: (3, T, n, 400)
-        gx = torch.stack([F.linear(p, c.weight_ih, c.bias_ih + c.bias_hh) for p, c in zip(parts, cells)], 0)
-        w_hh = torch.stack([c.weight_hh.t() for c in cells], 0)            # (3, 100, 400)
-        h = x.new_zeros(3, n, 100)
-        c = x.new_zeros(3, n, 100)
+        G = ops.linear_group
+        # hoisted input projections of the three cells for all timesteps: one grouped launch, (T, n, 400) each
+        gx = G([p.reshape(T * n, p.shape[-1]) for p in parts], [c.weight_ih for c in cells],
+               [c.bias_ih + c.bias_hh for c in cells], hip=True)
+        gx = [g.view(T, n, -1) for g in gx]
+        w_hh = [c.weight_hh for c in cells]
+        h = [x.new_zeros(n, 100) for _ in range(3)]
+        c = None                                                            # (3 n, 100); None = zero state
+        prev_cs = x.new_zeros(n, 300)
         mem = x.new_zeros(n, self.mem_dim)
         hs, mems = [], []
         for t in range(T):
-            g = gx[:, t] + torch.bmm(h, w_hh)                             # (3, n, 400) gate order i, f, g, o
-            i, f, gg, o = g.chunk(4, -1)
-            c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
-            h = torch.sigmoid(o) * torch.tanh(c_new)
-            prev_cs = torch.cat([c[0], c[1], c[2]], 1)
-            new_cs = torch.cat([c_new[0], c_new[1], c_new[2]], 1)
+            rec = G(h, w_hh, [None] * 3, hip=True)                           # h_m W_hh_m^T, gate order i, f, g, o
+            gates = torch.cat([gx[m][t] + rec[m] for m in range(3)], 0)     # (3 n, 400)
+            h_new, c_new = ops.lstm_pointwise(gates, c)
+            new_cs = c_new.view(3, n, 100).permute(1, 0, 2).reshape(n, 300)
             c_star = torch.cat([prev_cs, new_cs], 1)
-            att = F.softmax(self.att1_fc2(self.att1_dropout(F.relu(self.att1_fc1(c_star)))), dim=1)
-            attended = att * c_star
-            c_hat = torch.tanh(self.att2_fc2(self.att2_dropout(F.relu(self.att2_fc1(attended)))))
+            a1 = self.att1_dropout(G([c_star], [self.att1_fc1.weight], [self.att1_fc1.bias], act=1, hip=True)[0])
+            z = G([a1], [self.att1_fc2.weight], [self.att1_fc2.bias], hip=True)[0]
+            attended = ops.softmax_scale(z, c_star)
             both = torch.cat([attended, mem], 1)
-            g1 = torch.sigmoid(self.gamma1_fc2(self.gamma1_dropout(F.relu(self.gamma1_fc1(both)))))
-            g2 = torch.sigmoid(self.gamma2_fc2(self.gamma2_dropout(F.relu(self.gamma2_fc1(both)))))
-            mem = g1 * mem + g2 * c_hat
-            c = c_new
-            hs.append(torch.cat([h[0], h[1], h[2]], 1))
+            y = G([attended, both, both], [self.att2_fc1.weight, self.gamma1_fc1.weight, self.gamma2_fc1.weight],
+                  [self.att2_fc1.bias, self.gamma1_fc1.bias, self.gamma2_fc1.bias], act=1, hip=True)
+            y = [self.att2_dropout(y[0]), self.gamma1_dropout(y[1]), self.gamma2_dropout(y[2])]
+            u, v1, v2 = G(y, [self.att2_fc2.weight, self.gamma1_fc2.weight, self.gamma2_fc2.weight],
+                          [self.att2_fc2.bias, self.gamma1_fc2.bias, self.gamma2_fc2.bias], hip=True)
+            mem = ops.mfn_mem(u, v1, v2, mem)
+            c, prev_cs = c_new, new_cs
+            hv = h_new.view(3, n, 100)
+            h = [hv[0], hv[1], hv[2]]
+            hs.append(hv.permute(1, 0, 2).reshape(n, 300))
             mems.append(mem)
         return torch.cat([torch.stack(hs), torch.stack(mems)], -1)
 
@@ -95,26 +108,15 @@ class MMGatedAttention(nn.Module):
         a = self.dropouta(a) if len(a) != 0 else a
         v = self.dropoutv(v) if len(v) != 0 else v
         l = self.dropoutl(l) if len(l) != 0 else l
-        ha = torch.tanh(self.transform_a(a)) if 'a' in modals else a
-        hv = torch.tanh(self.transform_v(v)) if 'v' in modals else v
-        hl = torch.tanh(self.transform_l(l)) if 'l' in modals else l
-        out = []
-        if 'a' in modals and 'v' in modals:
-            z = torch.sigmoid(self.transform_av(torch.cat([a, v, a * v], -1)))
-            h_av = z * ha + (1 - z) * hv
-            if 'l' not in modals:
-                return h_av
-            out.append(h_av)
-        if 'a' in modals and 'l' in modals:
-            z = torch.sigmoid(self.transform_al(torch.cat([a, l, a * l], -1)))
-            h_al = z * ha + (1 - z) * hl
-            if 'v' not in modals:
-                return h_al
-            out.append(h_al)
-        if 'v' in modals and 'l' in modals:
-            z = torch.sigmoid(self.transform_vl(torch.cat([v, l, v * l], -1)))
-            h_vl = z * hv + (1 - z) * hl
-            if 'a' not in modals:
-                return h_vl
-            out.append(h_vl)
+        xs = {'a': a, 'v': v, 'l': l}
+        tr = {'a': self.transform_a, 'v': self.transform_v, 'l': self.transform_l}
+        use = [m for m in ('a', 'v', 'l') if m in modals]
+        # the transforms' pre-activations in one grouped launch; tanh is applied inside the pair kernel
+        pre = dict(zip(use, ops.linear_group([xs[m] for m in use], [tr[m].weight for m in use], [tr[m].bias for m in use],
+                                             hip=True)))
+        gate = {('a', 'v'): self.transform_av, ('a', 'l'): self.transform_al, ('v', 'l'): self.transform_vl}
+        out = [ops.gated_pair(xs[m], xs[n], pre[m], pre[n], g.weight, g.bias)
+               for (m, n), g in gate.items() if m in modals and n in modals]
+        if len(out) == 1:
+            return out[0]
         return torch.cat(out, -1)

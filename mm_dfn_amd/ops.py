@@ -851,11 +851,17 @@ class _LinearGroup(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, act, n, *args):
+        force = False
+        if isinstance(n, tuple):                 # (n, "hip"): every product of the node on the few-row kernel, never the library
+            n, force = n[0], True
         xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
         ys, saved = [], []
         x2s = [x.reshape(-1, x.shape[-1]) for x in xs]
-        if (1 < n <= 8 and all(x2.shape[0] <= GROUP_ROWS and linear_group_supported(x2.shape[0], w.shape[1], w.shape[0])
+        ctx.force = force
+        if force or (1 < n <= 8 and all(x2.shape[0] <= GROUP_ROWS and linear_group_supported(x2.shape[0], w.shape[1], w.shape[0])
                                and not linear_preferred(x2.shape[0], w.shape[1], w.shape[0]) for x2, w in zip(x2s, ws))):
+            if force and not all(linear_group_supported(x2.shape[0], w.shape[1], w.shape[0]) for x2, w in zip(x2s, ws)):
+                raise ValueError("linear_group(hip=True): a contraction wider than 768 or not a multiple of 4")
             # few rows (BASELINE cfg2 / cfg3 / cfg4: 1 056 .. 3 520): all projections of the group in ONE launch of the
             # few-row kernel (csrc/linear_small.hip) instead of n library GEMMs (cfg2: 16.7 us against 18.3 us for three
             # hipBLASLt launches, tools/bench_linear_group.py)
@@ -874,24 +880,131 @@ class _LinearGroup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dys):
         n, sv = ctx.n, ctx.saved_tensors
-        dxs, wg = [], []
+        dxs, wg, dy2s = [], [], []
         for g in range(n):
             x2, w, y = sv[3 * g], sv[3 * g + 1], sv[3 * g + 2]
-            dy2 = dys[g].reshape(-1, w.shape[0])
+            dy2 = dys[g].reshape(-1, w.shape[0]) if dys[g] is not None else torch.zeros(x2.shape[0], w.shape[0], dtype=x2.dtype, device=x2.device)
             if ctx.act:
                 dy2 = dy2 * (y > 0).to(dy2.dtype)
             dy2 = dy2.contiguous()
+            dy2s.append(dy2)
             wg.append(_wgrad(dy2, x2, ctx.param_refs[g][0], ctx.param_refs[g][1]))
-            dxs.append(_linear_dx(dy2, w).view(*dys[g].shape[:-1], w.shape[1]) if ctx.needs_input_grad[2 + g] else None)
+        if ctx.force:
+            # input gradients dX_g = dY_g . W_g of the whole group in one launch: the weight is read as stored ((N, K) = the
+            # K-major form of the product over N)
+            need = [g for g in range(n) if ctx.needs_input_grad[2 + g]]
+            outs = linear_group_raw([dict(x=dy2s[g], wk=sv[3 * g + 1]) for g in need]) if need else []
+            dxs = [None] * n
+            for g, o in zip(need, outs):
+                dxs[g] = o.view(*dys[g].shape[:-1], sv[3 * g + 1].shape[1]) if dys[g] is not None else o
+        else:
+            for g in range(n):
+                w = sv[3 * g + 1]
+                dxs.append(_linear_dx(dy2s[g], w).view(*dys[g].shape[:-1], w.shape[1]) if ctx.needs_input_grad[2 + g] else None)
         return (None, None) + tuple(dxs) + tuple(r[0] for r in wg) + tuple(r[1] for r in wg)
 
 
-def linear_group(xs, weights, biases, act=0):
-    """[act(x W^T + b) for each group] with all weight gradients computed by one grouped launch."""
+def linear_group(xs, weights, biases, act=0, hip=False):
+    """[act(x W^T + b) for each group] with all weight gradients computed by one grouped launch.  ``hip=True``: forward and
+    input gradients on the few-row kernel whatever the shape (csrc/linear_small.hip; contraction <= 768): the fusion
+    modules use it so that no library GEMM appears on their path."""
     for x in xs:
         _hip.require_cuda(x)
     n = len(xs)
-    return list(_LinearGroup.apply(act, n, *xs, *weights, *biases))
+    return list(_LinearGroup.apply(act, (n, "hip") if hip else n, *xs, *weights, *biases))
+
+
+class _SoftmaxScale(torch.autograd.Function):
+    """out = softmax(z, dim=1) * c (MFN attention, model_fusion.py:96-97)."""
+
+    @staticmethod
+    def forward(ctx, z, c):
+        _hip.require_cuda(z, c)
+        z, c = z.contiguous(), c.contiguous()
+        att, out = torch.empty_like(z), torch.empty_like(z)
+        _hip.check(_hip.lib().mmdfn_softmax_scale_fwd(_hip.ptr(z), _hip.ptr(c), _hip.ptr(att), _hip.ptr(out), z.shape[0],
+                                                      z.shape[1], _hip.stream()), "mmdfn_softmax_scale_fwd")
+        ctx.save_for_backward(att, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        att, c = ctx.saved_tensors
+        dout = dout.contiguous()
+        dz, dc = torch.empty_like(att), torch.empty_like(att)
+        _hip.check(_hip.lib().mmdfn_softmax_scale_bwd(_hip.ptr(att), _hip.ptr(c), _hip.ptr(dout), _hip.ptr(dz), _hip.ptr(dc),
+                                                      att.shape[0], att.shape[1], _hip.stream()), "mmdfn_softmax_scale_bwd")
+        return dz, dc
+
+
+def softmax_scale(z, c):
+    return _SoftmaxScale.apply(z, c)
+
+
+class _MfnMem(torch.autograd.Function):
+    """mem' = sigmoid(v1) mem + sigmoid(v2) tanh(u)  (model_fusion.py:98-102)."""
+
+    @staticmethod
+    def forward(ctx, u, v1, v2, mem):
+        _hip.require_cuda(u, v1, v2, mem)
+        u, v1, v2, mem = u.contiguous(), v1.contiguous(), v2.contiguous(), mem.contiguous()
+        out = torch.empty_like(mem)
+        saved = torch.empty(3, mem.numel(), dtype=mem.dtype, device=mem.device)
+        _hip.check(_hip.lib().mmdfn_mfn_mem_fwd(_hip.ptr(u), _hip.ptr(v1), _hip.ptr(v2), _hip.ptr(mem), _hip.ptr(out),
+                                                _hip.ptr(saved), mem.numel(), _hip.stream()), "mmdfn_mfn_mem_fwd")
+        ctx.save_for_backward(saved, mem)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved, mem = ctx.saved_tensors
+        dout = dout.contiguous()
+        du, dv1, dv2, dmem = (torch.empty_like(mem) for _ in range(4))
+        _hip.check(_hip.lib().mmdfn_mfn_mem_bwd(_hip.ptr(saved), _hip.ptr(mem), _hip.ptr(dout), _hip.ptr(du), _hip.ptr(dv1),
+                                                _hip.ptr(dv2), _hip.ptr(dmem), mem.numel(), _hip.stream()), "mmdfn_mfn_mem_bwd")
+        return du, dv1, dv2, dmem
+
+
+def mfn_mem(u, v1, v2, mem):
+    return _MfnMem.apply(u, v1, v2, mem)
+
+
+class _GatedPair(torch.autograd.Function):
+    """h = z tanh(p_m) + (1 - z) tanh(p_n), z = sigmoid(w . [x_m | x_n | x_m * x_n] + b)  (model.py:766-781); w: (1, 3D)."""
+
+    @staticmethod
+    def forward(ctx, xm, xn, pm, pn, w, b):
+        _hip.require_cuda(xm, xn, pm, pn, w, b)
+        xm, xn, pm, pn, w = xm.contiguous(), xn.contiguous(), pm.contiguous(), pn.contiguous(), w.contiguous()
+        R, D = xm.shape
+        C = pm.shape[1]
+        out = torch.empty_like(pm)
+        zs = torch.empty(R, dtype=xm.dtype, device=xm.device)
+        _hip.check(_hip.lib().mmdfn_gated_pair_fwd(_hip.ptr(xm), _hip.ptr(xn), _hip.ptr(w), _hip.ptr(b), _hip.ptr(pm), _hip.ptr(pn),
+                                                   _hip.ptr(out), _hip.ptr(zs), R, D, C, _hip.stream()), "mmdfn_gated_pair_fwd")
+        ctx.save_for_backward(xm, xn, pm, pn, w, zs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xm, xn, pm, pn, w, zs = ctx.saved_tensors
+        dout = dout.contiguous()
+        R, D = xm.shape
+        C = pm.shape[1]
+        dxm, dxn, dpm, dpn = torch.empty_like(xm), torch.empty_like(xn), torch.empty_like(pm), torch.empty_like(pn)
+        dpre = torch.empty(R, dtype=xm.dtype, device=xm.device)
+        lib = _hip.lib()
+        _hip.check(lib.mmdfn_gated_pair_bwd(_hip.ptr(xm), _hip.ptr(xn), _hip.ptr(w), _hip.ptr(pm), _hip.ptr(pn), _hip.ptr(zs),
+                                            _hip.ptr(dout), _hip.ptr(dxm), _hip.ptr(dxn), _hip.ptr(dpm), _hip.ptr(dpn),
+                                            _hip.ptr(dpre), R, D, C, _hip.stream()), "mmdfn_gated_pair_bwd")
+        dwb = torch.empty(3 * D + 1, dtype=xm.dtype, device=xm.device)
+        _hip.check(lib.mmdfn_rowscale_colsum(_hip.ptr(dpre), _hip.ptr(xm), _hip.ptr(xn), _hip.ptr(dwb), R, D, _hip.stream()),
+                   "mmdfn_rowscale_colsum")
+        return dxm, dxn, dpm, dpn, dwb[:3 * D].view(1, 3 * D), dwb[3 * D:].view(1)
+
+
+def gated_pair(xm, xn, pm, pn, w, b):
+    return _GatedPair.apply(xm, xn, pm, pn, w, b)
 
 
 class _GateLinear(torch.autograd.Function):
