@@ -1020,7 +1020,10 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
-    bool io_wave = (R == 1);
+    // the 5-wave kernel runs one workgroup per CU (its fifth wave shares a SIMD with a recurrence wave at ~210 VGPRs each):
+    // it wins while every sequence gets a CU of its own in one round (cfg2: 160 workgroups); beyond that the 4-wave kernel,
+    // two workgroups per CU, needs fewer rounds (cfg3 / cfg4: +4-5 % step time with the 5-wave kernel, measured)
+    bool io_wave = (R == 1) && (2 * sl <= 256);
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_GRU_IO")) io_wave = io_wave && e[0] != '0';      // A/B aid
 #endif
