@@ -19,6 +19,7 @@
 // layer: no concatenated copy), or (K, N) with n-contiguous rows (KMAJOR: dX = dY . Wcat reads Wcat as stored).
 #include "mmdfn_internal.h"
 #include "../../include/mmdfn_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,6 +41,8 @@ struct SmallGroup {
     int ntn[SG_MAX];
 };
 
+// ABL (tuning build, timing only): 1 no MFMA, 2 no operand loads, 4 no reduction / epilogue
+template <int ABL>
 __global__ __launch_bounds__(256) void linear_small_kernel(SmallGroup G) {
     __shared__ __attribute__((aligned(16))) float part[4][32][36];
 
@@ -91,7 +94,14 @@ __global__ __launch_bounds__(256) void linear_small_kernel(SmallGroup G) {
         for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 a[PRE][2], b[PRE][2];
+    if (ABL & 2) {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { a[q][e] = make_float4(1.f, 2.f, 3.f, 4.f); b[q][e] = a[q][e]; }
+    }
     auto load_chunk = [&](int slot, int c) {
+        if (ABL & 2) return;
         const int k = 16 * (c0 + c) + 4 * g;
         const int kc = k < K ? k : K - 4;
 #pragma unroll
@@ -135,10 +145,15 @@ __global__ __launch_bounds__(256) void linear_small_kernel(SmallGroup G) {
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], bv[ct][j], acc[rt][ct], 0, 0, 0);
+                    if (!(ABL & 1)) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], bv[ct][j], acc[rt][ct], 0, 0, 0);
+                    else acc[rt][ct][j] += av[rt][j] * bv[ct][j];
         }
     }
 
+    if (ABL & 4) {
+        if (acc[0][0][0] + acc[1][1][1] + acc[0][1][2] + acc[1][0][3] == 1.2345f) G.Y[p][tid] = 1.f;
+        return;
+    }
     // the four partial tiles meet in LDS (C/D layout of a 16 x 16 tile: column fi, rows 4 g + r)
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -221,7 +236,20 @@ extern "C" int mmdfn_linear_group(int n, const float* const* X, const float* con
         t0 += ((R[p] + 31) / 32) * G.ntn[p];
     }
     for (int p = n; p <= SG_MAX; ++p) G.tile0[p] = t0;
-    hipLaunchKernelGGL(linear_small_kernel, dim3(t0), dim3(256), 0, (hipStream_t)stream, G);
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_LSM_ABL")) {
+        switch (atoi(e)) {
+            case 1: hipLaunchKernelGGL(linear_small_kernel<1>, dim3(t0), dim3(256), 0, (hipStream_t)stream, G); MMDFN_CHECK_LAUNCH(); return 0;
+            case 2: hipLaunchKernelGGL(linear_small_kernel<2>, dim3(t0), dim3(256), 0, (hipStream_t)stream, G); MMDFN_CHECK_LAUNCH(); return 0;
+            case 4: hipLaunchKernelGGL(linear_small_kernel<4>, dim3(t0), dim3(256), 0, (hipStream_t)stream, G); MMDFN_CHECK_LAUNCH(); return 0;
+            case 6: hipLaunchKernelGGL(linear_small_kernel<6>, dim3(t0), dim3(256), 0, (hipStream_t)stream, G); MMDFN_CHECK_LAUNCH(); return 0;
+            case 5: hipLaunchKernelGGL(linear_small_kernel<5>, dim3(t0), dim3(256), 0, (hipStream_t)stream, G); MMDFN_CHECK_LAUNCH(); return 0;
+            case 7: hipLaunchKernelGGL(linear_small_kernel<7>, dim3(t0), dim3(256), 0, (hipStream_t)stream, G); MMDFN_CHECK_LAUNCH(); return 0;
+            default: break;
+        }
+    }
+#endif
+    hipLaunchKernelGGL(linear_small_kernel<0>, dim3(t0), dim3(256), 0, (hipStream_t)stream, G);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
