@@ -128,7 +128,10 @@ def test_random_ragged_batches_against_oracle(seed):
         and two fp32 evaluations land on different sides.  (Seen once in 46 random cases, seed 45 of
         tools/campaign.sh: the gradient of convs.0.weight moved by 2.4 % between the device / the build container's
         fp32 oracle on one side and the GPU box's fp32 oracle / fp64 on the other, log-probs equal to 5e-7; every other
-        weight draw on the same shapes agrees to 3e-6.)"""
+        weight draw on the same shapes agrees to 3e-6.  Round 3: with the modality projections on the few-row grouped
+        kernel -- another fp32 summation order -- the device lands on the other side of that kink while both oracles
+        agree with each other, so the campaign reports seed 45 as a failure of this check; with ops.GROUP_ROWS = 0
+        (library projections) the same model matches every gradient to 1e-4.  Log-probs agree to 6e-7 either way.)"""
         if not ref64:
             sd = synthetic.seeded_state_dict(m.state_dict(), 950 + seed)
             b = synthetic.make_batch(950 + seed + 1, lengths=lengths, **cfg)
