@@ -43,7 +43,7 @@ class GraphConvolution(nn.Module):
         else:
             support = (1 - alpha) * hi + alpha * h0
             r = support
-        out = theta * torch.mm(support, self.weight) + (1 - theta) * r
+        out = theta * ops.matmul_kn(support, self.weight) + (1 - theta) * r
         if self.residual:
             out = out + input
         return out

@@ -433,6 +433,34 @@ def linear_group_supported(R, K, N):
     return bool(_hip.lib().mmdfn_linear_group_supported(int(R), int(K), int(N)))
 
 
+def dense_nk(x2, weight, bias=None, act=0, out=None, accumulate=False):
+    """act(x2 W^T + b) (+ out) for W stored (N, K).  Engine per shape, both hand-written: the many-row kernels where they
+    win (linear_preferred: csrc/linear.hip, linear_split.hip), the LDS-staged few-row kernel (csrc/linear_small.hip)
+    otherwise.  Only a contraction width that is not a multiple of 4 (rows that cannot be fetched in 16-byte units) is
+    left to the library GEMM."""
+    N, K = weight.shape
+    if K % 4 == 0 and K >= 4:
+        if linear_preferred(x2.shape[0], K, N):
+            return linear_raw(x2, weight, bias, act, out=out, accumulate=accumulate)
+        q = dict(x=x2, w=weight, b=bias)
+        if out is not None:
+            q.update(out=out, accumulate=accumulate)
+        return linear_group_raw([q], act)[0]
+    y = torch.nn.functional.linear(x2, weight, bias)
+    if accumulate:
+        y = out.add_(y)
+    return torch.relu_(y) if act else y
+
+
+def dense_kn(x2, wk):
+    """x2 @ wk for wk stored (K, N) (an input gradient dX = dY . W read as stored; GraphConvolution.weight): the few-row
+    kernel's K-major form; widths that are not multiples of 4 go to the library GEMM."""
+    K, N = wk.shape
+    if K % 4 == 0 and K >= 4 and N % 4 == 0:
+        return linear_group_raw([dict(x=x2, wk=wk)])[0]
+    return x2 @ wk
+
+
 def linear_supported(x, weight):
     return x.is_cuda and x.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 4
 
@@ -770,15 +798,10 @@ class _Linear(torch.autograd.Function):
                     y = torch.relu_(y)
             else:
                 y = linear_raw(x2, weight, bias, act)
+        elif base is not None:
+            y = dense_nk(x2, weight, bias, act, out=base.reshape(-1, N).clone(), accumulate=True)
         else:
-            if base is not None:
-                y = torch.addmm(base.reshape(-1, N), x2, weight.t())
-                if bias is not None:
-                    y = y + bias
-            else:
-                y = torch.nn.functional.linear(x2, weight, bias)
-            if act:
-                y = torch.relu_(y)
+            y = dense_nk(x2, weight, bias, act)
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.has_base = base is not None
@@ -798,11 +821,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _wgrad(dy2, x2, ctx.weight_ref, ctx.bias_ref)         # dW and db in one pass over dY
         if ctx.needs_input_grad[0]:
-            if N % 4 == 0 and linear_preferred(dy2.shape[0], N, K):
-                dx = linear_raw(dy2, weight.t().contiguous(), None, 0)
-            else:
-                dx = dy2 @ weight
-            dx = dx.view(*dy.shape[:-1], K)
+            dx = _linear_dx(dy2, weight).view(*dy.shape[:-1], K)
         dbase = dy2.view(dy.shape) if ctx.has_base and ctx.needs_input_grad[4] else None
         return dx, dw, db, None, dbase
 
@@ -814,7 +833,7 @@ class _MatmulKN(torch.autograd.Function):
     def forward(ctx, x, w):
         ctx.weight_ref = w
         ctx.save_for_backward(x, w)
-        return torch.mm(x, w)
+        return dense_kn(x if x.dim() == 2 and x.stride(1) == 1 else x.contiguous(), w)
 
     @staticmethod
     def backward(ctx, dy):
@@ -824,24 +843,22 @@ class _MatmulKN(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw, _ = _wgrad(x, dy, ctx.weight_ref, None)                    # dW = x^T dy
         if ctx.needs_input_grad[0]:
-            dx = dy @ w.t()
+            dx = dense_nk(dy, w)                     # dX = dY W^T: w (K, N) is the (N_out = K, contraction = N) weight as stored
         return dx, dw
 
 
 def _linear_forward(x2, weight, bias, act):
     """act(x2 W^T + b) with the engine _Linear picks for the shape."""
-    N, K = weight.shape
-    if linear_supported(x2, weight) and linear_preferred(x2.shape[0], K, N):
-        return linear_raw(x2, weight, bias, act)
-    y = torch.nn.functional.linear(x2, weight, bias)
-    return torch.relu_(y) if act else y
+    return dense_nk(x2, weight, bias, act)
 
 
 def _linear_dx(dy2, weight):
     N, K = weight.shape
-    if N % 4 == 0 and linear_preferred(dy2.shape[0], N, K):
+    if N % 4 == 0 and linear_preferred(dy2.shape[0], N, K) and dy2.shape[0] >= 16384:
+        # very many rows: the bf16-piece kernel on a transposed copy of the weight (cfg3's 19 008 party rows: 59 us
+        # against 68 us for the K-major few-row form, tools/bench_linear_group.py)
         return linear_raw(dy2, weight.t().contiguous(), None, 0)
-    return dy2 @ weight
+    return dense_kn(dy2, weight)
 
 
 class _LinearGroup(torch.autograd.Function):
@@ -1016,10 +1033,7 @@ class _GateLinear(torch.autograd.Function):
     def forward(ctx, q, h, w_ih, w_hh, bsum, b_ih, b_hh):
         G = _linear_forward(q, w_ih, bsum, 0)
         if h is not None:
-            if linear_supported(h, w_hh) and linear_preferred(h.shape[0], w_hh.shape[1], w_hh.shape[0]):
-                linear_raw(h, w_hh, None, 0, out=G, accumulate=True)
-            else:
-                G = torch.addmm(G, h, w_hh.t())
+            G = dense_nk(h, w_hh, None, 0, out=G, accumulate=True)
         ctx.has_h = h is not None
         ctx.refs = (w_ih, w_hh, b_ih, b_hh)
         ctx.save_for_backward(q, h, w_ih, w_hh)
@@ -1067,11 +1081,10 @@ class _Linear2(torch.autograd.Function):
         w1c, w2c = w1.contiguous(), w2.contiguous()
         R, K = x2.shape
         n1, N = w1.shape[0], w1.shape[0] + w2.shape[0]
-        if wcat is not None and R < LINEAR2_LIBRARY_ROWS and (bcat is not None or b1 is None):
-            # few rows: a plain library GEMM on the stacked views beats the hand-written kernel (measured,
-            # profiles/r02_linear_vs_hipblaslt.txt: 1 760 x 200 -> 600 in 10.3 us vs 16.0 us; at 3 520 rows and above
-            # the library's kernel selection collapses -- 45 us vs 23 us -- so the switch is on the row count only)
-            y = torch.addmm(bcat, x2, wcat.t()) if bcat is not None else torch.mm(x2, wcat.t())
+        if R < LINEAR2_FEW_ROWS:
+            # few rows: the LDS-staged few-row kernel on the two parameters (csrc/linear_small.hip; 1 760 x 200 -> 600 in
+            # 12.4 us against 16.0 us for the 64 x 64-tile kernel below, tools/bench_linear_group.py)
+            y = linear_group_raw([dict(x=x2, w=w1c, w2=w2c, b=b1, b2=b2)])[0]
         else:
             y = torch.empty(R, N, dtype=torch.float32, device=x2.device)
             rc = _hip.lib().mmdfn_linear2(_hip.ptr(x2), _hip.ptr(w1c), _hip.ptr(w2c), n1, _hip.ptr(b1), _hip.ptr(b2), _hip.ptr(y),
@@ -1096,14 +1109,19 @@ class _Linear2(torch.autograd.Function):
                 # very many rows (cfg3's 19 008 party rows: 59 us against the library's 83 us,
                 # profiles/r02_linear_vs_hipblaslt.txt): the bf16-piece kernel on the transposed stacked weight
                 dx = linear_raw(dy2, wcat.t().contiguous(), None, 0).view(*dy.shape[:-1], w1.shape[1])
+            elif wcat is not None:
+                dx = dense_kn(dy2, wcat).view(*dy.shape[:-1], w1.shape[1])
             else:
-                dx = (dy2 @ wcat if wcat is not None else torch.addmm(d1 @ w1, d2, w2)).view(*dy.shape[:-1], w1.shape[1])
+                # no stacked copy from the caller: two K-major products on the parameters, the second accumulating
+                dx = linear_group_raw([dict(x=d1, wk=w1)])[0]
+                linear_group_raw([dict(x=d2, wk=w2, out=dx, accumulate=True)])
+                dx = dx.view(*dy.shape[:-1], w1.shape[1])
         dw1, db1 = _wgrad(d1, x2, p1, b1)
         dw2, db2 = _wgrad(d2, x2, p2, b2)
         return dx, dw1, dw2, db1, db2, None, None
 
 
-LINEAR2_LIBRARY_ROWS = 2048
+LINEAR2_FEW_ROWS = 2048
 GROUP_ROWS = 4096          # _LinearGroup: row count up to which a group of projections runs as one few-row launch
 
 

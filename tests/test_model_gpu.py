@@ -377,7 +377,7 @@ def test_fusion_modules_run_without_library_gemms():
         step()
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
-    assert any("linear_small_kernel" in n for n in names) and any("gated_pair_fwd_kernel" in n for n in names)
+    assert any("linear_lds_kernel" in n for n in names) and any("gated_pair_fwd_kernel" in n for n in names)
     assert any("softmax_scale_bwd_kernel" in n for n in names) and any("mfn_mem_fwd_kernel" in n for n in names)
     assert not [n for n in names if n.startswith("Cijk_") or "gemm" in n.lower() and "gemm_tn" not in n], names
     assert mfn.gamma2_fc2.weight.grad is not None and gat.transform_vl.weight.grad is not None

@@ -355,3 +355,25 @@ def test_weight_gradient_queue_survives_a_backward_that_raises():
         assert (p.grad is not None) == (n in want), n
         if n in want:
             assert float((p.grad - want[n]).abs().max()) / (float(want[n].abs().max()) + 1e-12) < 1e-5, n
+
+
+@pytest.mark.parametrize("lengths", [(20, 13, 7), tuple([110] * 16)])
+def test_training_step_launches_no_library_gemm(lengths):
+    """Every dense product of a training step (forward, input gradients, weight gradients) runs on this package's MFMA
+    kernels: no Tensile (`Cijk_*`: hipBLASLt / rocBLAS) kernel in the device trace, for a few-row batch and for the
+    BASELINE cfg2 shape (16 x 110: the context GRU's 1 760-row and the party GRU's 7 040-row products)."""
+    from torch.profiler import ProfilerActivity, profile
+    m = _model(dropout=0.1).train()
+    b, flat = _step_inputs(lengths=lengths)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        T.backward(_loss(m, b, flat))
+    step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert any("linear_lds_kernel" in n for n in names) and any("gru_seq" in n for n in names), names
+    assert not [n for n in names if n.startswith("Cijk_") or ("gemm" in n.lower() and "gemm_tn" not in n)], names

@@ -27,7 +27,7 @@ def step():
         p.grad = None
     logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
     loss = loss_f(logp, label)
-    loss.backward()
+    train.backward(loss)            # (the step as bench.py runs it: weight gradients batched)
 
 
 for _ in range(3):
