@@ -130,30 +130,6 @@ def test_out_of_scope_configurations_raise():
         DialogueGNNModel('LSTM', 100, 150, 150, 100, 100, 100, 100, 2, 200, 10, 10, graph_type='relation')
 
 
-def test_mfn_and_gated_attention_modules_against_reference_golden():
-    """SURVEY §8 a-13 / a-14 at module level (pure torch modules, reference state_dict keys)."""
-    from mm_dfn_amd import MFN, MMGatedAttention
-    g = np.load(os.path.join(GOLD, "fusion_modules.npz"))
-    rs = np.random.RandomState(700)
-    mfn = MFN()
-    mfn.load_state_dict(synthetic.seeded_state_dict(mfn.state_dict(), 700))
-    mfn.eval()
-    x = torch.from_numpy(rs.randn(9, 2, 900).astype(np.float32)).requires_grad_(True)
-    R = torch.from_numpy(rs.randn(9, 2, 400).astype(np.float32))
-    y = mfn(x)
-    (y * R).sum().backward()
-    assert np.abs(y.detach().numpy() - g["mfn_y"]).max() < 1e-5
-    assert np.abs(x.grad.numpy() - g["mfn_dx"]).max() / np.abs(g["mfn_dx"]).max() < 1e-4
-    assert np.abs(mfn.gamma1_fc1.weight.grad.numpy() - g["mfn_dW"]).max() / np.abs(g["mfn_dW"]).max() < 1e-4
-    ga = MMGatedAttention(300, 100, att_type='general')
-    ga.load_state_dict(synthetic.seeded_state_dict(ga.state_dict(), 701))
-    ga.eval()
-    a, v, l = (torch.from_numpy(rs.randn(11, 300).astype(np.float32)) for _ in range(3))
-    with torch.no_grad():
-        assert np.abs(ga(a, v, l, ['a', 'v', 'l']).numpy() - g["gated_avl"]).max() < 1e-6
-        assert np.abs(ga(a, [], l, ['a', 'l']).numpy() - g["gated_al"]).max() < 1e-6
-
-
 def test_pinned_lru_evicts_one_at_a_time_and_records_capture_users():
     from mm_dfn_amd.layout import PinnedLRU, recording
     c = PinnedLRU(3)

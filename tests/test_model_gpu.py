@@ -381,3 +381,30 @@ def test_fusion_modules_run_without_library_gemms():
     assert any("softmax_scale_bwd_kernel" in n for n in names) and any("mfn_mem_fwd_kernel" in n for n in names)
     assert not [n for n in names if n.startswith("Cijk_") or "gemm" in n.lower() and "gemm_tn" not in n], names
     assert mfn.gamma2_fc2.weight.grad is not None and gat.transform_vl.weight.grad is not None
+
+
+def test_mfn_and_gated_attention_modules_against_reference_golden():
+    """SURVEY 8 a-13 / a-14 at module level against fixtures generated from the reference modules
+    (tests/golden/fusion_modules.npz, tests/golden/make_golden.py): outputs, input gradient and a weight gradient of MFN
+    (model_fusion.py:10-120), outputs of MMGatedAttention 'general' for three and two modalities (model.py:718-781)."""
+    import os
+    from mm_dfn_amd import MFN, MMGatedAttention, synthetic
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fusion_modules.npz"))
+    rs = np.random.RandomState(700)
+    mfn = MFN()
+    mfn.load_state_dict(synthetic.seeded_state_dict(mfn.state_dict(), 700))
+    mfn = mfn.to(DEV).eval()
+    x = torch.from_numpy(rs.randn(9, 2, 900).astype(np.float32)).to(DEV).requires_grad_(True)
+    R = torch.from_numpy(rs.randn(9, 2, 400).astype(np.float32)).to(DEV)
+    y = mfn(x)
+    (y * R).sum().backward()
+    assert np.abs(y.detach().cpu().numpy() - g["mfn_y"]).max() < 1e-5
+    assert np.abs(x.grad.cpu().numpy() - g["mfn_dx"]).max() / np.abs(g["mfn_dx"]).max() < 1e-4
+    assert np.abs(mfn.gamma1_fc1.weight.grad.cpu().numpy() - g["mfn_dW"]).max() / np.abs(g["mfn_dW"]).max() < 1e-4
+    ga = MMGatedAttention(300, 100, att_type='general')
+    ga.load_state_dict(synthetic.seeded_state_dict(ga.state_dict(), 701))
+    ga = ga.to(DEV).eval()
+    a, v, l = (torch.from_numpy(rs.randn(11, 300).astype(np.float32)).to(DEV) for _ in range(3))
+    with torch.no_grad():
+        assert np.abs(ga(a, v, l, ['a', 'v', 'l']).cpu().numpy() - g["gated_avl"]).max() < 2e-6
+        assert np.abs(ga(a, [], l, ['a', 'l']).cpu().numpy() - g["gated_al"]).max() < 2e-6
