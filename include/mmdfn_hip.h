@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 9). */
+/* Library / device sanity: returns the ABI version (currently 10). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -178,6 +178,12 @@ int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, const 
                        int32_t* rank, int L, int B, int P, int H, void* stream);
 int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX,
                            const float* const* addend, int L, int B, int P, int H, void* stream);
+/* Column sums out[c] = sum_r A[r][c] of an (R, H) matrix (row stride lda; H, lda % 4 == 0, 16-byte aligned), bit-reproducible
+ * (slab partial sums + a small final launch): the bias gradient of gate pre-activations gathered after a bias-free
+ * projection (replaces the autograd `sum` of the broadcast bias add, model.py:1082).
+ * workspace: mmdfn_colsum_workspace(H) floats. */
+int64_t mmdfn_colsum_workspace(int H);
+int mmdfn_colsum(const float* A, int64_t R, int H, int lda, float* out, float* workspace, void* stream);
 int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const int32_t* rank,
                         const int64_t* flat_idx, float* out, const float* weights,
                         int L, int B, int P, int N, int H, void* stream);

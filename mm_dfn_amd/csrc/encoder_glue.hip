@@ -18,6 +18,7 @@ namespace {
 
 constexpr int MAXMOD = 4;
 constexpr int MAXL = 2048;
+constexpr int COLSUM_SLABS = 48;   // row slabs of the column-sum kernel (x 64-column blocks: ~480 workgroups at H = 600)
 
 struct ModPtrs {
     const float* p[MAXMOD];
@@ -206,6 +207,62 @@ __global__ void mask_scale_kernel(MaskScaleGroups G, int ngroups, float scale) {
     }
 }
 
+// out[c] = sum_r A[r][c] (the bias gradient of gate pre-activations that were gathered AFTER a bias-free projection: every
+// gathered row, padding included, received the bias, so its gradient is the column sum of ALL rows of dS -- not of the
+// scattered dG the weight gradient contracts).  Grid: 64-column blocks x row slabs; a slab's partial sums go to `ws`
+// [slab][H] and a second small launch adds them in slab order (bit-reproducible).  (A single launch whose last workgroup
+// finishes the sum needs a device-scope release fence per workgroup; on this chip that writes back the L2's dirty lines --
+// the 17 MB of dS the GRU backward has just produced -- and took 43 us against 8 us for the two launches.)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t R, int H, int lda,
+                                                     float* __restrict__ ws) {
+    __shared__ float4 part[16][16];
+    const int cb = blockIdx.x, sl = blockIdx.y, nsl = gridDim.y;
+    const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;           // 16 lanes x 16 bytes = the 64 columns; 16 row groups
+    const int col = 64 * cb + 4 * c4;
+    const int64_t rper = (R + nsl - 1) / nsl;
+    const int64_t r0 = sl * rper;
+    const int64_t r1 = (r0 + rper < R) ? r0 + rper : R;
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < H) {
+        const float* base = A + col;
+        for (int64_t r = r0 + rg; r < r1; r += 64) {                  // four independent 16-byte loads in flight per thread
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + 16 * u;
+                if (rr < r1) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + rr * lda);
+                    acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+                }
+            }
+        }
+    }
+    float4 t = make_float4((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                           (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w));
+    part[rg][c4] = t;
+    __syncthreads();
+    if (rg == 0 && col < H) {
+        float4 s4 = part[0][c4];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { const float4 v = part[q][c4]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+        *reinterpret_cast<float4*>(ws + (int64_t)sl * H + col) = s4;
+    }
+}
+
+// out[c] = sum over slabs (in slab order) of ws[slab][c]
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ ws, int nsl, int H, float* __restrict__ out) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= H) return;
+    float v[COLSUM_SLABS];                       // all slabs requested before the first add (one round trip, not nsl)
+#pragma unroll
+    for (int s2 = 0; s2 < COLSUM_SLABS; ++s2) v[s2] = (s2 < nsl) ? ws[(int64_t)s2 * H + c] : 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < COLSUM_SLABS; ++s2) t += v[s2];
+    out[c] = t;
+}
+
 }  // namespace
 
 extern "C" int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, const float* bias, float* S,
@@ -286,6 +343,22 @@ extern "C" int mmdfn_mask_scale(int ngroups, const float* const* x, const float*
     }
     for (int g = ngroups; g <= MAXMOD; ++g) G.start4[g] = acc;
     hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for(acc)), dim3(256), 0, (hipStream_t)stream, G, ngroups, scale);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t mmdfn_colsum_workspace(int H) { return (int64_t)COLSUM_SLABS * H; }
+
+extern "C" int mmdfn_colsum(const float* A, int64_t R, int H, int lda, float* out, float* workspace, void* stream) {
+    if (R <= 0 || H <= 0 || (H & 3) || lda < H || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
+        (reinterpret_cast<uintptr_t>(out) & 15)) return -1;
+    const int ncb = (H + 63) / 64;
+    if (ncb > 64) return -1;
+    int nsl = COLSUM_SLABS;
+    if ((int64_t)nsl * 64 > R) nsl = (int)((R + 63) / 64);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ncb, nsl), dim3(256), 0, (hipStream_t)stream, A, R, H, lda, workspace);
+    MMDFN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((H + 63) / 64), dim3(64), 0, (hipStream_t)stream, workspace, nsl, H, out);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

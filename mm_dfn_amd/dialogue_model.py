@@ -71,7 +71,7 @@ class _EdgeAttentionParams(nn.Module):
         self.att = _MlpAttention(dim)
 
 
-PROJECT_THEN_GATHER_ROWS = 12000
+PROJECT_THEN_GATHER_ROWS = 0
 
 
 class DialogueGNNModel(nn.Module):
@@ -182,9 +182,11 @@ class DialogueGNNModel(nn.Module):
                 # cfg2's 7040 party rows the extra small launches cost more than the halved GEMMs save: 1.146 vs
                 # 1.125 ms per step, tools/ab_project_then_gather.py, round 2)
                 w_ih, b_ih, _ = fused_gru._layer_params(self.rnn_parties, 0)
-                G = ops.linear2(torch.stack(act, 0), w_ih[0], w_ih[1], None, None)
-                gi_p, rank = ops.party_gather(G, qmask, bias=torch.cat(b_ih))
-                ctx, E = fused_gru.bigru2([Xl, None], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
+                gi_p, rank, *passed = ops.project_gather(act, qmask, w_ih[0], w_ih[1], b_ih[0], b_ih[1],
+                                                         fused_gru._stacked_view(*w_ih), fused_gru._stacked_view(*b_ih))
+                passed = iter(passed)
+                Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
+                ctx, E = fused_gru.bigru2([Xl_, None], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
                                           gi0=[None, gi_p])
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
             if act:

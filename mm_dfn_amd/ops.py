@@ -326,6 +326,128 @@ def party_gather(Xs, qmask, bias=None, passthrough=False):
     return _PartyGather.apply(qmask, bias, passthrough, *Xs)
 
 
+
+def colsum(A):
+    """Column sums of an (R, H) fp32 matrix (unit inner stride) in one bit-reproducible launch (csrc/encoder_glue.hip)."""
+    _hip.require_cuda(A)
+    _hip.require_f32(A)
+    if A.stride(1) != 1:
+        A = A.contiguous()
+    R, H = A.shape
+    lib = _hip.lib()
+    ws = torch.empty(int(lib.mmdfn_colsum_workspace(H)), dtype=torch.float32, device=A.device)
+    out = torch.empty(H, dtype=torch.float32, device=A.device)
+    _hip.check(lib.mmdfn_colsum(_hip.ptr(A), R, H, A.stride(0), _hip.ptr(out), _hip.ptr(ws), _hip.stream()), "mmdfn_colsum")
+    return out
+
+
+class _ProjectGather(torch.autograd.Function):
+    """First party-GRU layer without projecting padded party rows: gi_p = party_gather(X_m [W1; W2]^T) + [b1; b2] for every
+    speaker-encoded modality m, as ONE node: a grouped launch of the few-row kernel for the projections (each modality its
+    own problem, no stacked copy), the gather kernel, and on the way back the scatter, ONE grouped K-major launch for the
+    input gradients (accumulated onto the gradient that reaches X_m through its passthrough alias), the column-sum kernel
+    for the bias gradient and queued weight-gradient segments.  Outputs: (gi_p (L, Mn*B*P, N), rank, X_0', .., X_{Mn-1}')
+    with X_m' identities of the inputs (see _PartyGather)."""
+
+    @staticmethod
+    def forward(ctx, qmask, w1, w2, b1, b2, wcat, bcat, *Xs):
+        _hip.require_cuda(qmask, w1, w2, *Xs)
+        mods = [x.contiguous() for x in Xs]
+        qmask = qmask.contiguous()
+        L, B, P = qmask.shape
+        H = mods[0].shape[-1]
+        Mn = len(mods)
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        n1, N = w1.shape[0], w1.shape[0] + w2.shape[0]
+        G = torch.empty(Mn, L * B, N, dtype=torch.float32, device=qmask.device)
+        linear_group_raw([dict(x=m.view(L * B, H), w=w1c, w2=w2c, out=G[i]) for i, m in enumerate(mods)])
+        bias = None
+        if b1 is not None:
+            bias = bcat if bcat is not None else torch.cat([b1, b2])
+        S = torch.empty(L, Mn * B * P, N, dtype=torch.float32, device=qmask.device)
+        rank = torch.empty(L, B, P, dtype=torch.int32, device=qmask.device)
+        rc = _hip.lib().mmdfn_party_gather(Mn, _hip.ptr_array([G[i] for i in range(Mn)]), _hip.ptr(qmask), _hip.ptr(bias),
+                                           _hip.ptr(S), _hip.ptr(rank), L, B, P, N, _hip.stream())
+        _hip.check(rc, "mmdfn_party_gather")
+        ctx.dims = (L, B, P, H, Mn, n1, N)
+        ctx.refs = (w1, w2, b1, b2)
+        ctx.save_for_backward(rank, w1c, w2c, wcat, *mods)
+        ctx.mark_non_differentiable(rank)
+        ctx.set_materialize_grads(False)
+        return (S, rank) + tuple(Xs)
+
+    @staticmethod
+    def backward(ctx, dS, _drank, *dpass):
+        rank, w1, w2, wcat, *mods = ctx.saved_tensors
+        p1, p2, b1, b2 = ctx.refs
+        L, B, P, H, Mn, n1, N = ctx.dims
+        dev = rank.device
+        dS = dS.contiguous() if dS is not None else torch.zeros(L, Mn * B * P, N, dtype=torch.float32, device=dev)
+        dG = torch.empty(Mn, L * B, N, dtype=torch.float32, device=dev)
+        rc = _hip.lib().mmdfn_party_gather_bwd(Mn, _hip.ptr(dS), _hip.ptr(rank), _hip.ptr_array([dG[m] for m in range(Mn)]),
+                                               None, L, B, P, N, _hip.stream())
+        _hip.check(rc, "mmdfn_party_gather_bwd")
+        db1 = db2 = None
+        if b1 is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            db = colsum(dS.view(-1, N))
+            db1, db2 = db[:n1], db[n1:]
+        # input gradients: dX_m = dG_m [W1; W2] (+ the gradient that reached X_m's alias), one grouped launch
+        dXs = [None] * Mn
+        need = [m for m in range(Mn) if ctx.needs_input_grad[7 + m]]
+        if need:
+            outs = []
+            for m in need:
+                d = dpass[m] if m < len(dpass) else None
+                if d is not None and not (d.is_contiguous() and d.data_ptr() % 16 == 0):
+                    d = d.contiguous()
+                outs.append(d)
+            if wcat is not None:
+                probs = []
+                for m, d in zip(need, outs):
+                    q = dict(x=dG[m], wk=wcat)
+                    if d is not None:
+                        q.update(out=d.view(L * B, H), accumulate=True)      # in place on the alias' gradient buffer
+                    probs.append(q)
+                res = linear_group_raw(probs)
+            else:
+                res = []
+                for m, d in zip(need, outs):
+                    q = dict(x=dG[m][:, :n1], wk=w1)
+                    if d is not None:
+                        q.update(out=d.view(L * B, H), accumulate=True)
+                    o = linear_group_raw([q])[0]
+                    linear_group_raw([dict(x=dG[m][:, n1:], wk=w2, out=o, accumulate=True)])
+                    res.append(o)
+            for m, o in zip(need, res):
+                dXs[m] = o.view(L, B, H)
+        else:
+            dXs = [d for d in dpass] + [None] * (Mn - len(dpass))
+        # weight gradients: one segment per modality and direction
+        dw1 = dw2 = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            x2 = [m.view(L * B, H) for m in mods]
+            if _queueable(p1, [], n1, H) and _queueable(p2, [], N - n1, H):
+                for m in range(Mn):
+                    queue_wgrad(dG[m][:, :n1], x2[m], p1)
+                    queue_wgrad(dG[m][:, n1:], x2[m], p2)
+            else:
+                for m in range(Mn):
+                    a, _ = _wgrad_inline(dG[m][:, :n1], x2[m], False)
+                    b, _ = _wgrad_inline(dG[m][:, n1:], x2[m], False)
+                    dw1 = a if dw1 is None else dw1 + a
+                    dw2 = b if dw2 is None else dw2 + b
+        return (None, dw1, dw2, db1, db2, None, None) + tuple(dXs)
+
+
+def project_gather(Xs, qmask, w1, w2, b1, b2, wcat=None, bcat=None):
+    """(gi_p, rank, X_0', ..): see _ProjectGather.  ``wcat`` / ``bcat``: optional stacked views of [w1; w2] / [b1; b2] (no
+    gradient flows through them; without wcat the input gradient takes two launches per modality, without bcat the bias is
+    concatenated per call)."""
+    if w1.shape[1] % 4 or (w1.shape[0] + w2.shape[0]) % 4:
+        raise ValueError("project_gather: widths must be multiples of 4")
+    return _ProjectGather.apply(qmask, w1, w2, b1, b2, wcat, bcat, *Xs)
+
+
 class _PartyCombine(torch.autograd.Function):
     """out (Mn, N, H) = strip_pad(base_m + w_m * scatter(E)); E may be None (no speaker encoder), else it holds one
     (B*P)-column block per modality with a NON-ZERO weight, in modality order."""

@@ -9,9 +9,11 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mm_dfn_amd import FocalLoss, synthetic, train  # noqa: E402
+from mm_dfn_amd import FocalLoss, synthetic, train, dialogue_model  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+if len(sys.argv) > 2:                                   # party-row threshold of the project-then-gather form
+    dialogue_model.PROJECT_THEN_GATHER_ROWS = int(sys.argv[2])
 cfg = dict(synthetic.CONFIGS[name])
 model = synthetic.build_model(dropout=0.5, **cfg)
 model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
