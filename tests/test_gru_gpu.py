@@ -157,6 +157,58 @@ def test_party_gather_combine_kernels_match_index_composition(P, lengths, w, pas
         assert rel_err(Xk[i].grad, Xr[i].grad) < 1e-6
 
 
+@pytest.mark.parametrize("stacked_views", [True, False])
+@pytest.mark.parametrize("P,lengths,nact", [(2, [15, 9, 1, 6], 2), (9, [12, 12, 3], 3), (3, [1], 1), (2, [110, 64, 80], 2)])
+def test_project_gather_node_matches_projection_of_gathered_rows(P, lengths, nact, stacked_views):
+    """The first party-GRU layer as the reference computes it -- gather the party rows (padding = zeros), then
+    X [W_ih; W_ih_reverse]^T + b on EVERY row (model.py:1076-1082) -- against ops.project_gather (projection of the
+    utterances, gather, bias on every row): gate pre-activations, the gradients of both weight blocks and both biases (the
+    bias gradient is the column sum over ALL party rows, padding included), and the input gradients including the part
+    that arrives through the passthrough aliases."""
+    from mm_dfn_amd import ops
+    cfg = dict(B=len(lengths), L=max(lengths), P=P, C=6, nlayers=2, D_t=100, D_a=32, D_v=64)
+    q = synthetic.make_batch(4, lengths=lengths, **cfg)["qmask"].to(DEV)
+    L, B = max(lengths), len(lengths)
+    rs = np.random.RandomState(9)
+    t = lambda *sh: torch.from_numpy(rs.randn(*sh).astype(np.float32)).to(DEV)
+    Xs = [t(L, B, 200) for _ in range(nact)]
+    wbuf, bbuf = t(600, 200) * 0.1, t(600)
+    Wg, Wp = t(L, nact * B * P, 600), [t(L, B, 200) for _ in range(nact)]
+    # reference composition: index-op gather, then the projection over every party row
+    Xr = [x.clone().requires_grad_(True) for x in Xs]
+    w1r, w2r = wbuf[:300].clone().requires_grad_(True), wbuf[300:].clone().requires_grad_(True)
+    b1r, b2r = bbuf[:300].clone().requires_grad_(True), bbuf[300:].clone().requires_grad_(True)
+    Sr = V.party_gather(torch.stack(Xr, 0), V.party_plan(q))
+    gr = torch.nn.functional.linear(Sr, torch.cat([w1r, w2r]), torch.cat([b1r, b2r]))
+    ((gr * Wg).sum() + sum((x * w).sum() for x, w in zip(Xr, Wp))).backward()
+    # the node
+    Xk = [x.clone().requires_grad_(True) for x in Xs]
+    wk, bk = wbuf.clone(), bbuf.clone()
+    w1, w2 = wk[:300].requires_grad_(True), wk[300:].requires_grad_(True)
+    b1, b2 = bk[:300].requires_grad_(True), bk[300:].requires_grad_(True)
+    views = (wk, bk) if stacked_views else (None, None)
+    gk, rank, *passed = ops.project_gather(Xk, q, w1, w2, b1, b2, *views)
+    assert all(p_.data_ptr() == x.data_ptr() for p_, x in zip(passed, Xk))
+    ((gk * Wg).sum() + sum((x * w).sum() for x, w in zip(passed, Wp))).backward()
+    assert abs_err(gk, gr) < 2e-5
+    for a, b in ((w1, w1r), (w2, w2r), (b1, b1r), (b2, b2r)):
+        assert rel_err(a.grad, b.grad) < 2e-5
+    for a, b in zip(Xk, Xr):
+        assert rel_err(a.grad, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("R,H", [(7040, 600), (33, 600), (1, 4), (19008, 600), (100, 68), (64, 64)])
+def test_column_sum_kernel(R, H):
+    from mm_dfn_amd import ops
+    A = torch.from_numpy(np.random.RandomState(R + H).randn(R, H).astype(np.float32)).to(DEV)
+    got = ops.colsum(A)
+    assert torch.equal(got, ops.colsum(A))                        # fixed summation order
+    want = A.double().sum(0)
+    assert float((got.double() - want).abs().max()) < 1e-5 * max(1.0, float(A.abs().sum(0).max()))
+    part = ops.colsum(A[:, : H // 2 // 4 * 4 or 4])               # a column slice: row stride > width
+    assert float((part.double() - want[: part.numel()]).abs().max()) < 1e-5 * max(1.0, float(A.abs().sum(0).max()))
+
+
 @pytest.mark.parametrize("shapes", [[(9, 3, 200)], [(110, 16, 200), (110, 64, 200)], [(1, 1, 4), (3, 5, 8), (2, 2, 12), (7, 1, 4)]])
 def test_multi_tensor_mask_scale_is_dropout_on_given_flags(shapes):
     """nn.GRU(dropout=p) between the layers (model.py:866,868) for every encoder group in one launch each way:
