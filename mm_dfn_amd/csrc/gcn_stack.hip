@@ -774,319 +774,9 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 32-row forms of the two K8 kernels (round 3).  At 16 rows per block a wave issues one A fragment read per weight
-// fragment read and 4 MFMAs, pays the two block barriers, the pointwise phase and the operand prefetch distance every
-// 1.4 us of MFMA work: 3.25 us per block at BASELINE cfg5 (24 576 rows), 50 / 32 TFLOP/s.  With 32 rows per block every
-// weight fragment feeds two row tiles (2 + NT reads per 8 NT MFMAs), the barriers and the prefetch round trip are paid
-// once per 2.8 us of MFMA work, and A(block) needs no second LDS buffer: block i + 1 is parked while everybody is in the
-// pointwise phase of block i (after the barrier that ends the contraction) -- the LDS footprint is unchanged.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int RB2 = 32;
-
-// acc[r][t] += A (rows 16 r .. 16 r + 15 of sA) . W_t^T, r < 2: contract() with every weight fragment used twice
-template <int NT>
-__device__ __forceinline__ void contract2(f32x4 (&acc)[2][NT], const int (&wrow0)[NT], const float* sA, int lda,
-                                          const float* sW, int ldw, int K) {
-    const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
-    const float* ap0 = sA + fi * lda + 4 * g;
-    const float* ap1 = ap0 + 16 * lda;
-    const float* bp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bp[t] = sW + (wrow0[t] + fi) * ldw + 4 * g;
-    const int nk = (K + 15) >> 4;
-    float4 a0[2], a1[2], b0[NT], b1[NT];
-#define CT2_LOAD(A_, B_, KC)                                                           \
-    do {                                                                               \
-        A_[0] = ld4(ap0 + 16 * (KC));                                                  \
-        A_[1] = ld4(ap1 + 16 * (KC));                                                  \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) B_[t] = ld4(bp[t] + 16 * (KC)); \
-    } while (0)
-#define CT2_MMA(A_, B_)                                                                                        \
-    do {                                                                                                       \
-        const float av_[2][4] = {{A_[0].x, A_[0].y, A_[0].z, A_[0].w}, {A_[1].x, A_[1].y, A_[1].z, A_[1].w}};  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                   \
-                const float bv_ = (j == 0) ? B_[t].x : (j == 1) ? B_[t].y : (j == 2) ? B_[t].z : B_[t].w;     \
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[0][j], bv_, acc[0][t], 0, 0, 0);         \
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[1][j], bv_, acc[1][t], 0, 0, 0);         \
-            }                                                                                                  \
-    } while (0)
-    CT2_LOAD(a0, b0, 0);
-    int kc = 0;
-    for (; kc + 2 <= nk; kc += 2) {
-        CT2_LOAD(a1, b1, kc + 1);
-        CT2_MMA(a0, b0);
-        if (kc + 2 < nk) CT2_LOAD(a0, b0, kc + 2);      // uniform scalar branch
-        CT2_MMA(a1, b1);
-    }
-    if (kc < nk) CT2_MMA(a0, b0);
-#undef CT2_LOAD
-#undef CT2_MMA
-}
-
-__global__ __launch_bounds__(256) void lstm_gate_fwd32_kernel(const float* __restrict__ q, const float* __restrict__ h,
-                                                              const float* __restrict__ c, const float* __restrict__ Wih,
-                                                              const float* __restrict__ Whh, const float* __restrict__ bsum, const float* __restrict__ bsum2,
-                                                              float* __restrict__ gates, float* __restrict__ h_out,
-                                                              float* __restrict__ c_out, int R, int H) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int K = h ? 2 * H : H;
-    const int ldw = lds_stride(K), lde = UB + 4;
-    float* sW = smem;                                  // [4 gates][UB][ldw]
-    float* sA = sW + 4 * UB * ldw;                     // [32][ldw]   rows [q | h]
-    float* sE = sA + RB2 * ldw;                        // [4 gates][32][lde] pre-activations
-    const int u0 = blockIdx.y * UB;
-    const int nu = min(UB, H - u0);
-    const int H4 = H >> 2;
-    constexpr int NW1 = 13;                            // 4 gates x 32 units x (H / 4 <= 25) / 256 threads
-    float4 vi[NW1], vh[NW1];
-    {
-        const int total = 4 * UB * H4;
-#pragma unroll
-        for (int e = 0; e < NW1; ++e) {
-            const int i = threadIdx.x + 256 * e;
-            const int rowl = i / H4, k = (i - rowl * H4) * 4;
-            const int gate = rowl / UB, ul = rowl - gate * UB;
-            const bool ok = i < total && ul < nu;
-            const int64_t src = (int64_t)(gate * H + u0 + ul) * H + k;
-            vi[e] = ok ? ld4(Wih + src) : zero4();
-            vh[e] = (ok && h) ? ld4(Whh + src) : zero4();
-        }
-    }
-    const int nrb = (R + RB2 - 1) / RB2;
-    const int w = threadIdx.x >> 6;
-    const int wrow0[2] = {w * UB, w * UB + 16};        // gate = wave, both unit tiles (units past nu: zero weight rows)
-    constexpr int NS = 4;                              // 32 x H / 4 / 256 <= 4 for H <= 128
-    float4 rq[NS], rh[NS];
-    auto issue = [&](int rb) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB2 + r;
-            const bool ok = i < RB2 * H4 && row < R;
-            rq[s] = ok ? ld4(q + (int64_t)row * H + k) : zero4();
-            rh[s] = (ok && h) ? ld4(h + (int64_t)row * H + k) : zero4();
-        }
-    };
-    auto park = [&]() {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int i = threadIdx.x + 256 * s;
-            if (i >= RB2 * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4;
-            st4(sA + r * ldw + k, rq[s]);
-            if (h) st4(sA + r * ldw + H + k, rh[s]);
-        }
-    };
-    if ((int)blockIdx.x < nrb) issue(blockIdx.x);
-    {
-        const int total = 4 * UB * H4;
-#pragma unroll
-        for (int e = 0; e < NW1; ++e) {
-            const int i = threadIdx.x + 256 * e;
-            if (i >= total) continue;
-            const int rowl = i / H4, k = (i - rowl * H4) * 4;
-            st4(sW + rowl * ldw + k, vi[e]);                       // rowl = gate * UB + ul
-            if (h) st4(sW + rowl * ldw + H + k, vh[e]);
-        }
-        zero_pads(sW, 4 * UB, ldw, K);
-    }
-    zero_pads(sA, RB2, ldw, K);
-    if ((int)blockIdx.x < nrb) park();
-    // the cell math: every thread owns (row, 2 units) of each 16-row half of the 32 x 32 block
-    const int er = threadIdx.x >> 4, eu = (threadIdx.x & 15) * 2;
-    const bool ethread = eu < nu;                      // nu is a multiple of 4
-    float2 bi = make_float2(0.f, 0.f), bf = bi, bg = bi, bo = bi;
-    if (ethread) {
-        bi = *reinterpret_cast<const float2*>(bsum + u0 + eu); bf = *reinterpret_cast<const float2*>(bsum + H + u0 + eu);
-        bg = *reinterpret_cast<const float2*>(bsum + 2 * H + u0 + eu); bo = *reinterpret_cast<const float2*>(bsum + 3 * H + u0 + eu);
-        if (bsum2) {
-            const float2 ci = *reinterpret_cast<const float2*>(bsum2 + u0 + eu), cf = *reinterpret_cast<const float2*>(bsum2 + H + u0 + eu);
-            const float2 cg = *reinterpret_cast<const float2*>(bsum2 + 2 * H + u0 + eu), co = *reinterpret_cast<const float2*>(bsum2 + 3 * H + u0 + eu);
-            bi.x += ci.x; bi.y += ci.y; bf.x += cf.x; bf.y += cf.y; bg.x += cg.x; bg.y += cg.y; bo.x += co.x; bo.y += co.y;
-        }
-    }
-    __syncthreads();
-    FOR_ROW_BLOCKS(rb, nrb) {
-        const int nxt = rb + gridDim.x;
-        if (nxt < nrb) issue(nxt);
-        float2 cp[2];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int erow = rb * RB2 + 16 * hf + er;
-            cp[hf] = (c && ethread && erow < R) ? *reinterpret_cast<const float2*>(c + (int64_t)erow * H + u0 + eu)
-                                                : make_float2(0.f, 0.f);
-        }
-        f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-        contract2<2>(acc, wrow0, sA, ldw, sW, ldw, K);
-        {
-            const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sE[(w * RB2 + 16 * hf + 4 * g + r) * lde + 16 * t + fi] = acc[hf][t][r];
-        }
-        __syncthreads();                               // the pre-activations are complete; nobody reads A(rb) any more
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int erl = 16 * hf + er, erow = rb * RB2 + erl;
-            if (ethread && erow < R) {
-                const float2 pi = *reinterpret_cast<const float2*>(sE + (0 * RB2 + erl) * lde + eu);
-                const float2 pf = *reinterpret_cast<const float2*>(sE + (1 * RB2 + erl) * lde + eu);
-                const float2 pg = *reinterpret_cast<const float2*>(sE + (2 * RB2 + erl) * lde + eu);
-                const float2 po = *reinterpret_cast<const float2*>(sE + (3 * RB2 + erl) * lde + eu);
-                float2 gi, gf, gg, go, cn, hn;
-#define K8F(F_)                                                                 \
-    {                                                                           \
-        gi.F_ = sigm(pi.F_ + bi.F_); gf.F_ = sigm(pf.F_ + bf.F_); gg.F_ = tanhf_(pg.F_ + bg.F_); go.F_ = sigm(po.F_ + bo.F_); \
-        cn.F_ = gf.F_ * cp[hf].F_ + gi.F_ * gg.F_;                              \
-        hn.F_ = go.F_ * tanhf_(cn.F_);                                          \
-    }
-                K8F(x) K8F(y)
-#undef K8F
-                float* gr = gates + (int64_t)erow * 4 * H + u0 + eu;
-                *reinterpret_cast<float2*>(gr) = gi; *reinterpret_cast<float2*>(gr + H) = gf;
-                *reinterpret_cast<float2*>(gr + 2 * H) = gg; *reinterpret_cast<float2*>(gr + 3 * H) = go;
-                *reinterpret_cast<float2*>(c_out + (int64_t)erow * H + u0 + eu) = cn;
-                *reinterpret_cast<float2*>(h_out + (int64_t)erow * H + u0 + eu) = hn;
-            }
-        }
-        if (nxt < nrb) park();
-        __syncthreads();
-    }
-}
-
-// ABL (tuning build, timing only): 1 no MFMA, 2 no operand loads, 4 no gate math (operands parked as loaded), 8 no result stores
-template <int ABL>
-__global__ __launch_bounds__(256) void lstm_gate_bwd32_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
-                                                              const float* __restrict__ c_new, const float* __restrict__ dh_a,
-                                                              const float* __restrict__ dh_b, const float* __restrict__ dc_next,
-                                                              const float* __restrict__ Wih, const float* __restrict__ Whh,
-                                                              const float* __restrict__ dres, float* __restrict__ dG,
-                                                              float* __restrict__ dc_prev, float* __restrict__ dq,
-                                                              float* __restrict__ dh_prev, int R, int H, int has_h,
-                                                              int lddres) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int K = 4 * H;
-    const int ldw = lds_stride(K);
-    float* sW = smem;                                  // [CBW][ldw]
-    float* sA = sW + CBW * ldw;                        // [32][ldw]   rows dG
-    const int nb = (H + CBW - 1) / CBW;
-    const bool is_dh = (int)blockIdx.y >= nb;
-    const int n0 = (is_dh ? blockIdx.y - nb : blockIdx.y) * CBW;
-    const int ncols = min(CBW, H - n0);
-    WeightStager<true> wst;
-    wst.issue(is_dh ? Whh : Wih, H, n0, ncols, K);
-    const int nrb = (R + RB2 - 1) / RB2;
-    const int w = threadIdx.x >> 6;
-    const int wrow0[1] = {16 * w < ncols ? 16 * w : 0};
-    const bool has_tile = 16 * w < ncols;
-    const bool writer = blockIdx.y == 0;
-    const int H4 = H >> 2;
-    constexpr int NS = 4;                              // 32 * H / 4 / 256 <= 4 for H <= 128
-    float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdc[NS];
-    auto issue = [&](int rb) {
-#pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
-            const int i = threadIdx.x + 256 * s_;
-            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB2 + r;
-            const bool ok = !(ABL & 2) && i < RB2 * H4 && row < R;
-            const int64_t o = (int64_t)row * H + u;
-            const float* gr = gates + (int64_t)row * 4 * H + u;
-            rgi[s_] = ok ? ld4(gr) : zero4();
-            rgf[s_] = ok ? ld4(gr + H) : zero4();
-            rgg[s_] = ok ? ld4(gr + 2 * H) : zero4();
-            rgo[s_] = ok ? ld4(gr + 3 * H) : zero4();
-            rcn[s_] = ok ? ld4(c_new + o) : zero4();
-            rcp[s_] = (ok && c_prev) ? ld4(c_prev + o) : zero4();
-            float4 d = (ok && dh_a) ? ld4(dh_a + o) : zero4();
-            if (ok && dh_b) d = add4(d, ld4(dh_b + o));
-            rdh[s_] = d;
-            rdc[s_] = (ok && dc_next) ? ld4(dc_next + o) : zero4();
-        }
-    };
-    auto park = [&](int rb) {
-#pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
-            const int i = threadIdx.x + 256 * s_;
-            if (i >= RB2 * H4) continue;
-            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB2 + r;
-            float4 di, df, dg, dO, dcp;
-#define GB1(F)                                                                      \
-    {                                                                               \
-        const float gi = rgi[s_].F, gf = rgf[s_].F, gg = rgg[s_].F, go = rgo[s_].F; \
-        const float tc = tanhf_(rcn[s_].F);                                         \
-        const float dc = rdc[s_].F + rdh[s_].F * go * (1.0f - tc * tc);             \
-        dO.F = rdh[s_].F * tc * go * (1.0f - go);                                   \
-        di.F = dc * gg * gi * (1.0f - gi);                                          \
-        df.F = dc * rcp[s_].F * gf * (1.0f - gf);                                   \
-        dg.F = dc * gi * (1.0f - gg * gg);                                          \
-        dcp.F = dc * gf;                                                            \
-    }
-            if (ABL & 4) { di = rgi[s_]; df = rgf[s_]; dg = rgg[s_]; dO = rgo[s_]; dcp = rcn[s_]; }
-            else { GB1(x) GB1(y) GB1(z) GB1(w) }
-#undef GB1
-            float* sp = sA + r * ldw + u;                // rows past R carry zeros (their loads were zeroed)
-            st4(sp, di); st4(sp + H, df); st4(sp + 2 * H, dg); st4(sp + 3 * H, dO);
-            if (!(ABL & 8) && writer && row < R) {
-                float* d = dG + (int64_t)row * 4 * H + u;
-                st4(d, di); st4(d + H, df); st4(d + 2 * H, dg); st4(d + 3 * H, dO);
-                if (has_h) st4(dc_prev + (int64_t)row * H + u, dcp);
-            }
-        }
-    };
-    if ((int)blockIdx.x < nrb) issue(blockIdx.x);
-    wst.commit(sW, ldw, ncols, K);
-    if (ncols < CBW) {                                 // weight rows of missing columns: zeros (their results are dropped)
-        for (int i = threadIdx.x; i < (CBW - ncols) * (ldw >> 2); i += 256) st4(sW + ncols * ldw + 4 * i, zero4());
-    }
-    zero_pads(sA, RB2, ldw, K);
-    if ((int)blockIdx.x < nrb) park(blockIdx.x);
-    __syncthreads();
-    // results leave straight from the accumulators (C/D layout: lane (fi, g) holds column fi, rows 4 g .. 4 g + 3 of a
-    // 16 x 16 tile: 16 lanes = one 64-byte run of an output row), so A's space is never borrowed and block i + 1 can be
-    // parked as soon as everybody has left the contraction
-    const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
-    const int ecol = n0 + 16 * w + fi;
-    const bool ecol_ok = has_tile && (16 * w + fi) < ncols;
-    float* const outp = is_dh ? dh_prev : dq;
-    FOR_ROW_BLOCKS(rb, nrb) {
-        const int nxt = rb + gridDim.x;
-        if (nxt < nrb) issue(nxt);
-        float rv[2][4];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int erow = rb * RB2 + 16 * hf + 4 * g + r;
-                rv[hf][r] = (!is_dh && dres && ecol_ok && erow < R) ? dres[(int64_t)erow * lddres + ecol] : 0.f;
-            }
-        f32x4 acc[2][1] = {{{0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}}};
-        if (!(ABL & 1)) contract2<1>(acc, wrow0, sA, ldw, sW, ldw, K);
-        else { acc[0][0][0] = sA[fi * ldw + g]; acc[1][0][1] = sA[(16 + fi) * ldw + g]; }
-        if (ecol_ok && !(ABL & 8)) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int erow = rb * RB2 + 16 * hf + 4 * g + r;
-                    if (erow < R) outp[(int64_t)erow * H + ecol] = acc[hf][0][r] + rv[hf][r];
-                }
-        }
-        __syncthreads();                               // every wave is done reading A(rb)
-        if (nxt < nrb) park(nxt);
-        __syncthreads();
-    }
-}
-
-inline bool bad_dims(int64_t R, int H) { return R <= 0 || H < 4 || (H & 3) || H > 100 || R > (int64_t)1 << 30; }
-
-// ------------------------------------------------------------------------------------------------------------------
-// K8 backward, producer / consumer form.  Timing ablations of the kernels above (tools/ablate_gate_bwd.py, 24 576 rows:
-// base 12 us + operand loads 32 + gate math 22 + MFMAs 30 + result stores 29 = the 105 us measured) show the phases of a
-// row block simply add up: four waves that all stage, then all contract, then all store leave the matrix cores idle
+// K8 backward, producer / consumer form.  Timing ablations of the four-wave kernel above (tools/ablate_gate_bwd.py, 24 576
+// rows: base 12 us + operand loads 32 + gate math 22 + MFMAs 30 + result stores 29 = the 105-110 us measured; a 32-row-block
+// variant that reuses every weight fragment for two row tiles changed that by 5 %) show the phases of a row block simply add up: four waves that all stage, then all contract, then all store leave the matrix cores idle
 // while the memory system works and vice versa.  Here the workgroup has EIGHT waves: waves 4-7 are producers (operand
 // loads of block i + 2 in flight, gate math of block i + 1, dG / dc written out, A(i + 1) parked in the other LDS buffer),
 // waves 0-3 are consumers (contraction of A(i) against the weight slice, results stored straight from the accumulators);
@@ -1249,16 +939,141 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
     }
 }
 
-// rows per block of the two K8 kernels: 32 from GATE32_ROWS rows on (tuning build: MMDFN_GATE32=0|1 forces)
-constexpr int GATE32_ROWS = 4096;
-inline bool gate_rows32(int R) {
-#ifdef MMDFN_TUNING
-    if (const char* e = getenv("MMDFN_GATE32")) return atoi(e) != 0;
-#endif
-    return R >= GATE32_ROWS;
+// K8 forward, producer / consumer form (see the backward above): waves 0-3 contract A(i) (wave = gate, both unit tiles) and
+// leave the pre-activations in sE[i & 1]; waves 4-7 run the cell math of block i - 1 from the other sE buffer and store
+// gates / c' / h', park A(i + 1) and keep block i + 2's rows in flight.  One barrier per block.
+__global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __restrict__ q, const float* __restrict__ h,
+                                                               const float* __restrict__ c, const float* __restrict__ Wih,
+                                                               const float* __restrict__ Whh, const float* __restrict__ bsum, const float* __restrict__ bsum2,
+                                                               float* __restrict__ gates, float* __restrict__ h_out,
+                                                               float* __restrict__ c_out, int R, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = h ? 2 * H : H;
+    const int ldw = lds_stride(K), lde = UB + 4;
+    float* sW = smem;                                  // [4 gates][UB][ldw]
+    float* sA = sW + 4 * UB * ldw;                     // [2][16][ldw]   rows [q | h]
+    float* sE = sA + 2 * RB * ldw;                     // [2][4 gates][16][lde] pre-activations
+    const int u0 = blockIdx.y * UB;
+    const int nu = min(UB, H - u0);
+    const int H4 = H >> 2;
+    const int tid = threadIdx.x & 255;
+    const bool producer = threadIdx.x >= 256;
+    // ---- prologue (all 512 threads): weight rows (gate, ul) <- [W_ih | W_hh] row gate * H + u0 + ul; missing units: zeros
+    {
+        const int total = 4 * UB * H4;
+        for (int i = threadIdx.x; i < total; i += 512) {
+            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            const int gate = rowl / UB, ul = rowl - gate * UB;
+            const bool ok = ul < nu;
+            const int64_t src = (int64_t)(gate * H + u0 + ul) * H + k;
+            st4(sW + rowl * ldw + k, ok ? ld4(Wih + src) : zero4());
+            if (h) st4(sW + rowl * ldw + H + k, ok ? ld4(Whh + src) : zero4());
+        }
+        const int np4 = (ldw - K) >> 2;
+        for (int i = threadIdx.x; i < 4 * UB * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sW + r * ldw + K + 4 * j, zero4()); }
+        for (int i = threadIdx.x; i < 2 * RB * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sA + r * ldw + K + 4 * j, zero4()); }
+    }
+    const int nrb = (R + RB - 1) / RB;
+    constexpr int NS = 2;
+    float4 rq[NS], rh[NS];
+    auto issue = [&](int rb) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * H4 && row < R;
+            rq[s] = ok ? ld4(q + (int64_t)row * H + k) : zero4();
+            rh[s] = (ok && h) ? ld4(h + (int64_t)row * H + k) : zero4();
+        }
+    };
+    auto park = [&](float* dst) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            if (i >= RB * H4) continue;
+            const int r = i / H4, k = (i - r * H4) * 4;
+            st4(dst + r * ldw + k, rq[s]);
+            if (h) st4(dst + r * ldw + H + k, rh[s]);
+        }
+    };
+    // the cell math (producers): every thread owns one (row, 2 units) group of the 16 x 32 block
+    const int er = tid >> 4, eu = (tid & 15) * 2;
+    const bool ethread = eu < nu;                      // nu is a multiple of 4
+    float2 bi = make_float2(0.f, 0.f), bf = bi, bg = bi, bo = bi;
+    if (producer && ethread) {
+        bi = *reinterpret_cast<const float2*>(bsum + u0 + eu); bf = *reinterpret_cast<const float2*>(bsum + H + u0 + eu);
+        bg = *reinterpret_cast<const float2*>(bsum + 2 * H + u0 + eu); bo = *reinterpret_cast<const float2*>(bsum + 3 * H + u0 + eu);
+        if (bsum2) {
+            const float2 ci = *reinterpret_cast<const float2*>(bsum2 + u0 + eu), cf = *reinterpret_cast<const float2*>(bsum2 + H + u0 + eu);
+            const float2 cg = *reinterpret_cast<const float2*>(bsum2 + 2 * H + u0 + eu), co = *reinterpret_cast<const float2*>(bsum2 + 3 * H + u0 + eu);
+            bi.x += ci.x; bi.y += ci.y; bf.x += cf.x; bf.y += cf.y; bg.x += cg.x; bg.y += cg.y; bo.x += co.x; bo.y += co.y;
+        }
+    }
+    auto cell = [&](int rb, const float* E, float2 cp) {
+        const int erow = rb * RB + er;
+        if (!(ethread && erow < R)) return;
+        const float2 pi = *reinterpret_cast<const float2*>(E + (0 * RB + er) * lde + eu);
+        const float2 pf = *reinterpret_cast<const float2*>(E + (1 * RB + er) * lde + eu);
+        const float2 pg = *reinterpret_cast<const float2*>(E + (2 * RB + er) * lde + eu);
+        const float2 po = *reinterpret_cast<const float2*>(E + (3 * RB + er) * lde + eu);
+        float2 gi, gf, gg, go, cn, hn;
+#define K8F(F_)                                                                 \
+    {                                                                           \
+        gi.F_ = sigm(pi.F_ + bi.F_); gf.F_ = sigm(pf.F_ + bf.F_); gg.F_ = tanhf_(pg.F_ + bg.F_); go.F_ = sigm(po.F_ + bo.F_); \
+        cn.F_ = gf.F_ * cp.F_ + gi.F_ * gg.F_;                                  \
+        hn.F_ = go.F_ * tanhf_(cn.F_);                                          \
+    }
+        K8F(x) K8F(y)
+#undef K8F
+        float* gr = gates + (int64_t)erow * 4 * H + u0 + eu;
+        *reinterpret_cast<float2*>(gr) = gi; *reinterpret_cast<float2*>(gr + H) = gf;
+        *reinterpret_cast<float2*>(gr + 2 * H) = gg; *reinterpret_cast<float2*>(gr + 3 * H) = go;
+        *reinterpret_cast<float2*>(c_out + (int64_t)erow * H + u0 + eu) = cn;
+        *reinterpret_cast<float2*>(h_out + (int64_t)erow * H + u0 + eu) = hn;
+    };
+    auto load_c = [&](int rb) {
+        const int erow = rb * RB + er;
+        return (c && ethread && erow < R) ? *reinterpret_cast<const float2*>(c + (int64_t)erow * H + u0 + eu) : make_float2(0.f, 0.f);
+    };
+    const int first = blockIdx.x, stride = gridDim.x;
+    float2 cp_prev = make_float2(0.f, 0.f);            // c rows of the block whose cell math runs next
+    if (producer) {
+        if (first < nrb) { issue(first); park(sA); cp_prev = load_c(first); }
+        if (first + stride < nrb) issue(first + stride);
+    }
+    __syncthreads();
+    const int w = tid >> 6;
+    const int wrow0[2] = {w * UB, w * UB + 16};        // consumer wave = gate, both unit tiles
+    int buf = 0, prev_rb = -1;
+    for (int rb = first; rb < nrb; rb += stride) {
+        const int nxt = rb + stride;
+        if (producer) {
+            if (prev_rb >= 0) cell(prev_rb, sE + (buf ^ 1) * 4 * RB * lde, cp_prev);
+            cp_prev = load_c(rb);
+            if (nxt < nrb) {
+                park(sA + (buf ^ 1) * RB * ldw);
+                if (nxt + stride < nrb) issue(nxt + stride);
+            }
+        } else {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            contract<2>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, K);
+            const int lane = tid & 63, fi = lane & 15, g = lane >> 4;
+            float* E = sE + buf * 4 * RB * lde;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) E[(w * RB + 4 * g + r) * lde + 16 * t + fi] = acc[t][r];
+        }
+        __syncthreads();
+        prev_rb = rb;
+        buf ^= 1;
+    }
+    if (producer && prev_rb >= 0) cell(prev_rb, sE + (buf ^ 1) * 4 * RB * lde, cp_prev);
 }
 
-// producer / consumer form of the K8 backward (tuning build: MMDFN_GATE_WS=0|1 forces)
+inline bool bad_dims(int64_t R, int H) { return R <= 0 || H < 4 || (H & 3) || H > 100 || R > (int64_t)1 << 30; }
+
+// producer / consumer forms of the K8 kernels (tuning build: MMDFN_GATE_WS=0|1 forces)
 inline bool gate_ws(int R) {
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_GATE_WS")) return atoi(e) != 0;
@@ -1266,8 +1081,8 @@ inline bool gate_ws(int R) {
     return R >= 64;
 }
 
-inline int row_groups(int R, int column_blocks, int rows_per_block = RB) {
-    const int nrb = (R + rows_per_block - 1) / rows_per_block;
+inline int row_groups(int R, int column_blocks) {
+    const int nrb = (R + RB - 1) / RB;
     int gq = (256 + column_blocks - 1) / column_blocks;     // ~ one workgroup per CU (LDS holds one weight slice per CU)
     if (gq > nrb) gq = nrb;
     // even out the row blocks per workgroup: with 330 blocks on 256 groups 74 workgroups would do two and set the pace
@@ -1311,10 +1126,13 @@ extern "C" int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* 
                                    void* stream) {
     if (bad_dims(R, H) || (h == nullptr) != (c == nullptr)) return -1;
     const int ncb = (H + UB - 1) / UB;
-    if (gate_rows32(R)) {
-        const size_t lds32 = ((size_t)(4 * UB + RB2) * lds_stride(h ? 2 * H : H) + 4 * RB2 * (UB + 4)) * sizeof(float);
-        LAUNCH_BIG_LDS(lstm_gate_fwd32_kernel, dim3(row_groups(R, ncb, RB2), ncb), lds32, stream, q, h, c, Wih, Whh, bsum, bsum2,
-                       gates, h_out, c_out, R, H);
+    if (gate_ws(R)) {
+        const size_t ldsw = ((size_t)(4 * UB + 2 * RB) * lds_stride(h ? 2 * H : H) + 2 * 4 * RB * (UB + 4)) * sizeof(float);
+        if (ldsw > 156 * 1024) return -1;
+        if (int e_ = mmdfn_allow_big_lds(lstm_gate_fwd_ws_kernel)) return e_;
+        hipLaunchKernelGGL(lstm_gate_fwd_ws_kernel, dim3(row_groups(R, ncb), ncb), dim3(512), ldsw, (hipStream_t)stream, q, h, c, Wih,
+                           Whh, bsum, bsum2, gates, h_out, c_out, R, H);
+        MMDFN_CHECK_LAUNCH();
         return 0;
     }
     const size_t lds = ((size_t)(4 * UB + 2 * RB) * lds_stride(h ? 2 * H : H) + 4 * RB * (UB + 4)) * sizeof(float);
@@ -1355,26 +1173,6 @@ extern "C" int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, cons
         hipLaunchKernelGGL(lstm_gate_bwd_ws_kernel<0>, dim3(row_groups(R, ncb), ncb), dim3(512), ldsw, (hipStream_t)stream, gates,
                            c_prev, c_new, dh_a, dh_b, dc_next, Wih, Whh, dres, dG, dc_prev, dq, dh_prev, R, H, has_h, lddres);
         MMDFN_CHECK_LAUNCH();
-        return 0;
-    }
-    if (gate_rows32(R)) {
-        const size_t lds32 = (size_t)(CBW + RB2) * lds_stride(4 * H) * sizeof(float);
-#ifdef MMDFN_TUNING
-#define GB32_ABL(A_)                                                                                                        \
-    case A_:                                                                                                                \
-        LAUNCH_BIG_LDS(lstm_gate_bwd32_kernel<A_>, dim3(row_groups(R, ncb, RB2), ncb), lds32, stream, gates, c_prev, c_new, \
-                       dh_a, dh_b, dc_next, Wih, Whh, dres, dG, dc_prev, dq, dh_prev, R, H, has_h, lddres);                 \
-        return 0;
-        if (const char* e = getenv("MMDFN_GATE_ABL")) {
-            switch (atoi(e)) {
-                GB32_ABL(1) GB32_ABL(2) GB32_ABL(4) GB32_ABL(8) GB32_ABL(3) GB32_ABL(6) GB32_ABL(7) GB32_ABL(15) GB32_ABL(12) GB32_ABL(14)
-                default: break;
-            }
-        }
-#undef GB32_ABL
-#endif
-        LAUNCH_BIG_LDS(lstm_gate_bwd32_kernel<0>, dim3(row_groups(R, ncb, RB2), ncb), lds32, stream, gates, c_prev, c_new, dh_a, dh_b,
-                       dc_next, Wih, Whh, dres, dG, dc_prev, dq, dh_prev, R, H, has_h, lddres);
         return 0;
     }
     const size_t lds = (size_t)(CBW + 2 * RB) * lds_stride(4 * H) * sizeof(float);

@@ -533,7 +533,7 @@ def test_gcn_input_stage_kernels(R, F, H, masked, residue):
 
 @pytest.mark.parametrize("R,H,first", [(37, 100, False), (37, 100, True), (600, 36, False), (3, 4, True), (2000, 96, False),
                                        (5280, 100, False),
-                                       # from 4 096 rows on the 32-row-block forms run (ragged last block, first layer, narrow H)
+                                       # larger launches (ragged last block, first layer, narrow H, BASELINE cfg5 rows)
                                        (4097, 100, False), (4100, 100, True), (4111, 36, False), (24576, 100, False)])
 def test_lstm_gate_kernels(R, H, first):
     from mm_dfn_amd import _hip

@@ -1,4 +1,4 @@
-"""Compile-time timing ablations of the 32-row and the producer / consumer K8 backward kernels (tuning build, MMDFN_GATE_ABL bits: 1 no MFMA, 2 no operand
+"""Compile-time timing ablations of the producer / consumer K8 backward kernel (tuning build, MMDFN_GATE_ABL bits: 1 no MFMA, 2 no operand
 loads, 4 no gate math, 8 no result stores) at R rows, H = 100.      python tools/ablate_gate_bwd.py [R]"""
 import os, sys
 os.environ["MMDFN_TUNING_LIB"] = "1"
@@ -26,9 +26,8 @@ def gtime(fn, iters=20):
     e0.record(); g.replay(); g.replay(); e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / (2 * iters) * 1e3
 os.environ["MMDFN_GATE_WS"] = "0"
-os.environ["MMDFN_GATE32"] = "0"
-print("R = %d: 16-row kernel %.1f us" % (R, gtime(run)))
-for name, env in (("32-row kernel", dict(MMDFN_GATE32="1", MMDFN_GATE_WS="0")), ("producer / consumer kernel", dict(MMDFN_GATE_WS="1"))):
+print("R = %d: four-wave kernel %.1f us" % (R, gtime(run)))
+for name, env in (("producer / consumer kernel", dict(MMDFN_GATE_WS="1")),):
     os.environ.update(env)
     print(" ", name)
     for abl in (0, 1, 2, 4, 8, 3, 6, 12, 7, 14, 15):
