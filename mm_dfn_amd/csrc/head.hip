@@ -38,10 +38,14 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     {   // batches of 8 independent 16-byte loads per thread (one load in flight per thread would pay the latency 6x)
         const int total = C * W / 4;
         for (int base = threadIdx.x; base < total; base += 256 * 8) {
+            // (unconditional loads from a clamped index: a guarded load into v[e] makes hipcc keep v[] in scratch and wait
+            // for every load before the next -- 8 serial round trips and a private segment per launch, 15 us for this kernel)
             float4 v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (base + 256 * e < total) v[e] = reinterpret_cast<const float4*>(Wt)[base + 256 * e];
+            for (int e = 0; e < 8; ++e) {
+                const int i = base + 256 * e;
+                v[e] = reinterpret_cast<const float4*>(Wt)[i < total ? i : total - 1];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (base + 256 * e < total) reinterpret_cast<float4*>(sW)[base + 256 * e] = v[e];
@@ -54,18 +58,33 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         float acc[HC_MAX];
 #pragma unroll
         for (int c = 0; c < HC_MAX; ++c) acc[c] = 0.f;
-        for (int j = lane; j < W4; j += 64) {
-            float4 z = *reinterpret_cast<const float4*>(Fm + feat_off(row, 4 * j, ldf, split, N));
-            if (mask) {
-                const float4 m = *reinterpret_cast<const float4*>(mask + row * W + 4 * j);
-                z.x *= m.x * mscale; z.y *= m.y * mscale; z.z *= m.z * mscale; z.w *= m.w * mscale;
-            }
-            z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f);
+        // all of the row's 16-byte loads (features and keep flags) go out before the first use: one memory round trip per
+        // row instead of one per 64-lane slice (W = 900: 4 slices; the kernel is a 19 MB stream, 16.5 -> 8 us at N = 5 280)
+        constexpr int NJ = 4;
+        for (int j0 = 0; j0 < W4; j0 += 64 * NJ) {
+            float4 zv[NJ], mv[NJ];
 #pragma unroll
-            for (int c = 0; c < HC_MAX; ++c) {
-                if (c < C) {
-                    const float4 wv = *reinterpret_cast<const float4*>(sW + c * W + 4 * j);
-                    acc[c] += z.x * wv.x + z.y * wv.y + z.z * wv.z + z.w * wv.w;
+            for (int u = 0; u < NJ; ++u) {
+                const int j = j0 + 64 * u + lane;
+                zv[u] = (j < W4) ? *reinterpret_cast<const float4*>(Fm + feat_off(row, 4 * j, ldf, split, N)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mask) mv[u] = (j < W4) ? *reinterpret_cast<const float4*>(mask + row * W + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NJ; ++u) {
+                const int j = j0 + 64 * u + lane;
+                if (j >= W4) continue;
+                float4 z = zv[u];
+                if (mask) {
+                    const float4 m = mv[u];
+                    z.x *= m.x * mscale; z.y *= m.y * mscale; z.z *= m.z * mscale; z.w *= m.w * mscale;
+                }
+                z.x = fmaxf(z.x, 0.f); z.y = fmaxf(z.y, 0.f); z.z = fmaxf(z.z, 0.f); z.w = fmaxf(z.w, 0.f);
+#pragma unroll
+                for (int c = 0; c < HC_MAX; ++c) {
+                    if (c < C) {
+                        const float4 wv = *reinterpret_cast<const float4*>(sW + c * W + 4 * j);
+                        acc[c] += z.x * wv.x + z.y * wv.y + z.z * wv.z + z.w * wv.w;
+                    }
                 }
             }
         }
@@ -106,8 +125,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         float4 v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int i = base + 256 * e, c = i / cols4, j = i - c * cols4;
-            if (i < C * cols4) v[e] = *reinterpret_cast<const float4*>(Wt + (int64_t)c * W + col0 + 4 * j);
+            const int i0 = base + 256 * e, i = i0 < C * cols4 ? i0 : C * cols4 - 1, c = i / cols4, j = i - c * cols4;
+            v[e] = *reinterpret_cast<const float4*>(Wt + (int64_t)c * W + col0 + 4 * j);      // (clamped, unconditional: see head_fwd)
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -125,31 +144,52 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int s = 0; s < HB_COLS / 256; ++s) dw[c][s] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
-        float g[HC_MAX];
-        float sd = 0.f;
+    // A wave walks ~10 rows (5 280 rows on 512 waves) and every row is one memory round trip, so the NEXT row's operands are
+    // requested before the current row is worked on (20.7 -> 12 us at N = 5 280)
+    constexpr int NSL = HB_COLS / 256;
+    const int64_t rstep = (int64_t)gridDim.x * 4;
+    float gq[HC_MAX], lq[HC_MAX];
+    float4 zq[NSL], mq[NSL];
+    auto fetch = [&](int64_t row) {
 #pragma unroll
         for (int c = 0; c < HC_MAX; ++c) {
-            g[c] = (c < C) ? dlogp[row * C + c] : 0.f;
-            sd += g[c];
+            gq[c] = (c < C && row < N) ? dlogp[row * C + c] : 0.f;
+            lq[c] = (c < C && row < N) ? logp[row * C + c] : 0.f;
         }
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            const int j = lane + 64 * s;
+            const bool ok = j < cols4 && row < N;
+            zq[s] = ok ? *reinterpret_cast<const float4*>(Fm + feat_off(row, col0 + 4 * j, ldf, split, N)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            mq[s] = (ok && mask) ? *reinterpret_cast<const float4*>(mask + row * W + col0 + 4 * j) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+    };
+    fetch((int64_t)blockIdx.x * 4 + w);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += rstep) {
+        float g[HC_MAX], lp[HC_MAX];
+        float4 zc[NSL], mc[NSL];
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c) { g[c] = gq[c]; lp[c] = lq[c]; }
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) { zc[s] = zq[s]; mc[s] = mq[s]; }
+        fetch(row + rstep);
+        float sd = 0.f;
+#pragma unroll
+        for (int c = 0; c < HC_MAX; ++c) sd += g[c];
 #pragma unroll
         for (int c = 0; c < HC_MAX; ++c) {
             if (c < C) {
-                g[c] -= expf(logp[row * C + c]) * sd;
+                g[c] -= expf(lp[c]) * sd;
                 db[c] += g[c];                        // (every lane holds the same value; lane 0 reports it)
             }
         }
 #pragma unroll
-        for (int s = 0; s < HB_COLS / 256; ++s) {
+        for (int s = 0; s < NSL; ++s) {
             const int j = lane + 64 * s;
             if (j >= cols4) continue;
-            float4 z = *reinterpret_cast<const float4*>(Fm + feat_off(row, col0 + 4 * j, ldf, split, N));
-            float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (mask) {
-                m = *reinterpret_cast<const float4*>(mask + row * W + col0 + 4 * j);
-                m.x *= mscale; m.y *= mscale; m.z *= mscale; m.w *= mscale;
-            }
+            float4 z = zc[s];
+            float4 m = mc[s];
+            if (mask) { m.x *= mscale; m.y *= mscale; m.z *= mscale; m.w *= mscale; }
             z.x = fmaxf(z.x * m.x, 0.f); z.y = fmaxf(z.y * m.y, 0.f); z.z = fmaxf(z.z * m.z, 0.f); z.w = fmaxf(z.w * m.w, 0.f);
             float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
