@@ -809,16 +809,27 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
     const int nyb = gridDim.y, yb = blockIdx.y;
     const bool wr_i = (0 % nyb) == yb, wr_f = (1 % nyb) == yb, wr_g = (2 % nyb) == yb, wr_o = (3 % nyb) == yb, wr_c = yb == nyb - 1;
     const int H4 = H >> 2;
-    // ---- prologue: all 512 threads park the weight slice (k-contiguous rows sW[n][k] from the (K, H) parameter)
+    // ---- prologue: all 512 threads park the weight slice (k-contiguous rows sW[n][k] from the (K, H) parameter); all of a
+    // thread's loads (<= 13 slots) go out before its first LDS store
     {
         const float* Wsrc = is_dh ? Whh : Wih;
         const int inner = ncols >> 2;                  // 16-byte slots per source row (k)
         const int total = K * inner;
-        for (int i = threadIdx.x; i < total; i += 512) {
+        constexpr int NW2 = 13;                        // 400 x 16 / 512
+        float4 v[NW2];
+#pragma unroll
+        for (int e = 0; e < NW2; ++e) {
+            const int i0 = threadIdx.x + 512 * e, i = i0 < total ? i0 : total - 1;
             const int r = i / inner, j = i - r * inner;
-            const float4 v = ld4(Wsrc + (int64_t)r * H + n0 + 4 * j);
+            v[e] = ld4(Wsrc + (int64_t)r * H + n0 + 4 * j);
+        }
+#pragma unroll
+        for (int e = 0; e < NW2; ++e) {
+            const int i = threadIdx.x + 512 * e;
+            if (i >= total) continue;
+            const int r = i / inner, j = i - r * inner;
             float* d = sW + (4 * j) * ldw + r;
-            d[0] = v.x; d[ldw] = v.y; d[2 * ldw] = v.z; d[3 * ldw] = v.w;
+            d[0] = v[e].x; d[ldw] = v[e].y; d[2 * ldw] = v[e].z; d[3 * ldw] = v[e].w;
         }
         const int np4 = (ldw - K) >> 2;                // zero pads of the weight rows and of both A buffers; missing columns
         for (int i = threadIdx.x; i < ncols * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sW + r * ldw + K + 4 * j, zero4()); }
@@ -958,16 +969,30 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
     const int H4 = H >> 2;
     const int tid = threadIdx.x & 255;
     const bool producer = threadIdx.x >= 256;
-    // ---- prologue (all 512 threads): weight rows (gate, ul) <- [W_ih | W_hh] row gate * H + u0 + ul; missing units: zeros
+    // ---- prologue (all 512 threads): weight rows (gate, ul) <- [W_ih | W_hh] row gate * H + u0 + ul; missing units: zeros.
+    // Every load of the slice goes out before the first LDS store (7 + 7 slots per thread, unconditional loads from clamped
+    // addresses: one memory round trip for the slice, not one per slot)
     {
         const int total = 4 * UB * H4;
-        for (int i = threadIdx.x; i < total; i += 512) {
+        constexpr int NW2 = 7;                             // 4 gates x 32 units x (H / 4 <= 25) / 512 threads
+        float4 vi[NW2], vh[NW2];
+#pragma unroll
+        for (int e = 0; e < NW2; ++e) {
+            const int i0 = threadIdx.x + 512 * e, i = i0 < total ? i0 : total - 1;
             const int rowl = i / H4, k = (i - rowl * H4) * 4;
             const int gate = rowl / UB, ul = rowl - gate * UB;
-            const bool ok = ul < nu;
-            const int64_t src = (int64_t)(gate * H + u0 + ul) * H + k;
-            st4(sW + rowl * ldw + k, ok ? ld4(Wih + src) : zero4());
-            if (h) st4(sW + rowl * ldw + H + k, ok ? ld4(Whh + src) : zero4());
+            const int64_t src = (int64_t)(gate * H + u0 + (ul < nu ? ul : nu - 1)) * H + k;
+            vi[e] = ld4(Wih + src);
+            vh[e] = h ? ld4(Whh + src) : zero4();
+        }
+#pragma unroll
+        for (int e = 0; e < NW2; ++e) {
+            const int i = threadIdx.x + 512 * e;
+            if (i >= total) continue;
+            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            const int ul = rowl - (rowl / UB) * UB;
+            st4(sW + rowl * ldw + k, ul < nu ? vi[e] : zero4());
+            if (h) st4(sW + rowl * ldw + H + k, ul < nu ? vh[e] : zero4());
         }
         const int np4 = (ldw - K) >> 2;
         for (int i = threadIdx.x; i < 4 * UB * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sW + r * ldw + K + 4 * j, zero4()); }
