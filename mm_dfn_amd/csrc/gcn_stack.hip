@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
             const int r = i / F4, k = (i - r * F4) * 4, row = rb * RB + r;
             const bool ok = i < RB * F4 && row < R;
             rx[s] = ok ? ld4(x + (int64_t)row * F + k) : zero4();
-            rm[s] = (ok && mx) ? scl4(ld4(mx + (int64_t)row * F + k), ms) : one4();
+            rm[s] = (ok && mx) ? ld4(mx + (int64_t)row * F + k) : one4();      // raw flags: arithmetic on a value just loaded would wait for it here
         }
     };
     auto park = [&](int rb, float* dst) {
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
             const int i = threadIdx.x + 256 * s;
             if (i >= RB * F4) continue;
             const int r = i / F4, k = (i - r * F4) * 4, row = rb * RB + r;
-            const float4 v = mul4(rx[s], rm[s]);
+            const float4 v = mul4(rx[s], scl4(rm[s], mx ? ms : 1.0f));
             st4(dst + r * ldw + k, v);
             if (row < R) st4(xd + (int64_t)row * ldxd + k, v);
         }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
             const int i = threadIdx.x + 256 * s;
             const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
-            em[s] = (ok && m0) ? scl4(ld4(m0 + (int64_t)row * H + n), ms) : one4();
+            em[s] = (ok && m0) ? ld4(m0 + (int64_t)row * H + n) : one4();
             eb[s] = (ok && b0) ? ld4(b0 + n) : zero4();
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
             float4 v = add4(ld4(sP + r * ldp + n), eb[s]);
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             st4(h0 + (int64_t)row * H + n, v);
-            st4(cur0 + (int64_t)row * H + n, mul4(v, em[s]));
+            st4(cur0 + (int64_t)row * H + n, mul4(v, scl4(em[s], m0 ? ms : 1.0f)));
         }
         if (nxt < nrb) park(nxt, sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
             const bool ok = i < RB * H4 && row < R;
             const int64_t o = (int64_t)row * H + k;
             rd[s] = (ok && dcur0) ? ld4(dcur0 + o) : zero4();
-            rmk[s] = (ok && m0) ? scl4(ld4(m0 + o), ms) : one4();
+            rmk[s] = (ok && m0) ? ld4(m0 + o) : one4();
             rdh[s] = (ok && dh0) ? ld4(dh0 + o) : zero4();
             rh0[s] = ok ? ld4(h0 + o) : zero4();
         }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
             const int i = threadIdx.x + 256 * s;
             if (i >= RB * H4) continue;
             const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
-            float4 v = add4(mul4(rd[s], rmk[s]), rdh[s]);
+            float4 v = add4(mul4(rd[s], scl4(rmk[s], m0 ? ms : 1.0f)), rdh[s]);
             v.x = rh0[s].x > 0.f ? v.x : 0.f; v.y = rh0[s].y > 0.f ? v.y : 0.f;
             v.z = rh0[s].z > 0.f ? v.z : 0.f; v.w = rh0[s].w > 0.f ? v.w : 0.f;
             st4(dst + r * ldw + k, v);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
             const int r = i / F4, n = (i - r * F4) * 4, row = rb * RB + r;
             const bool ok = i < RB * F4 && row < R;
             ed[s] = (ok && dxd) ? ld4(dxd + (int64_t)row * lddxd + n) : zero4();
-            em[s] = (ok && mx) ? scl4(ld4(mx + (int64_t)row * F + n), ms) : one4();
+            em[s] = (ok && mx) ? ld4(mx + (int64_t)row * F + n) : one4();
         }
         f32x4 acc[4];
 #pragma unroll
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
             const int i = threadIdx.x + 256 * s;
             const int r = i / F4, n = (i - r * F4) * 4, row = rb * RB + r;
             if (i >= RB * F4 || row >= R) continue;
-            st4(dx + (int64_t)row * F + n, mul4(add4(ld4(sP + r * ldp + n), ed[s]), em[s]));
+            st4(dx + (int64_t)row * F + n, mul4(add4(ld4(sP + r * ldp + n), ed[s]), scl4(em[s], mx ? ms : 1.0f)));
         }
         if (nxt < nrb) park(nxt, sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
             const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             eq[s] = (ok && q) ? ld4(q + (int64_t)row * H + n) : zero4();
-            em[s] = (ok && m) ? scl4(ld4(m + (int64_t)row * H + n), ms) : one4();
+            em[s] = (ok && m) ? ld4(m + (int64_t)row * H + n) : one4();
         }
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         contract<2>(acc, wrow0, A, ldw, sW, ldw, K);
@@ -418,12 +418,13 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
             const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
             if (i >= RB * H4 || row >= R) continue;
             const float4 p = ld4(sP + r * ldp + n), vh = ld4(A + r * ldw + n), v0 = ld4(A + r * ldw + H + n);
+            const float4 ems = scl4(em[s], m ? ms : 1.0f);
             float4 o, gm;
 #define K7F(F_)                                                                                            \
     {                                                                                                      \
         const float pre = theta * p.F_ + (1.0f - theta) * ((1.0f - alpha) * vh.F_ + alpha * v0.F_);       \
-        o.F_ = fmaxf(pre, 0.f) * em[s].F_ + eq[s].F_;                                                      \
-        gm.F_ = pre > 0.f ? em[s].F_ : 0.f;                                                                \
+        o.F_ = fmaxf(pre, 0.f) * ems.F_ + eq[s].F_;                                                        \
+        gm.F_ = pre > 0.f ? ems.F_ : 0.f;                                                                  \
     }
             K7F(x) K7F(y) K7F(z) K7F(w)
 #undef K7F
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
     const bool writer = blockIdx.y == 0;
     const int H4 = H >> 2;
     constexpr int NS = 2;                              // 16 * H / 4 / 256 <= 2 for H <= 128
-    float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdc[NS];
+    float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdh2[NS], rdc[NS];
     auto issue = [&](int rb) {
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
@@ -705,9 +706,8 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
             rgo[s_] = ok ? ld4(gr + 3 * H) : zero4();
             rcn[s_] = ok ? ld4(c_new + o) : zero4();
             rcp[s_] = (ok && c_prev) ? ld4(c_prev + o) : zero4();
-            float4 d = (ok && dh_a) ? ld4(dh_a + o) : zero4();
-            if (ok && dh_b) d = add4(d, ld4(dh_b + o));
-            rdh[s_] = d;
+            rdh[s_] = (ok && dh_a) ? ld4(dh_a + o) : zero4();
+            rdh2[s_] = (ok && dh_b) ? ld4(dh_b + o) : zero4();          // (added at use: an add here would wait for both loads)
             rdc[s_] = (ok && dc_next) ? ld4(dc_next + o) : zero4();
         }
     };
@@ -722,8 +722,9 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
     {                                                                               \
         const float gi = rgi[s_].F, gf = rgf[s_].F, gg = rgg[s_].F, go = rgo[s_].F; \
         const float tc = tanhf_(rcn[s_].F);                                         \
-        const float dc = rdc[s_].F + rdh[s_].F * go * (1.0f - tc * tc);             \
-        dO.F = rdh[s_].F * tc * go * (1.0f - go);                                   \
+        const float dhv = rdh[s_].F + rdh2[s_].F;                                   \
+        const float dc = rdc[s_].F + dhv * go * (1.0f - tc * tc);                   \
+        dO.F = dhv * tc * go * (1.0f - go);                                         \
         di.F = dc * gg * gi * (1.0f - gi);                                          \
         df.F = dc * rcp[s_].F * gf * (1.0f - gf);                                   \
         dg.F = dc * gi * (1.0f - gg * gg);                                          \
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
         for (int i = threadIdx.x; i < 2 * RB * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sA + r * ldw + K + 4 * j, zero4()); }
     }
     constexpr int NS = 2;                              // 16 * H / 4 / 256 <= 2 for H <= 128
-    float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdc[NS];
+    float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdh2[NS], rdc[NS];
     auto issue = [&](int rb) {
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
@@ -852,9 +853,8 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
             rgo[s_] = ok ? ld4(gr + 3 * H) : zero4();
             rcn[s_] = ok ? ld4(c_new + o) : zero4();
             rcp[s_] = (ok && c_prev) ? ld4(c_prev + o) : zero4();
-            float4 d = (ok && dh_a) ? ld4(dh_a + o) : zero4();
-            if (ok && dh_b) d = add4(d, ld4(dh_b + o));
-            rdh[s_] = d;
+            rdh[s_] = (ok && dh_a) ? ld4(dh_a + o) : zero4();
+            rdh2[s_] = (ok && dh_b) ? ld4(dh_b + o) : zero4();          // (added at use: an add here would wait for both loads)
             rdc[s_] = (ok && dc_next) ? ld4(dc_next + o) : zero4();
         }
     };
@@ -869,8 +869,9 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
     {                                                                               \
         const float gi = rgi[s_].F, gf = rgf[s_].F, gg = rgg[s_].F, go = rgo[s_].F; \
         const float tc = tanhf_(rcn[s_].F);                                         \
-        const float dc = rdc[s_].F + rdh[s_].F * go * (1.0f - tc * tc);             \
-        dO.F = rdh[s_].F * tc * go * (1.0f - go);                                   \
+        const float dhv = rdh[s_].F + rdh2[s_].F;                                   \
+        const float dc = rdc[s_].F + dhv * go * (1.0f - tc * tc);                   \
+        dO.F = dhv * tc * go * (1.0f - go);                                         \
         di.F = dc * gg * gi * (1.0f - gi);                                          \
         df.F = dc * rcp[s_].F * gf * (1.0f - gf);                                   \
         dg.F = dc * gi * (1.0f - gg * gg);                                          \
