@@ -62,6 +62,7 @@ SIGNATURES = {
     "mmdfn_party_combine": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mmdfn_mask_scale": [_I, _P, _P, _P, _P, _F, _P],
+    "mmdfn_keep_flags": [_P, _L, _F, _P, _P],
     "mmdfn_colsum_workspace": [_I],
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }

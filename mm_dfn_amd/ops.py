@@ -1294,12 +1294,44 @@ def keep_scale(p):
     return 0.0 if p >= 1.0 else 1.0 / (1.0 - p)
 
 
+_FLAG_STATE = {}       # device index -> [device state (seed, offset, workgroup counter), host mirror (seed, offset)]
+
+
+def draw_flags(n, p, device):
+    """n (a multiple of 4) fresh fp32 keep flags from the package's Philox kernel (csrc/encoder_glue.hip).  The generator state
+    lives on the device and every launch advances it, so replays of a captured graph draw new flags.  In eager mode the state
+    follows torch's CUDA generator: it is re-seeded from (initial_seed, offset) whenever those differ from what this function
+    left behind (torch.manual_seed, a restored RNG state, other random ops in between), and the generator's offset is advanced
+    by the counters consumed -- `torch.manual_seed(s)` reproduces a run exactly as it does for torch's own dropout."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _FLAG_STATE.get(idx)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None:
+        if capturing:
+            raise RuntimeError("the first dropout draw on a device cannot happen inside a stream capture (run one eager step first)")
+        ent = _FLAG_STATE[idx] = [torch.zeros(4, dtype=torch.int64, device=device), None]
+    n8 = (n + 7) // 8                      # Philox counters one launch consumes (8 flags each)
+    if not capturing:
+        gen = torch.cuda.default_generators[idx]
+        now = (int(gen.initial_seed()), int(gen.get_offset()))
+        if ent[1] != now:
+            seed = now[0] - (1 << 64) if now[0] >= (1 << 63) else now[0]
+            ent[0].copy_(torch.tensor([seed, now[1], 0, 0], dtype=torch.int64), non_blocking=False)
+        # leave torch's generator behind the counters this launch consumes (its offset moves in multiples of 4)
+        gen.set_offset(now[1] + 4 * ((n8 + 3) // 4))
+        ent[1] = (now[0], int(gen.get_offset()))
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    _hip.check(_hip.lib().mmdfn_keep_flags(_hip.ptr(out), n, float(1.0 - p), _hip.ptr(ent[0]), _hip.stream()), "mmdfn_keep_flags")
+    return out
+
+
 def keep_flags(n, p, device):
     """n fp32 keep flags (1 with probability 1 - p), 16-byte aligned."""
     n = int(n)
     scope = _FLAG_SCOPE
     if scope is None:
-        return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(1.0 - p)
+        return draw_flags((n + 3) & ~3, p, device)[:n]
     k = (device, float(p))
     ent = scope.bufs.get(k)
     if ent is None:
@@ -1307,7 +1339,7 @@ def keep_flags(n, p, device):
     n4 = (n + 3) & ~3
     if ent[0] is None or ent[1] + n4 > ent[0].numel():
         want = max(n4, _FLAG_HINT.get((scope.key,) + k, 0) - ent[2])
-        ent[0] = torch.empty(want, dtype=torch.float32, device=device).bernoulli_(1.0 - p)
+        ent[0] = draw_flags(want, p, device)
         ent[1] = 0
     out = ent[0][ent[1]:ent[1] + n]
     ent[1] += n4

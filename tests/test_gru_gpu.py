@@ -285,3 +285,45 @@ def test_direction_weight_pairs_become_one_stacked_operand_without_a_copy():
     assert rel_err(x2.grad, xg) < 1e-6
     for k, p in g2.named_parameters():
         assert rel_err(p.grad, grads[k]) < 1e-6, k
+
+
+def test_keep_flag_generator_statistics_seeding_and_graph_replay():
+    """ops.draw_flags (csrc/encoder_glue.hip, Philox4x32-10 with device-resident state): the keep rate, independence of
+    consecutive draws, torch.manual_seed reproducibility (also with another torch random op in between), the degenerate rates,
+    and fresh flags at every replay of a captured graph."""
+    from mm_dfn_amd import ops
+    n = 1 << 20
+    torch.manual_seed(1234)
+    a = ops.draw_flags(n, 0.3, DEV)
+    b = ops.draw_flags(n, 0.3, DEV)
+    assert set(torch.unique(a).tolist()) == {0.0, 1.0}
+    assert abs(float(a.mean()) - 0.7) < 3e-3 and abs(float(b.mean()) - 0.7) < 3e-3
+    assert abs(float((a * b).mean()) - 0.49) < 3e-3                     # consecutive draws are independent
+    assert abs(float((a[:-1] * a[1:]).mean()) - 0.49) < 3e-3           # and so are neighbours
+    torch.manual_seed(1234)
+    a2 = ops.draw_flags(n, 0.3, DEV)
+    r1 = torch.rand(5, device=DEV)
+    b2 = ops.draw_flags(n, 0.3, DEV)
+    assert torch.equal(a, a2) and not torch.equal(b, b2)               # the torch.rand in between moved the stream
+    torch.manual_seed(1234)
+    ops.draw_flags(n, 0.3, DEV)
+    assert torch.equal(torch.rand(5, device=DEV), r1)
+    assert torch.equal(ops.draw_flags(n, 0.3, DEV), b2)
+    assert float(ops.draw_flags(64, 0.0, DEV).min()) == 1.0 and float(ops.draw_flags(64, 1.0, DEV).max()) == 0.0
+    # captured: the state advances on the device, replay after replay
+    out = torch.empty(4096, device=DEV)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.draw_flags(4096, 0.5, DEV)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out.copy_(ops.draw_flags(4096, 0.5, DEV))
+    torch.cuda.current_stream().wait_stream(s)
+    seen = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append(out.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    assert all(abs(float(x.mean()) - 0.5) < 0.05 for x in seen)
