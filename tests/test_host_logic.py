@@ -170,11 +170,13 @@ def test_focal_loss_alpha_table_must_cover_the_classes():
     assert torch.isfinite(f(lp, torch.tensor([0, 1, 1, 0])))
 
 
-def test_flag_pool_shares_one_draw_per_step():
+def test_flag_pool_shares_one_draw_per_step(monkeypatch):
     """ops.keep_flags inside a flag_pool scope: the first step draws per request, later steps with the same key draw once
-    and hand out disjoint 16-byte aligned slices; outside a scope every request is its own draw."""
+    and hand out disjoint 16-byte aligned slices; outside a scope every request is its own draw.  (Host logic only: the draw
+    itself -- the device's Philox kernel, tests/test_gru_gpu.py -- is replaced by a CPU stand-in here.)"""
     import torch
     from mm_dfn_amd import ops
+    monkeypatch.setattr(ops, "draw_flags", lambda n, p, device: torch.empty(n, device=device).bernoulli_(1.0 - p))
     dev = torch.device("cpu")
     a = ops.keep_flags(10, 0.5, dev)
     assert a.shape == (10,) and set(a.unique().tolist()) <= {0.0, 1.0}
