@@ -185,7 +185,7 @@ int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* 
 /* Dropout keep flags (replaces the generator launch behind F.dropout / nn.Dropout / nn.GRU(dropout=p), model.py:866,868,1328,
  * model_GCN.py:453-470): out[i] = 1.0f with probability `keep`, else 0.0f, n % 4 == 0, 16-byte aligned; Philox4x32-10 keyed by
  * state[0] (seed) at counter state[1] + i / 8 (16 random bits per flag: the rate is exact to 2^-16).  `state`: three 64-bit words
- * in DEVICE memory (seed, offset, 0); the launch adds ceil(n / 8) to the offset itself, so replays of a captured graph draw fresh flags. */
+ * in DEVICE memory (seed, offset, 0); the launch adds ceil(n / 8) rounded up to a multiple of 64 to the offset itself, so replays of a captured graph draw fresh flags. */
 int mmdfn_keep_flags(float* out, int64_t n, float keep, void* state, void* stream);
 int64_t mmdfn_colsum_workspace(int H);
 int mmdfn_colsum(const float* A, int64_t R, int H, int lda, float* out, float* workspace, void* stream);

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(1024) void keep_flags_kernel(float* __restrict__ ou
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
     // one Philox call = 128 random bits = EIGHT flags (16 bits each: the keep rate is exact to 2^-16, the generator is the
     // multiplier-bound part of the kernel: 19 v_mad_u64_u32 per call)
+    // (whole waves: n8 is a multiple of 64 -- the launcher rounds the counter range up, the slot guards below cut the tail)
     for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 1024) {
         const unsigned long long c = offset + (unsigned long long)i;
         const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0u, 0u), key);
@@ -298,8 +299,11 @@ __global__ __launch_bounds__(1024) void keep_flags_kernel(float* __restrict__ ou
         v.z = (all || (r.y & 0xFFFFu) < threshold) ? 1.f : 0.f; v.w = (all || (r.y >> 16) < threshold) ? 1.f : 0.f;
         u.x = (all || (r.z & 0xFFFFu) < threshold) ? 1.f : 0.f; u.y = (all || (r.z >> 16) < threshold) ? 1.f : 0.f;
         u.z = (all || (r.w & 0xFFFFu) < threshold) ? 1.f : 0.f; u.w = (all || (r.w >> 16) < threshold) ? 1.f : 0.f;
-        *reinterpret_cast<float4*>(out + 8 * i) = v;
-        if (2 * i + 1 < n4) *reinterpret_cast<float4*>(out + 8 * i + 4) = u;
+        // the wave's 128 float4 slots as two contiguous 1 KB stores (which flag lands where is immaterial)
+        const int lane = threadIdx.x & 63;
+        const int64_t sa = 2 * (i - lane) + lane, sb = sa + 64;
+        if (sa < n4) *reinterpret_cast<float4*>(out + 4 * sa) = v;
+        if (sb < n4) *reinterpret_cast<float4*>(out + 4 * sb) = u;
     }
     __shared__ int last_s;
     __syncthreads();
@@ -416,7 +420,7 @@ extern "C" int mmdfn_colsum(const float* A, int64_t R, int H, int lda, float* ou
 
 extern "C" int mmdfn_keep_flags(float* out, int64_t n, float keep, void* state, void* stream) {
     if (n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || state == nullptr || !(keep >= 0.f) || keep > 1.f) return -1;
-    const int64_t n4 = n >> 2, n8 = (n4 + 1) >> 1;
+    const int64_t n4 = n >> 2, n8 = (((n4 + 1) >> 1) + 63) & ~(int64_t)63;      // Philox counters consumed: whole waves
     // keep = 1: every flag is 1 whatever the draw
     const int all = keep >= 1.f ? 1 : 0;
     const uint32_t threshold = all ? 65536u : (uint32_t)((double)keep * 65536.0 + 0.5);

@@ -1311,7 +1311,7 @@ def draw_flags(n, p, device):
         if capturing:
             raise RuntimeError("the first dropout draw on a device cannot happen inside a stream capture (run one eager step first)")
         ent = _FLAG_STATE[idx] = [torch.zeros(4, dtype=torch.int64, device=device), None]
-    n8 = (n + 7) // 8                      # Philox counters one launch consumes (8 flags each)
+    n8 = ((n + 7) // 8 + 63) // 64 * 64    # Philox counters one launch consumes (8 flags each, whole waves)
     if not capturing:
         gen = torch.cuda.default_generators[idx]
         now = (int(gen.initial_seed()), int(gen.get_offset()))
