@@ -60,18 +60,22 @@ __global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const floa
     const int kper = (L + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kper;
     const int k_hi = (k_lo + kper < L) ? k_lo + kper : L;
-    for (int idx = k_lo * per_k + tid; idx < k_hi * per_k; idx += 256) {
-        const int k = idx / per_k;
-        const int rem = idx - k * per_k;
-        const int m = rem / H4;
-        const int c4 = rem - m * H4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < cnt) v = *reinterpret_cast<const float4*>(X.p[m] + ((int64_t)sel[k] * B + b) * H + 4 * c4);
-        if (bias != nullptr) {   // rows gathered AFTER a bias-free projection: every row, padding included, gets the bias
-            const float4 bb = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    // thread -> fixed (modality, 16-byte column) slots, rows k in the inner loop: no integer division per element, the bias
+    // slice is loaded once per slot
+    for (int j = tid; j < per_k; j += 256) {
+        const int m = j / H4;
+        const int c4 = j - m * H4;
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias != nullptr) bb = *reinterpret_cast<const float4*>(bias + 4 * c4);   // rows gathered AFTER a bias-free projection: every row, padding included, gets the bias
+        const float* xm = X.p[m] + (int64_t)b * H + 4 * c4;
+        float* sm = S + (((int64_t)m * B + b) * P + p) * H + 4 * c4;
+#pragma unroll 4
+        for (int k = k_lo; k < k_hi; ++k) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < cnt) v = *reinterpret_cast<const float4*>(xm + (int64_t)sel[k] * B * H);
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            *reinterpret_cast<float4*>(sm + (int64_t)k * cols * H) = v;
         }
-        *reinterpret_cast<float4*>(S + ((int64_t)k * cols + ((int64_t)m * B + b) * P + p) * H + 4 * c4) = v;
     }
 }
 
