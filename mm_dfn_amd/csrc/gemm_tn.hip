@@ -389,8 +389,35 @@ extern "C" int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* 
 // In the batch form ~25 contractions share one launch, so no single one has to fill the chip: 8 splits each (~1000 rows
 // per split at the hot-path sizes) instead of 8-16 keeps as many workgroups in flight with half the slabs to write and to
 // reduce (cfg2 step 1.117 -> 1.109 ms; 4 or fewer splits lose again).
-static int batch_eff_splits(int R, int M, int N, int* rps_out) {
-    const int splits = tn_splits_for(R, M, N, 1000);
+// Rows per split of a BATCH: 1 000 at the dialogue-graph sizes (above); when the batch as a whole already holds many more
+// workgroups than that needs (BASELINE cfg5: 24 576-row segments, 15 000 workgroups of 16 chunks at 512 rows per split, 69
+// TFLOP/s), longer splits -- about 12 workgroups per CU in total, at most 4 096 rows -- amortise each workgroup's prologue and
+// write / reduce a quarter of the slabs.
+static int batch_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
+    double units = 0.0;                                  // sum over segments of output tiles x rows
+    for (int s = 0; s < nseg; ++s) {
+        const int o = out[s];
+        if (o < 0 || o >= nout) continue;
+        units += (double)(((M[o] + TM - 1) / TM) * ((N[o] + TN - 1) / TN)) * R[s];
+    }
+    double wgs = 3072.0;
+    int rt_max = 4096;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_TN_BATCH_WGS")) wgs = atof(e);
+    if (const char* e = getenv("MMDFN_TN_BATCH_RTMAX")) rt_max = atoi(e);
+#endif
+    int rt = (int)(units / wgs);
+    if (rt < 1000) rt = 1000;
+    if (rt > rt_max) rt = rt_max;
+    return rt;
+}
+
+static int batch_eff_splits(int R, int M, int N, int rows_target, int* rps_out) {
+    int splits = tn_splits_for(R, M, N, 1000);
+    if (rows_target > 1000) {
+        splits = (R + rows_target - 1) / rows_target;
+        if (splits < 1) splits = 1;
+    }
     const int rps = ((R + splits - 1) / splits + BR - 1) / BR * BR;
     if (rps_out) *rps_out = rps;
     return (R + rps - 1) / rps;
@@ -399,10 +426,11 @@ static int batch_eff_splits(int R, int M, int N, int* rps_out) {
 extern "C" int64_t mmdfn_gemm_tn_batch_workspace(int nseg, const int* R, const int* out, int nout, const int* M,
                                                  const int* N) {
     int64_t total = 0;
+    const int rt = batch_rows_target(nseg, R, out, nout, M, N);
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout) return -1;
-        total += (int64_t)batch_eff_splits(R[s], M[o], N[o], nullptr) * ((int64_t)M[o] * N[o] + M[o]);
+        total += (int64_t)batch_eff_splits(R[s], M[o], N[o], rt, nullptr) * ((int64_t)M[o] * N[o] + M[o]);
     }
     return total;
 }
@@ -416,6 +444,7 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     TnOuts oq;
     // pass 1: splits per output (its segments stack their slabs)
     int out_splits[TN_MAXOUT], seg_eff[TN_MAXSEG], seg_rps[TN_MAXSEG];
+    const int rt = batch_rows_target(nseg, R, out, nout, M, N);
     for (int o = 0; o < nout; ++o) {
         out_splits[o] = 0;
         if (M[o] <= 0 || N[o] <= 0 || (M[o] & 3) || (N[o] & 3) || ldc[o] < N[o]) return -1;
@@ -423,7 +452,7 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout || R[s] <= 0 || (lda[s] & 3) || (ldb[s] & 3) || lda[s] < M[o] || ldb[s] < N[o]) return -1;
-        seg_eff[s] = batch_eff_splits(R[s], M[o], N[o], &seg_rps[s]);
+        seg_eff[s] = batch_eff_splits(R[s], M[o], N[o], rt, &seg_rps[s]);
         out_splits[o] += seg_eff[s];
     }
     // workspace layout: per output [splits][M][N] then [splits][M]
