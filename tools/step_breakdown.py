@@ -15,7 +15,7 @@ FAMILIES = [
     ("fusion_modules", r"softmax_scale|mfn_mem|gated_pair|rowscale_colsum"),
     ("library_gemm_k_not_multiple_of_4", r"^Cijk_"),
     ("head_and_loss", r"head_|focal_loss"),
-    ("encoder_glue", r"party_|mask_scale|colsum"),
+    ("encoder_glue", r"party_|mask_scale|colsum|keep_flags"),
     ("optimizer", r"adam_step"),
     ("aten_and_runtime", r"at::native|rocclr|rocprim|elementwise_kernel_with_index"),
 ]
