@@ -153,11 +153,7 @@ __global__ __launch_bounds__(64 * NW) void propagate_kernel(
 //     modalities' rows read by the cross-modal terms are served by that XCD's L2.
 //   * small LDS / VGPR footprint on purpose: with BKT = 16 six 4-wave workgroups fit per CU, so a
 //     launch of <= 6 waves per SIMD runs in ONE round with the MFMA pipe shared by all of them.
-// PFALL (dialogues of at most 8 chunks = 128 utterances: every BASELINE config but cfg5): ALL chunk loads of the workgroup (one
-// H slot and one tile fragment per thread and chunk) and the epilogue's cross-modal operands (M <= 3) are requested before the first
-// chunk is consumed.  A launch at these sizes is a chain of memory round trips (chunk ring of depth 2: ~3.5 of them, then one more
-// for the other modalities' rows in the epilogue: 9.1 us for 6.6 MB at cfg2); with everything in flight at once it is ONE.
-template <int NWR, int NWC, int NCTW, int BKT, int RPW, bool PFALL = false>
+template <int NWR, int NWC, int NCTW, int BKT, int RPW>
 __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_v2_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
@@ -253,9 +249,8 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
     // Raw loads only; the zero-masking happens when a set is consumed, otherwise the selects would
     // force a vmcnt(0) wait right behind the loads.  The loop is unrolled by two so that the ring
     // index is static (runtime-indexed register arrays would go to scratch).
-    constexpr int NSETS = PFALL ? 8 : 2;
-    float4 hset[NSETS][NH4] = {};
-    float4 aset[NSETS][RPW][NSUB] = {};
+    float4 hset[2][NH4] = {};
+    float4 aset[2][RPW][NSUB] = {};
     const int nchunks = (L + BKT - 1) / BKT;
 
 #define MMDFN_ISSUE(SET, K0)                                                                              \
@@ -297,7 +292,7 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
                 av[rp][4 * h + 3] = (a_ok[rp] && ka_ + 3 < L) ? v.w : 0.f;                                \
             }                                                                                             \
         __syncthreads();                                                                                  \
-        if (!PFALL && (C) + 2 < nchunks) MMDFN_ISSUE((SET) & 1, ((C) + 2) * BKT);                         \
+        if ((C) + 2 < nchunks) MMDFN_ISSUE(SET, ((C) + 2) * BKT);                                         \
         if (wave_active && !(abl & 2)) {                                                                  \
             __builtin_amdgcn_s_setprio(3); /* MFMA phase outranks other waves' load/store phases */       \
             const float* hbase = &Hs[16 * wc * NCTW + frow];                                              \
@@ -321,45 +316,11 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
         __builtin_amdgcn_sched_barrier(0);                                                                \
     } while (0)
 
-    // epilogue operands of this thread's output slots (PFALL, M <= 3): the other modalities' H rows and cross weights
-    constexpr int EIT = PFALL ? (OROWS * (CB / 4) + NT - 1) / NT : 1;
-    float4 eh[EIT][2] = {};
-    float ew[EIT][2] = {};
-    const bool epf = PFALL && M <= 3 && !(abl & 1) && (BM == OROWS);
-    if (PFALL) {
-        const int cw4p = ((d - c0 < CB) ? (d - c0) : CB) / 4;
-        if (epf) {
-#pragma unroll
-            for (int it = 0; it < EIT; ++it) {
-                const int idx = tid + it * NT;
-                const int rr = idx / cw4p, c4 = idx - rr * cw4p;
-                const int row = r0 + rr;
-                const bool ok = idx < OROWS * cw4p && row < L;
-                const int64_t grow = rs + (ok ? row : r0);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (q < M - 1) {
-                        const int n = q + (q >= m ? 1 : 0);
-                        const int pk = (m < n) ? mmdfn_pair_index(m, n, M) : mmdfn_pair_index(n, m, M);
-                        ew[it][q] = cross[(int64_t)pk * N + grow];
-                        eh[it][q] = *reinterpret_cast<const float4*>(H + ((int64_t)n * N + grow) * ldh + c0 + 4 * (ok ? c4 : 0));
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < nchunks) MMDFN_ISSUE(c, c * BKT);
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < nchunks) MMDFN_CHUNK(c, c);
-    } else {
-        MMDFN_ISSUE(0, 0);
-        if (nchunks > 1) MMDFN_ISSUE(1, BKT);
-        for (int c = 0; c < nchunks; c += 2) {
-            MMDFN_CHUNK(0, c);
-            if (c + 1 < nchunks) MMDFN_CHUNK(1, c + 1);
-        }
+    MMDFN_ISSUE(0, 0);
+    if (nchunks > 1) MMDFN_ISSUE(1, BKT);
+    for (int c = 0; c < nchunks; c += 2) {
+        MMDFN_CHUNK(0, c);
+        if (c + 1 < nchunks) MMDFN_CHUNK(1, c + 1);
     }
 #undef MMDFN_ISSUE
 #undef MMDFN_CHUNK
@@ -382,25 +343,6 @@ __global__ __launch_bounds__(64 * NWR * NWC, (RPW >= 4 ? 2 : 4)) void propagate_
             }
         }
         __syncthreads();
-        if (epf) {                                   // operands already in registers (one pass: BM == OROWS)
-#pragma unroll
-            for (int it = 0; it < EIT; ++it) {
-                const int idx = tid + it * NT;
-                const int rr = idx / cw4, c4 = idx - rr * cw4;
-                const int row = r0 + rr;
-                if (idx >= OROWS * cw4 || row >= L) continue;
-                float4 v = *reinterpret_cast<const float4*>(&Os[rr * LDH + 4 * c4]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (q < M - 1) {
-                        v.x = fmaf(ew[it][q], eh[it][q].x, v.x); v.y = fmaf(ew[it][q], eh[it][q].y, v.y);
-                        v.z = fmaf(ew[it][q], eh[it][q].z, v.z); v.w = fmaf(ew[it][q], eh[it][q].w, v.w);
-                    }
-                }
-                *reinterpret_cast<float4*>(out + ((int64_t)m * N + rs + row) * ldo + c0 + 4 * c4) = v;
-            }
-            continue;
-        }
         for (int idx = tid; idx < OROWS * cw4; idx += NT) {
             const int rr = idx / cw4;
             const int c4 = idx - rr * cw4;
@@ -436,7 +378,7 @@ int ablation() {
 constexpr int ablation() { return 0; }
 #endif
 
-template <int NWR, int NWC, int NCTW, int BKT, int RPW, bool PFALL = false>
+template <int NWR, int NWC, int NCTW, int BKT, int RPW>
 int launch_v2(const float* tiles, const float* cross, const float* H, float* out, const int32_t* dia_len,
               const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int d, int ldh, int ldo,
               int max_len, hipStream_t s) {
@@ -446,7 +388,7 @@ int launch_v2(const float* tiles, const float* cross, const float* H, float* out
     const int ncb = (d + CB - 1) / CB;
     dim3 grid(((B + 7) / 8) * 8 * M * max_rb * ncb);
     dim3 block(64 * NWR * NWC);
-    hipLaunchKernelGGL((propagate_v2_kernel<NWR, NWC, NCTW, BKT, RPW, PFALL>), grid, block, 0, s, tiles, cross, H, out, dia_len,
+    hipLaunchKernelGGL((propagate_v2_kernel<NWR, NWC, NCTW, BKT, RPW>), grid, block, 0, s, tiles, cross, H, out, dia_len,
                        row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, ablation());
     MMDFN_CHECK_LAUNCH();
     return 0;
@@ -459,15 +401,6 @@ int tuning_override() {
 }
 #else
 constexpr int tuning_override() { return -1; }
-#endif
-
-#ifdef MMDFN_TUNING
-bool no_pfall() {
-    const char* e = getenv("MMDFN_PROP_NO_PFALL");
-    return e && atoi(e) != 0;
-}
-#else
-constexpr bool no_pfall() { return false; }
 #endif
 
 template <int NW, int NCT>
@@ -548,15 +481,11 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
                                                     ldo, max_len, s);
         if (rc != -2) return rc;
     }
-    const bool short_dialogues = max_len <= 128 && !no_pfall();        // at most 8 chunks of 16: everything in flight at once
     if (d <= 112) {
-        if (approx_rows <= 32768L)
-            return short_dialogues ? launch_v2<2, 4, 2, 16, 1, true>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d,
-                                                                     ldh, ldo, max_len, s)
-                                   : V2(2, 4, 2, 16, 1);
+        if (approx_rows <= 32768L) return V2(2, 4, 2, 16, 1);
         return V2(8, 1, 7, 16, 1);
     }
-    if (d <= 224) return V2(4, 2, 7, 16, 1);      // (its 7 column tiles per wave leave no registers for eight chunk sets)
+    if (d <= 224) return V2(4, 2, 7, 16, 1);
     return V2(4, 2, 4, 16, 1);
 }
 #undef V2
