@@ -104,6 +104,27 @@ def measured_traffic(key, kernel):
     return ent["traffic_bytes"], "profiles/r03_propagate_traffic.json (commit %s, kernel %s)" % (d.get("commit", "?"), ent["kernel"])
 
 
+def measured_traffic_bwd():
+    """HBM bytes of the cfg5 backward leg = the sum over its three kernels (dH: propagate_split, dA: tile_dot_split +
+    cross_dot) of the same committed PMC passes; attached only if all three kernels are still in the loaded library."""
+    d = profile_json("r03_propagate_traffic.json")
+    if not d or "legs" not in d or "cfg5_b32" not in d:
+        return None, None
+    names = ("tile_dot_split_kernel", "cross_dot_kernel")
+    legs = {n: [l for l in d["legs"] if l["kernel"] == n] for n in names}
+    if not all(legs.values()):
+        return None, None
+    from mm_dfn_amd import build as _b
+    try:
+        blob = open(_b.LIBPATH, "rb").read()
+    except OSError:
+        return None, None
+    if not all(n.encode() in blob for n in names + ("propagate_split_kernel",)):
+        return None, "profiles/r03_propagate_traffic.json names kernels that are not in the current library: not attached"
+    total = d["cfg5_b32"]["traffic_bytes"] + sum(max(l["traffic_bytes"] for l in legs[n]) for n in names)
+    return total, "profiles/r03_propagate_traffic.json (commit %s): propagate_split + tile_dot_split + cross_dot" % d.get("commit", "?")
+
+
 def time_propagate(make_set, nsets, iters, warm_replays=10, timed_replays=3):
     """Average duration (ms) of one K6 propagate launch.  ``nsets`` independent (adjacency, H, out) buffer sets are
     rotated launch by launch, sized so that together they exceed the 256 MB Infinity Cache: no launch finds its
@@ -579,6 +600,10 @@ def roofline_legs(out, a, dev, n_utt, lengths):
                                     "bound": "hbm", "achieved": bb / (msb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "algorithmic_bytes": bb, "avg_us": msb * 1e3}
+        tb, srcb = measured_traffic_bwd()
+        out["roofline_cfg5_bwd"]["traffic"] = tb
+        if srcb:
+            out["roofline_cfg5_bwd"]["traffic_source"] = srcb
         del adj5, H5, dO5, gb
         torch.cuda.empty_cache()
         # the d = 512 stress variant SURVEY 8d asks for next to the reference-faithful d = 100: 18.94 MB and 1.63 GFLOP per
