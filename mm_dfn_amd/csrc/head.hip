@@ -46,9 +46,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                 const int i = base + 256 * e;
                 v[e] = reinterpret_cast<const float4*>(Wt)[i < total ? i : total - 1];
             }
+            // (the stores go to the clamped slot as well: behind a guard hipcc sinks each load into its store's branch again)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (base + 256 * e < total) reinterpret_cast<float4*>(sW)[base + 256 * e] = v[e];
+            for (int e = 0; e < 8; ++e) {
+                const int i = base + 256 * e;
+                reinterpret_cast<float4*>(sW)[i < total ? i : total - 1] = v[e];
+            }
         }
     }
     __syncthreads();
@@ -64,10 +67,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         for (int j0 = 0; j0 < W4; j0 += 64 * NJ) {
             float4 zv[NJ], mv[NJ];
 #pragma unroll
-            for (int u = 0; u < NJ; ++u) {
+            for (int u = 0; u < NJ; ++u) {                        // unconditional loads from clamped columns (selected at use)
                 const int j = j0 + 64 * u + lane;
-                zv[u] = (j < W4) ? *reinterpret_cast<const float4*>(Fm + feat_off(row, 4 * j, ldf, split, N)) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mask) mv[u] = (j < W4) ? *reinterpret_cast<const float4*>(mask + row * W + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int jc = j < W4 ? j : W4 - 1;
+                zv[u] = *reinterpret_cast<const float4*>(Fm + feat_off(row, 4 * jc, ldf, split, N));
+                mv[u] = *reinterpret_cast<const float4*>((mask ? mask : Fm) + (mask ? row * W + 4 * jc : feat_off(row, 4 * jc, ldf, split, N)));
             }
 #pragma unroll
             for (int u = 0; u < NJ; ++u) {
@@ -130,8 +134,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int i = base + 256 * e, c = i / cols4, j = i - c * cols4;
-            if (i < C * cols4) reinterpret_cast<float4*>(sm)[c * (HB_COLS / 4) + j] = v[e];
+            const int i0 = base + 256 * e, i = i0 < C * cols4 ? i0 : C * cols4 - 1, c = i / cols4, j = i - c * cols4;
+            reinterpret_cast<float4*>(sm)[c * (HB_COLS / 4) + j] = v[e];                              // (clamped slot: no guard)
         }
     }
     __syncthreads();
