@@ -18,7 +18,7 @@ namespace {
 
 constexpr int HC_MAX = 8;        // classes (IEMOCAP 6, MELD 7); wider heads stay on the library path
 constexpr int HB_COLS = 1024;    // feature columns per backward column block (4 float4 per lane)
-constexpr int HB_GROUPS = 128;   // row groups (workgroups per column block) of the backward pass
+constexpr int HB_GROUPS = 256;   // row groups (workgroups per column block) of the backward pass: a wave walks ~5 rows at N = 5 280 (each row is a memory round trip)
 
 // Element (row, col) of the feature matrix.  split = 0: plain rows of stride ld.  split = Wm > 0: the matrix is the
 // column-wise concatenation of W / Wm blocks that live one after the other as (N, Wm) matrices of row stride ld -- the
