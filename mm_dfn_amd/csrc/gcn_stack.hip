@@ -50,6 +50,17 @@ __device__ __forceinline__ float4 fma4(float4 a, float s, float4 b) { return mak
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+// Conflict-free 16-byte fragment reads.  A wave's ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19,
+// 28-31} (+32): half of a group comes from k-group g, the other half from g + 1, so with lane (i, g) reading row i, 16-byte unit
+// 4 kc + g of a row-major image two lanes of a group always meet on a bank whatever the (odd) row stride (PMC: SQ_LDS_BANK_CONFLICT
+// = 50-64 % of SQ_LDS_IDX_ACTIVE in the round-2 stack kernels).  The MFMA does not care which data row its row i carries nor in which
+// order k is walked, as long as the result is filed accordingly and both operands agree: lane (i, g) reads data row frag_row(i) --
+// even rows for the lanes {0-3, 12-15}, odd rows for {4-11} -- and unit 4 kc + frag_unit(g) with frag_unit = 0, 2, 1, 3.  Within a
+// lane group the even rows then sit on even units and the odd rows on odd units (the stride is an odd number of units): 16 distinct
+// bank slots.  Accumulator element (r of lane (i, g)) belongs to data row frag_row(4 g + r), output column frag_row(i) of the tile.
+__device__ __forceinline__ int frag_row(int i) { return i < 4 ? 2 * i : (i < 12 ? 2 * (i - 4) + 1 : 2 * (i - 12) + 8); }
+__device__ __forceinline__ int frag_unit(int g) { return ((g & 1) << 1) | (g >> 1); }
+
 // LDS row stride (floats) for rows of K floats: room for K rounded up to 16 (the MFMA loop reads whole 16-wide chunks;
 // the padding holds zeros), 16-byte aligned and (stride / 4) odd, so that the 16 rows a quarter wave reads at one k
 // land on 16 different 16-byte bank groups.
@@ -115,10 +126,10 @@ template <int NT>
 __device__ __forceinline__ void contract(f32x4 (&acc)[NT], const int (&wrow0)[NT], const float* sA, int lda, const float* sW,
                                          int ldw, int K) {
     const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
-    const float* ap = sA + fi * lda + 4 * g;
+    const float* ap = sA + frag_row(fi) * lda + 4 * frag_unit(g);
     const float* bp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bp[t] = sW + (wrow0[t] + fi) * ldw + 4 * g;
+    for (int t = 0; t < NT; ++t) bp[t] = sW + (wrow0[t] + frag_row(fi)) * ldw + 4 * frag_unit(g);
     const int nk = (K + 15) >> 4;
     float4 a0, a1, b0[NT], b1[NT];
 #define CT_LOAD(A_, B_, KC)                                                          \
@@ -162,7 +173,7 @@ __device__ __forceinline__ int wave_tiles(int (&wrow0)[NT], int ntiles) {
     return nt;
 }
 
-// accumulators -> LDS sP[16][ldp] (C/D layout of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + r)
+// accumulators -> LDS sP[16][ldp] (C/D layout of the 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + r, both through frag_row)
 template <int NT>
 __device__ __forceinline__ void spill_tiles(const f32x4 (&acc)[NT], const int (&wrow0)[NT], int nt, float* sP, int ldp) {
     const int lane = threadIdx.x & 63, fi = lane & 15, g = lane >> 4;
@@ -170,7 +181,7 @@ __device__ __forceinline__ void spill_tiles(const f32x4 (&acc)[NT], const int (&
     for (int t = 0; t < NT; ++t) {
         if (t < nt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sP[(4 * g + r) * ldp + wrow0[t] + fi] = acc[t][r];
+            for (int r = 0; r < 4; ++r) sP[frag_row(4 * g + r) * ldp + wrow0[t] + frag_row(fi)] = acc[t][r];
         }
     }
 }
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sE[(w * RB + 4 * g + r) * lde + 16 * t + fi] = acc[t][r];
+                for (int r = 0; r < 4; ++r) sE[(w * RB + frag_row(4 * g + r)) * lde + 16 * t + frag_row(fi)] = acc[t][r];
         }
         __syncthreads();
         if (ethread && erow < R) {
@@ -915,8 +926,8 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
     // consumer constants: wave w contracts the 16-column tile w of the slice; lane (fi, g) holds column fi, rows 4 g .. + 3
     const int w = tid >> 6, lane = tid & 63, fi = lane & 15, g = lane >> 4;
     const int wrow0[1] = {16 * w < ncols ? 16 * w : 0};
-    const int ecol = n0 + 16 * w + fi;
-    const bool ecol_ok = (16 * w + fi) < ncols;
+    const int ecol = n0 + 16 * w + frag_row(fi);        // (output column / rows of this lane's accumulator elements: frag_row)
+    const bool ecol_ok = (16 * w + frag_row(fi)) < ncols;
     float* const outp = is_dh ? dh_prev : dq;
     int buf = 0;
     for (int rb = first; rb < nrb; rb += stride) {
@@ -932,7 +943,7 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
             float rv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int erow = rb * RB + 4 * g + r;
+                const int erow = rb * RB + frag_row(4 * g + r);
                 rv[r] = (!is_dh && dres && ecol_ok && erow < R) ? dres[(int64_t)erow * lddres + ecol] : 0.f;
             }
             f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
             if (ecol_ok && !(ABL & 8)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int erow = rb * RB + 4 * g + r;
+                    const int erow = rb * RB + frag_row(4 * g + r);
                     if (erow < R) outp[(int64_t)erow * H + ecol] = acc[0][r] + rv[r];
                 }
             }
@@ -1088,7 +1099,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) E[(w * RB + 4 * g + r) * lde + 16 * t + fi] = acc[t][r];
+                for (int r = 0; r < 4; ++r) E[(w * RB + frag_row(4 * g + r)) * lde + 16 * t + frag_row(fi)] = acc[t][r];
         }
         __syncthreads();
         prev_rb = rb;
