@@ -518,8 +518,12 @@ extern "C" int mmdfn_linear_group(int n, const float* const* X, const float* con
         if (!kmajor[p] && N1[p] < N[p] && (reinterpret_cast<uintptr_t>(W2[p]) & 15)) lds = false;
         t64 += (int64_t)((R[p] + 63) / 64) * ((N[p] + TN - 1) / TN);
     }
-    // 64-row tiles once they fill the chip on their own (2 workgroups per CU); 32-row tiles (k split across waves) below
-    int tm = (lds && t64 >= LDS64_TILES) ? 64 : 32;
+    // 64-row tiles once they fill the chip on their own (2 workgroups per CU) AND the contraction is long (measured: 7 040 x 600
+    // -> 200: 29.9 us against 33.3 us with 32-row tiles; at K = 200 the 32-row tiles win, 3 520 x 200 -> 600: 19.2 against 21.5 us);
+    // 32-row tiles (k split across waves) otherwise
+    int kmin = 1 << 30;
+    for (int p = 0; p < n; ++p) kmin = K[p] < kmin ? K[p] : kmin;
+    int tm = (lds && t64 >= LDS64_TILES && kmin >= 400) ? 64 : 32;
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_LSM_V1")) lds = lds && atoi(e) == 0;
     if (const char* e = getenv("MMDFN_LSM_TM")) tm = atoi(e);
