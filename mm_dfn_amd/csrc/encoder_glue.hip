@@ -306,8 +306,8 @@ __global__ __launch_bounds__(1024) void keep_flags_kernel(float* __restrict__ ou
         // the wave's 128 float4 slots as two contiguous 1 KB stores (which flag lands where is immaterial)
         const int lane = threadIdx.x & 63;
         const int64_t sa = 2 * (i - lane) + lane, sb = sa + 64;
-        if (sa < n4) *reinterpret_cast<float4*>(out + 4 * sa) = v;
-        if (sb < n4) *reinterpret_cast<float4*>(out + 4 * sb) = u;
+        if (sa < n4) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(out + 4 * sa));
+        if (sb < n4) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, u), reinterpret_cast<f32x4*>(out + 4 * sb));
     }
     __shared__ int last_s;
     __syncthreads();
