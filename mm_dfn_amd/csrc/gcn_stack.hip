@@ -58,6 +58,8 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 // even rows for the lanes {0-3, 12-15}, odd rows for {4-11} -- and unit 4 kc + frag_unit(g) with frag_unit = 0, 2, 1, 3.  Within a
 // lane group the even rows then sit on even units and the odd rows on odd units (the stride is an odd number of units): 16 distinct
 // bank slots.  Accumulator element (r of lane (i, g)) belongs to data row frag_row(4 g + r), output column frag_row(i) of the tile.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store2(float* p, float2 v) { __builtin_nontemporal_store((f32x2_t){v.x, v.y}, reinterpret_cast<f32x2_t*>(p)); }
 __device__ __forceinline__ int frag_row(int i) { return i < 4 ? 2 * i : (i < 12 ? 2 * (i - 4) + 1 : 2 * (i - 12) + 8); }
 __device__ __forceinline__ int frag_unit(int g) { return ((g & 1) << 1) | (g >> 1); }
 
@@ -1062,9 +1064,9 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
     }
         K8F(x) K8F(y)
 #undef K8F
+        // the gate activations are read again only by the backward pass: around the L2 (nontemporal), h' and c' stay cached
         float* gr = gates + (int64_t)erow * 4 * H + u0 + eu;
-        *reinterpret_cast<float2*>(gr) = gi; *reinterpret_cast<float2*>(gr + H) = gf;
-        *reinterpret_cast<float2*>(gr + 2 * H) = gg; *reinterpret_cast<float2*>(gr + 3 * H) = go;
+        nt_store2(gr, gi); nt_store2(gr + H, gf); nt_store2(gr + 2 * H, gg); nt_store2(gr + 3 * H, go);
         *reinterpret_cast<float2*>(c_out + (int64_t)erow * H + u0 + eu) = cn;
         *reinterpret_cast<float2*>(h_out + (int64_t)erow * H + u0 + eu) = hn;
     };

@@ -38,7 +38,8 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
                                                  const float* __restrict__ W2b, int n1,
                                                  const float* __restrict__ bias, const float* __restrict__ bias2,
                                                  float* __restrict__ Yb, int Rv, int Nv,
-                                                 int Nstore, int K, int ldx, int ldw, int ldy, int act, int accumulate) {
+                                                 int Nstore, int K, int ldx, int ldw, int ldy, int act, int accumulate,
+                                                 bool nt_store = false) {
     constexpr int NCT = 4;
     constexpr int ABLC = 0;
     constexpr int WROWS = 32;
@@ -139,7 +140,9 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
                     }
-                    *reinterpret_cast<float4*>(yrow + c) = make_float4(o[0], o[1], o[2], o[3]);
+                    // (nt_store: results nobody reads soon -- the 201 MB of adjacency-gradient tiles -- go around the L2)
+                    if (nt_store) __builtin_nontemporal_store((f32x4){o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(yrow + c));
+                    else *reinterpret_cast<float4*>(yrow + c) = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
         }
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void tile_dot_split_kernel(const float* __r
     const int Rv = (L - r0 < 128) ? L - r0 : 128;
     const int Nv = (L - c0 < 128) ? L - c0 : 128;
     const int Ns = (ld - c0 < 128) ? ld - c0 : 128;
-    split_gemm_block(Xm, Ym, nullptr, 1 << 30, nullptr, nullptr, T, Rv, Nv, Ns, K, ldx, ldy, ld, 0, accumulate);
+    split_gemm_block(Xm, Ym, nullptr, 1 << 30, nullptr, nullptr, T, Rv, Nv, Ns, K, ldx, ldy, ld, 0, accumulate, true);
 }
 
 }  // namespace
