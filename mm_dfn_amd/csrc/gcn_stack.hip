@@ -59,6 +59,8 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 // lane group the even rows then sit on even units and the odd rows on odd units (the stride is an odd number of units): 16 distinct
 // bank slots.  Accumulator element (r of lane (i, g)) belongs to data row frag_row(4 g + r), output column frag_row(i) of the tile.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// 16-byte store around the L2 for results the NEXT kernels do not read (operands of the end-of-backward weight-gradient batch)
+__device__ __forceinline__ void st4_nt(float* p, float4 v) { __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p)); }
 __device__ __forceinline__ void nt_store2(float* p, float2 v) { __builtin_nontemporal_store((f32x2_t){v.x, v.y}, reinterpret_cast<f32x2_t*>(p)); }
 __device__ __forceinline__ int frag_row(int i) { return i < 4 ? 2 * i : (i < 12 ? 2 * (i - 4) + 1 : 2 * (i - 12) + 8); }
 __device__ __forceinline__ int frag_unit(int g) { return ((g & 1) << 1) | (g >> 1); }
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
             v.x = rh0[s].x > 0.f ? v.x : 0.f; v.y = rh0[s].y > 0.f ? v.y : 0.f;
             v.z = rh0[s].z > 0.f ? v.z : 0.f; v.w = rh0[s].w > 0.f ? v.w : 0.f;
             st4(dst + r * ldw + k, v);
-            if (row < R) st4(dpre + (int64_t)row * H + k, v);
+            if (row < R) st4_nt(dpre + (int64_t)row * H + k, v);
         }
     };
     if ((int)blockIdx.x < nrb) issue(blockIdx.x);
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
             const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
             const float4 v = scl4(mul4(rd[s], rg[s]), theta);
             st4(dst + r * ldw + k, v);
-            if (row < R) st4(dP + (int64_t)row * H + k, v);
+            if (row < R) st4_nt(dP + (int64_t)row * H + k, v);
         }
     };
     if ((int)blockIdx.x < nrb) issue(blockIdx.x);
@@ -911,10 +913,10 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
             const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB + r;
             if (row >= R) continue;
             float* d = dG + (int64_t)row * 4 * H + u;
-            if (wr_i) st4(d, odi[s_]);
-            if (wr_f) st4(d + H, odf[s_]);
-            if (wr_g) st4(d + 2 * H, odg[s_]);
-            if (wr_o) st4(d + 3 * H, odo[s_]);
+            if (wr_i) st4_nt(d, odi[s_]);
+            if (wr_f) st4_nt(d + H, odf[s_]);
+            if (wr_g) st4_nt(d + 2 * H, odg[s_]);
+            if (wr_o) st4_nt(d + 3 * H, odo[s_]);
             if (has_h && wr_c) st4(dc_prev + (int64_t)row * H + u, odc[s_]);
         }
     };
