@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
             const int r = i / F4, k = (i - r * F4) * 4, row = rb * RB + r;
             const float4 v = mul4(rx[s], scl4(rm[s], mx ? ms : 1.0f));
             st4(dst + r * ldw + k, v);
-            if (row < R) st4(xd + (int64_t)row * ldxd + k, v);
+            if (row < R) st4_nt(xd + (int64_t)row * ldxd + k, v);       // (read again by the weight-gradient batch only)
         }
     };
     const int rb0 = blockIdx.x;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
             K7F(x) K7F(y) K7F(z) K7F(w)
 #undef K7F
             st4(out + (int64_t)row * ldo + n, o);
-            st4(gmask + (int64_t)row * H + n, gm);
+            st4_nt(gmask + (int64_t)row * H + n, gm);            // (saved for the backward pass)
         }
         if (nxt < nrb) park(sA + (buf ^ 1) * RB * ldw);
         __syncthreads();

@@ -422,10 +422,11 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
                     const float4 v = *reinterpret_cast<const float4*>(&out_s[b & 1][sl][u][0]);
                     const float g4 = out_s[b & 1][sl][u][4];
                     yp[u] = v.x;
-                    gp[u] = v.y;
-                    gp[GH + u] = v.z;
-                    gp[2 * GH + u] = v.w;
-                    gp[3 * GH + u] = g4;
+                    // (the saved gate values are read again by the backward pass only: nontemporal, around the L2)
+                    __builtin_nontemporal_store(v.y, &gp[u]);
+                    __builtin_nontemporal_store(v.z, &gp[GH + u]);
+                    __builtin_nontemporal_store(v.w, &gp[2 * GH + u]);
+                    __builtin_nontemporal_store(g4, &gp[3 * GH + u]);
                 }
             }
         };
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
             if (c4 < 3 * GH / 4)
                 *reinterpret_cast<float4*>(dgi + o + 4 * c4) = v;
             else
-                *reinterpret_cast<float4*>(dgh + o + 4 * (c4 - 3 * GH / 4)) = v;
+                __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(dgh + o + 4 * (c4 - 3 * GH / 4)));   // (read by the weight-gradient batch only)
         }
     };
 
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
             if (c4 < 3 * GH / 4)
                 *reinterpret_cast<float4*>(dgi + o + 4 * c4) = v;
             else
-                *reinterpret_cast<float4*>(dgh + o + 4 * (c4 - 3 * GH / 4)) = v;
+                __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(dgh + o + 4 * (c4 - 3 * GH / 4)));   // (read by the weight-gradient batch only)
         }
     };
 
