@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             if (c4 < GH / 4)
                 *reinterpret_cast<float4*>(y + o * (2 * GH) + dir * GH + 4 * c4) = v;
             else
-                *reinterpret_cast<float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4)) = v;
+                __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4)));   // (saved for the backward pass)
         }
     };
 
