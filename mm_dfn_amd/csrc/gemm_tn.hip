@@ -15,19 +15,36 @@
 namespace {
 
 constexpr int BR = 32;          // rows per staged chunk
-constexpr int TM = 64, TN = 64; // output tile per workgroup
+constexpr int TM = 64, TN = 64; // output tile per workgroup (TNW columns in the wide form)
+constexpr int TNW = 112;
 constexpr int LDA = TM + 4;     // = 4 (mod 8)
 constexpr int LDB = TN + 4;
+constexpr int BS_FLOATS = 32 * (TNW + 4);    // B stage of the wider form (BR rows)
+
+// 1: the 112-column tile covers N better than the 64-column one
+inline bool tn_wide(int N) {
+    const double e64 = (double)N / (64.0 * ((N + 63) / 64)), e112 = (double)N / (112.0 * ((N + 111) / 112));
+    return e112 > e64 + 0.02;
+}
 
 // One workgroup: output tile `tile` of split `split`.  B is read at row r + bshift (rows outside [0, R) count as
 // zero): the recurrent-weight gradient  dW_hh = sum_t dgh_t (x) h_{t-1}  pairs row t of dgh with row t-1 (forward
 // direction) or t+1 (reverse) of the output sequence, and with the shift inside the kernel A still covers every row,
 // so its column sums are the complete bias gradient.
-__device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const float* __restrict__ B,
-                                             float* __restrict__ part, float* __restrict__ colpart, int R, int M, int N,
-                                             int lda, int ldb, int rows_per_split, int bshift, int tile, int split) {
-    __shared__ __attribute__((aligned(16))) float As[2][BR * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BR * LDB];
+// WIDE: the tile is 64 x 112 (seven 16-column MFMA tiles per wave, the four waves take 16 rows each) instead of 64 x 64 (2 x 2
+// per wave, waves 2 x 2): the hot-path outputs are 100 or 200 columns wide, which 64-column tiles cover at 78 % (64 + 36) and
+// 112-column tiles at 89 %.
+template <bool WIDE>
+__device__ __forceinline__ void gemm_tn_body(float (*As)[BR * LDA], float* Bs0, const float* __restrict__ A,
+                                             const float* __restrict__ B, float* __restrict__ part,
+                                             float* __restrict__ colpart, int R, int M, int N, int lda, int ldb,
+                                             int rows_per_split, int bshift, int tile, int split) {
+    constexpr int TN = WIDE ? TNW : 64;
+    constexpr int LDB = TN + 4;                         // = 4 (mod 8) for both widths
+    constexpr int WMT = WIDE ? 1 : 2, WNT = WIDE ? 7 : 2;   // 16-row / 16-column MFMA tiles per wave
+    constexpr int NSB = WIDE ? 4 : 2;                   // B staging slots per thread (32 x TN / 4 float4 over 256 threads)
+    constexpr int BSL = BR * TN / 4;                    // B float4 per chunk (896 / 512)
+    float(*Bs)[BR * LDB] = reinterpret_cast<float(*)[BR * LDB]>(Bs0);
     const int nbn = (N + TN - 1) / TN;
     const int bm = tile / nbn;
     const int bn = tile - bm * nbn;
@@ -35,17 +52,21 @@ __device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const 
     const int r_end = min(R, r_begin + rows_per_split);
     const int m0 = bm * TM, n0 = bn * TN;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w & 1, wn = w >> 1;
+    const int wm = WIDE ? w : (w & 1), wn = WIDE ? 0 : (w >> 1);
+    const int mrow0 = 16 * WMT * wm, ncol0 = 16 * WNT * wn;    // the wave's corner inside the tile
     const int fi = lane & 15, g = lane >> 4;
 
-    f32x4 acc[2][2];
+    f32x4 acc[WMT][WNT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float csum[2] = {0.f, 0.f};
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[WMT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) csum[i] = 0.f;
 
-    // staging slots: BR*16 float4 per operand = 512 -> 2 per thread per operand
+    // staging slots: A BR*16 float4 = 512 -> 2 per thread; B BR*TN/4 float4 -> 2 (512) or 4 (896: the fourth slot exists for
+    // the first two waves only, a wave-uniform condition)
     int s_r[2], s_c[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -53,19 +74,34 @@ __device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const 
         s_r[e] = idx >> 4;
         s_c[e] = (idx & 15) * 4;
     }
+    int b_r[NSB], b_c[NSB];
+    bool b_on[NSB];
+#pragma unroll
+    for (int e = 0; e < NSB; ++e) {
+        const int idx = tid + e * 256;
+        b_on[e] = idx < BSL;
+        const int ic = b_on[e] ? idx : BSL - 1;
+        b_r[e] = ic / (TN / 4);
+        b_c[e] = (ic - b_r[e] * (TN / 4)) * 4;
+    }
     // two register sets form a ring: the loads of chunk c + 2 are issued during chunk c and stored to LDS at the top
     // of chunk c + 2, i.e. two MFMA blocks later -- twice the bytes in flight of a distance-1 prefetch (the kernel is
     // latency-bound: a split is 10-20 chunks long).  Unrolled by two so that the ring index is static.
-    float4 ra[2][2], rb[2][2];
+    float4 ra[2][2], rb[2][NSB];
 #define TN_ISSUE(SET, R0)                                                                                     \
     do {                                                                                                      \
         _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                       \
             const int r = (R0) + s_r[e];                                                                      \
             const int rc = r < r_end ? r : r_end - 1;                                                         \
+            const int ca = m0 + s_c[e];                                                                       \
+            ra[SET][e] = *reinterpret_cast<const float4*>(A + (int64_t)rc * lda + (ca < M ? ca : 0));         \
+        }                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < NSB; ++e) {                                                     \
+            const int r = (R0) + b_r[e];                                                                      \
+            const int rc = r < r_end ? r : r_end - 1;                                                         \
             const int rbs = rc + bshift;                                                                      \
             const int rbc = rbs < 0 ? 0 : (rbs < R ? rbs : R - 1);                                            \
-            const int ca = m0 + s_c[e], cb = n0 + s_c[e];                                                     \
-            ra[SET][e] = *reinterpret_cast<const float4*>(A + (int64_t)rc * lda + (ca < M ? ca : 0));         \
+            const int cb = n0 + b_c[e];                                                                       \
             rb[SET][e] = *reinterpret_cast<const float4*>(B + (int64_t)rbc * ldb + (cb < N ? cb : 0));        \
         }                                                                                                     \
     } while (0)
@@ -75,27 +111,30 @@ __device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const 
         float* as = As[(C) & 1];                                                                              \
         float* bs = Bs[(C) & 1];                                                                              \
         _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                       \
-            const bool rok = (r0 + s_r[e]) < r_end;                                                           \
-            const int rbs = r0 + s_r[e] + bshift;                                                             \
-            const bool aok = rok && (m0 + s_c[e] < M), bok = rok && (n0 + s_c[e] < N) && rbs >= 0 && rbs < R; \
+            const bool aok = (r0 + s_r[e]) < r_end && (m0 + s_c[e] < M);                                      \
             /* M, N are multiples of 4 (checked by the launcher), so a float4 is fully inside or outside */   \
-            const float4 va = ra[SET][e], vb = rb[SET][e];                                                    \
+            const float4 va = ra[SET][e];                                                                     \
             *reinterpret_cast<float4*>(&as[s_r[e] * LDA + s_c[e]]) =                                          \
                 make_float4(aok ? va.x : 0.f, aok ? va.y : 0.f, aok ? va.z : 0.f, aok ? va.w : 0.f);          \
-            *reinterpret_cast<float4*>(&bs[s_r[e] * LDB + s_c[e]]) =                                          \
-                make_float4(bok ? vb.x : 0.f, bok ? vb.y : 0.f, bok ? vb.z : 0.f, bok ? vb.w : 0.f);          \
+        }                                                                                                     \
+        _Pragma("unroll") for (int e = 0; e < NSB; ++e) {                                                     \
+            const int rbs = r0 + b_r[e] + bshift;                                                             \
+            const bool bok = (r0 + b_r[e]) < r_end && (n0 + b_c[e] < N) && rbs >= 0 && rbs < R;               \
+            const float4 vb = rb[SET][e];                                                                     \
+            if (NSB == 2 || e < 3 || b_on[e])                                                                 \
+                *reinterpret_cast<float4*>(&bs[b_r[e] * LDB + b_c[e]]) =                                      \
+                    make_float4(bok ? vb.x : 0.f, bok ? vb.y : 0.f, bok ? vb.z : 0.f, bok ? vb.w : 0.f);      \
         }                                                                                                     \
         __syncthreads();                                                                                      \
         if ((C) + 2 < nchunks) TN_ISSUE(SET, r0 + 2 * BR);                                                    \
         _Pragma("unroll") for (int ks = 0; ks < BR / 4; ++ks) {                                               \
             const int rr = 4 * ks + g; /* MFMA k index = row within the chunk */                              \
-            float av[2], bv[2];                                                                               \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) av[i] = as[rr * LDA + 32 * wm + 16 * i + fi];       \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) bv[j] = bs[rr * LDB + 32 * wn + 16 * j + fi];       \
-            csum[0] += av[0];                                                                                 \
-            csum[1] += av[1];                                                                                 \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+            float av[WMT], bv[WNT];                                                                           \
+            _Pragma("unroll") for (int i = 0; i < WMT; ++i) av[i] = as[rr * LDA + mrow0 + 16 * i + fi];       \
+            _Pragma("unroll") for (int j = 0; j < WNT; ++j) bv[j] = bs[rr * LDB + ncol0 + 16 * j + fi];       \
+            _Pragma("unroll") for (int i = 0; i < WMT; ++i) csum[i] += av[i];                                 \
+            _Pragma("unroll") for (int i = 0; i < WMT; ++i)                                                   \
+                _Pragma("unroll") for (int j = 0; j < WNT; ++j)                                               \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);       \
         }                                                                                                     \
     } while (0)
@@ -111,24 +150,24 @@ __device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const 
     // partial tile -> workspace [split][M][N]; C/D layout: col (n) = lane&15, row (m) = 4g + r
     float* P = part + (int64_t)split * M * N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 32 * wn + 16 * j + fi;
+        for (int j = 0; j < WNT; ++j) {
+            const int n = n0 + ncol0 + 16 * j + fi;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 32 * wm + 16 * i + 4 * g + r;
+                const int m = m0 + mrow0 + 16 * i + 4 * g + r;
                 if (m < M && n < N) P[(int64_t)m * N + n] = acc[i][j][r];
             }
         }
     if (colpart != nullptr && bn == 0 && wn == 0) {
         // lanes with equal fi hold partial sums of the same column (different row residues g)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WMT; ++i) {
             float v = csum[i];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            const int m = m0 + 32 * wm + 16 * i + fi;
+            const int m = m0 + mrow0 + 16 * i + fi;
             if (g == 0 && m < M) colpart[(int64_t)split * M + m] = v;
         }
     }
@@ -137,7 +176,9 @@ __device__ __forceinline__ void gemm_tn_body(const float* __restrict__ A, const 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ part, float* __restrict__ colpart,
                                                       int R, int M, int N, int lda, int ldb, int rows_per_split) {
-    gemm_tn_body(A, B, part, colpart, R, M, N, lda, ldb, rows_per_split, 0, blockIdx.x, blockIdx.y);
+    __shared__ __attribute__((aligned(16))) float As[2][BR * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BR * LDB];
+    gemm_tn_body<false>(As, Bs, A, B, part, colpart, R, M, N, lda, ldb, rows_per_split, 0, blockIdx.x, blockIdx.y);
 }
 
 // up to TN_MAXG independent problems in one launch (each too small to fill the chip on its own)
@@ -162,8 +203,10 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroups gq)
     const int local = blockIdx.x - gq.wg_prefix[p];
     const int split = local / gq.tiles[p];
     const int tile = local - split * gq.tiles[p];
-    gemm_tn_body(gq.A[p], gq.B[p], gq.part[p], gq.colpart[p], gq.R[p], gq.M[p], gq.N[p], gq.lda[p], gq.ldb[p],
-                 gq.rows_per_split[p], gq.bshift[p], tile, split);
+    __shared__ __attribute__((aligned(16))) float As[2][BR * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BR * LDB];
+    gemm_tn_body<false>(As, Bs, gq.A[p], gq.B[p], gq.part[p], gq.colpart[p], gq.R[p], gq.M[p], gq.N[p], gq.lda[p], gq.ldb[p],
+                        gq.rows_per_split[p], gq.bshift[p], tile, split);
 }
 
 __device__ __forceinline__ void gemm_tn_reduce_body(const float* __restrict__ part, const float* __restrict__ colpart,
@@ -216,7 +259,7 @@ struct TnSegs {
     float* part[TN_MAXSEG];
     float* colpart[TN_MAXSEG];
     int R[TN_MAXSEG], lda[TN_MAXSEG], ldb[TN_MAXSEG], bshift[TN_MAXSEG], rows_per_split[TN_MAXSEG], tiles[TN_MAXSEG];
-    int M[TN_MAXSEG], N[TN_MAXSEG];
+    int M[TN_MAXSEG], N[TN_MAXSEG], wide[TN_MAXSEG];
     int wg_prefix[TN_MAXSEG + 1];
     int n;
 };
@@ -237,8 +280,14 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(const TnSegs sq) {
     const int local = blockIdx.x - sq.wg_prefix[p];
     const int split = local / sq.tiles[p];
     const int tile = local - split * sq.tiles[p];
-    gemm_tn_body(sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p],
-                 sq.rows_per_split[p], sq.bshift[p], tile, split);
+    __shared__ __attribute__((aligned(16))) float As[2][BR * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BS_FLOATS];
+    if (sq.wide[p])
+        gemm_tn_body<true>(As, Bs, sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p],
+                           sq.rows_per_split[p], sq.bshift[p], tile, split);
+    else
+        gemm_tn_body<false>(As, Bs, sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p],
+                            sq.rows_per_split[p], sq.bshift[p], tile, split);
 }
 
 __global__ void gemm_tn_batch_reduce_kernel(const TnOuts oq) {
@@ -393,6 +442,12 @@ extern "C" int mmdfn_gemm_tn_grouped(int n, const float* const* A, const float* 
 // workgroups than that needs (BASELINE cfg5: 24 576-row segments, 15 000 workgroups of 16 chunks at 512 rows per split, 69
 // TFLOP/s), longer splits -- about 12 workgroups per CU in total, at most 4 096 rows -- amortise each workgroup's prologue and
 // write / reduce a quarter of the slabs.
+#ifdef MMDFN_TUNING
+static bool tn_no_wide() { const char* e = getenv("MMDFN_TN_NO_WIDE"); return e && atoi(e) != 0; }
+#else
+constexpr bool tn_no_wide() { return false; }
+#endif
+
 static int batch_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
     double units = 0.0;                                  // sum over segments of output tiles x rows
     for (int s = 0; s < nseg; ++s) {
@@ -489,7 +544,10 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     sq.wg_prefix[0] = 0;
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
-        const int tiles = ((M[o] + TM - 1) / TM) * ((N[o] + TN - 1) / TN);
+        const bool wide = tn_wide(N[o]) && !tn_no_wide();
+        const int tnw = wide ? TNW : TN;
+        const int tiles = ((M[o] + TM - 1) / TM) * ((N[o] + tnw - 1) / tnw);
+        sq.wide[s] = wide ? 1 : 0;
         sq.A[s] = A[s]; sq.B[s] = B[s];
         sq.part[s] = part_base[o] + (int64_t)used[o] * M[o] * N[o];
         sq.colpart[s] = (oq.colsum[o] != nullptr) ? col_base[o] + (int64_t)used[o] * M[o] : nullptr;

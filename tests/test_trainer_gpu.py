@@ -202,8 +202,15 @@ def test_captured_step_cache_with_flat_adam_recaptures_after_the_flat_layout(tmp
         runs.append((m, losses, cache))
     (m0, l0, _), (m1, l1, cache) = runs
     assert all(abs(a - b) < 3e-4 for a, b in zip(l0, l1)), (l0, l1)
+    # 12 Adam steps of lr 1e-3 move a weight by up to 1.2e-2.  The two runs differ in the optimizer arithmetic (torch's multi-tensor
+    # Adam vs the fused flat kernel), and Adam normalises every gradient: an entry whose gradient is a rounding error away from
+    # zero can move by a different +-lr per step in the two runs, so the maximum over a tensor is a lottery (5e-5 .. 1.3e-4 seen
+    # with different summation orders of the weight-gradient kernel) while the mean deviation stays at 1e-9 .. 2e-6.  Checked:
+    # the mean deviation (tight) and the worst entry against the distance one step can move it.
     for (k, x), (_, y) in zip(m0.named_parameters(), m1.named_parameters()):
-        assert float((x - y).abs().max()) < 5e-5, k
+        d = (x - y).abs()
+        assert float(d.mean()) < 1e-5, k
+        assert float(d.max()) < 1e-3, k
     assert cache.recaptures >= 1                          # the entry captured before the first optimizer step
     assert cache.hits >= 2 * 4 - 1                         # epochs 2 and 3 replay
 
