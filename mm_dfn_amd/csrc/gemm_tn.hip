@@ -274,24 +274,9 @@ struct TnOuts {
     int n;
 };
 
-// (three waves per SIMD: with the register budget of four hipcc keeps fewer operand sets in flight, 134 against 131 us at cfg2)
+// Segments flagged `wide` (outputs 100 or 200 columns wide) use 64 x 112 tiles, the others 64 x 64.  Register budget of three
+// waves per SIMD (136 VGPRs): with the default budget hipcc took 146 and the occupancy of two cost the small cfg2 batch 13 us.
 __global__ __launch_bounds__(256, 3) void gemm_tn_batch_kernel(const TnSegs sq) {
-    int p = 0;
-    while (p + 1 < sq.n && (int)blockIdx.x >= sq.wg_prefix[p + 1]) ++p;
-    const int local = blockIdx.x - sq.wg_prefix[p];
-    const int split = local / sq.tiles[p];
-    const int tile = local - split * sq.tiles[p];
-    __shared__ __attribute__((aligned(16))) float As[2][BR * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BR * LDB];
-    gemm_tn_body<false>(As, Bs, sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p],
-                        sq.rows_per_split[p], sq.bshift[p], tile, split);
-}
-
-// The same launch with 64 x 112 tiles for the segments flagged `wide`.  A kernel of its own: the seven accumulator tiles of the
-// wide form cost registers (146 against 96 VGPRs: two workgroups per CU instead of four), which a small batch -- BASELINE cfg2: few,
-// short, latency-bound workgroups -- pays for with 13 us, while the large batches (cfg3 / cfg4 / cfg5) gain 6-45 us from the better
-// tile coverage; the host picks by the size of the batch.
-__global__ __launch_bounds__(256) void gemm_tn_batch_wide_kernel(const TnSegs sq) {
     int p = 0;
     while (p + 1 < sq.n && (int)blockIdx.x >= sq.wg_prefix[p + 1]) ++p;
     const int local = blockIdx.x - sq.wg_prefix[p];
@@ -465,17 +450,6 @@ static bool tn_no_wide() { const char* e = getenv("MMDFN_TN_NO_WIDE"); return e 
 constexpr bool tn_no_wide() { return false; }
 #endif
 
-static double batch_units(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
-    double units = 0.0;                                  // sum over segments of output tiles x rows
-    for (int s = 0; s < nseg; ++s) {
-        const int o = out[s];
-        if (o < 0 || o >= nout) continue;
-        units += (double)(((M[o] + TM - 1) / TM) * ((N[o] + TN - 1) / TN)) * R[s];
-    }
-    return units;
-}
-constexpr double WIDE_BATCH_UNITS = 2.0e6;      // batches at least this large run the wide-tile kernel (cfg2: 1.4e6, cfg4: 2.8e6)
-
 static int batch_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
     double units = 0.0;                                  // sum over segments of output tiles x rows
     for (int s = 0; s < nseg; ++s) {
@@ -568,7 +542,7 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     }
     int used[TN_MAXOUT];
     for (int o = 0; o < nout; ++o) used[o] = 0;
-    const bool use_wide = !tn_no_wide() && batch_units(nseg, R, out, nout, M, N) >= WIDE_BATCH_UNITS;
+    const bool use_wide = !tn_no_wide();
     sq.n = nseg;
     sq.wg_prefix[0] = 0;
     for (int s = 0; s < nseg; ++s) {
@@ -591,8 +565,7 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
         sq.wg_prefix[s + 1] = sq.wg_prefix[nseg];
     }
     hipStream_t st = (hipStream_t)stream;
-    if (use_wide) hipLaunchKernelGGL(gemm_tn_batch_wide_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
-    else hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
     MMDFN_CHECK_LAUNCH();
     hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[nout]), dim3(256), 0, st, oq);
     MMDFN_CHECK_LAUNCH();
