@@ -107,7 +107,6 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
     if (vec_ok) {
         constexpr int LDO = 128 + 8;
         float* Os = reinterpret_cast<float*>(smem);
-        const int erow = tid >> 2, eq = tid & 3;
         __syncthreads();                               // the last step's (unused) fragment reloads have retired
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -120,30 +119,32 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
                     for (int r = 0; r < 16; ++r) Os[(lrow0 + (r & 3) + 8 * (r >> 2)) * LDO + 32 * ct + l32] = acc[ct][r];
             }
             __syncthreads();
-            const int row = 64 * pass + erow;
-            if (row < Rv) {
+            // 32 consecutive lanes write one row's 128 columns (512 contiguous bytes, whole cache lines per instruction: with
+            // four lanes per row a store instruction left 64-byte pieces, which nontemporal stores sent to memory one by one --
+            // WRITE_SIZE 279 MB for 197 MB of tiles)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + 256 * j;
+                const int er = idx >> 5, c = 4 * (idx & 31);
+                const int row = 64 * pass + er;
+                if (row >= Rv || c >= Nstore) continue;
                 float* yrow = Yb + (int64_t)row * ldy;
+                float4 v = *reinterpret_cast<const float4*>(&Os[er * LDO + c]);
+                float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = 4 * (eq + 4 * j);
-                    if (c >= Nstore) continue;
-                    float4 v = *reinterpret_cast<const float4*>(&Os[erow * LDO + c]);
-                    float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[e] = (c + e < Nv) ? o[e] + (bias ? (c + e < n1 ? bias[c + e] : bias2[c + e - n1]) : 0.f) : 0.f;
-                    if (accumulate) {
-                        const float4 old = *reinterpret_cast<const float4*>(yrow + c);
-                        o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
-                    }
-                    if (act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-                    }
-                    // (nt_store: results nobody reads soon -- the 201 MB of adjacency-gradient tiles -- go around the L2)
-                    if (nt_store) __builtin_nontemporal_store((f32x4){o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(yrow + c));
-                    else *reinterpret_cast<float4*>(yrow + c) = make_float4(o[0], o[1], o[2], o[3]);
+                for (int e = 0; e < 4; ++e)
+                    o[e] = (c + e < Nv) ? o[e] + (bias ? (c + e < n1 ? bias[c + e] : bias2[c + e - n1]) : 0.f) : 0.f;
+                if (accumulate) {
+                    const float4 old = *reinterpret_cast<const float4*>(yrow + c);
+                    o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
                 }
+                if (act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                }
+                // (nt_store: results nobody reads soon -- the 201 MB of adjacency-gradient tiles -- go around the L2)
+                if (nt_store) __builtin_nontemporal_store((f32x4){o[0], o[1], o[2], o[3]}, reinterpret_cast<f32x4*>(yrow + c));
+                else *reinterpret_cast<float4*>(yrow + c) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
         return;
