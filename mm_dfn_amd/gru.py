@@ -150,8 +150,7 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
     if torch.is_grad_enabled():
         pairs = [_layer_params(gru, layer)[0] for layer in range(2) for gru in grus]
         wcat = [_stacked_view(wf, wr) for wf, wr in pairs]
-        # the stacked input biases [b_ih; b_ih_reverse] the same way (views only: used by the forward pass of launches
-        # with few rows, which is a library GEMM on the stacked views)
+        # the stacked input biases [b_ih; b_ih_reverse] the same way (views only)
         bcat = [_stacked_view(bf, br) for bf, br in (_layer_params(gru, layer)[1] for layer in range(2) for gru in grus)]
         if any(w is None for w in wcat):
             halves = [w for pair in pairs for w in pair]

@@ -588,9 +588,9 @@ def linear_supported(x, weight):
 
 
 def linear_preferred(rows, K, N):
-    """Shapes where the MFMA kernel beats the library GEMM on MI355X (tools/bench_linear.py, round 1):
-    many rows and a short contraction (the batched party-GRU input projection, the GCN input layer, the
-    LSTM gate pre-activations).  Small-row / long-K projections stay on hipBLASLt (a plain library GEMM)."""
+    """Shapes that run on the many-row kernels (csrc/linear.hip, linear_split.hip; tools/bench_linear.py, round 1): many rows
+    and a short contraction (the batched party-GRU input projection, the GCN input layer, the LSTM gate pre-activations), or
+    many 128 x 128 tiles.  Everything else goes to the LDS-staged few-row kernel (csrc/linear_small.hip, dense_nk / dense_kn)."""
     if rows >= 4096 and K <= 256:
         return True
     # many 128 x 128 output tiles: the bf16-piece variant (csrc/linear_split.hip) also wins at long K
@@ -904,8 +904,8 @@ def _wgrad(dy2, x2, weight, bias):
 
 
 class _Linear(torch.autograd.Function):
-    """y = act(x W^T + b) (+ base).  Engine per shape: the hand-written MFMA kernels where they win
-    (linear_preferred), the library GEMM otherwise; dW / db always off the critical path (side stream)."""
+    """y = act(x W^T + b) (+ base).  Engine per shape (dense_nk): the many-row MFMA kernels where linear_preferred says so,
+    the few-row kernel otherwise; dW / db through the step's weight-gradient batch (or in line outside ops.wgrad_batch())."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, base):
@@ -1225,11 +1225,11 @@ class _Linear2(torch.autograd.Function):
         d1, d2 = dy2[:, :n1], dy2[:, n1:]
         dx = None
         if ctx.needs_input_grad[0]:
-            # the input gradient is one plain library GEMM over the stacked weight when the caller provides a stacked
-            # copy (bigru2 packs all of a step's in one launch), two accumulating GEMMs on the parameters otherwise
+            # the input gradient is one K-major launch of the few-row kernel over the stacked weight when the caller provides a
+            # stacked view (gru._stacked_view), two accumulating launches on the parameters otherwise
             if wcat is not None and dy2.shape[0] >= 16384 and linear_preferred(dy2.shape[0], dy2.shape[1], w1.shape[1]):
-                # very many rows (cfg3's 19 008 party rows: 59 us against the library's 83 us,
-                # profiles/r02_linear_vs_hipblaslt.txt): the bf16-piece kernel on the transposed stacked weight
+                # very many rows (cfg3's 19 008 party rows: 54-59 us against 67 us for the K-major few-row form,
+                # tools/bench_linear_group.py): the bf16-piece kernel on the transposed stacked weight
                 dx = linear_raw(dy2, wcat.t().contiguous(), None, 0).view(*dy.shape[:-1], w1.shape[1])
             elif wcat is not None:
                 dx = dense_kn(dy2, wcat).view(*dy.shape[:-1], w1.shape[1])
