@@ -11,6 +11,8 @@
 #include "mmdfn_internal.h"
 #include "../../include/mmdfn_hip.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <stdint.h>
 
 namespace {
 
@@ -292,6 +294,163 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_batch_kernel(const TnSegs sq) 
                             sq.rows_per_split[p], sq.bshift[p], tile, split);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tall form for LONG segments (BASELINE cfg5: 24 576 .. 98 304 rows into a 400 x 100 or 100 x 100 output).  At that length the
+// 64 x 112 tiles above are bound by the CU's vector-memory path, not by the matrix pipe: a tile moves (64 + 112) x 4 bytes per
+// row for 64 x 112 multiply-adds, three co-resident workgroups ask the L1 for ~38 of its 64 bytes per clock and the MFMA pipe
+// sits at ~52 % (hot and cold operands time the same: tools/bench_gemm_tn_tall.py).  Here ONE workgroup owns every output row of a
+// segment (up to 448 = 4 waves x 7 row tiles) x all (<= 112) columns: (400 + 100) x 4 bytes per row for 400 x 100 multiply-adds,
+// 2.5 x fewer bytes per MFMA.  The 49 accumulator tiles of a wave leave no registers for staging, so operand rows go global -> LDS
+// by LDS-DMA (global_load_lds_dwordx4: scalar chunk base + per-lane offset, destination lane-linear), rows stored back to back:
+// a row stride of M (N) floats with 16 <= M mod 64 <= 48 puts the four k rows of a fragment read in different bank groups, which is
+// what the launcher checks (400, 100, 300, 600 qualify; 200, 512 stay on the tiles above).  Columns past M / N of the last MFMA
+// tile read the next row's data: they only reach accumulator rows / columns that are never stored.
+constexpr int TBR = 16;                        // rows per staged chunk
+constexpr int TALL_MAX_M = 448, TALL_MAX_N = 112;
+
+__device__ __forceinline__ void tall_dma(uint32_t m0v, uint32_t off, const void* base) {
+    uint32_t keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(m0v), "v"(off), "s"(base) : "memory");
+}
+
+template <int RT>
+__device__ __forceinline__ void gemm_tn_tall_body(float* smem, const float* __restrict__ A, const float* __restrict__ B,
+                                                  float* __restrict__ part, float* __restrict__ colpart, int R, int M, int NT,
+                                                  int lda, int ldb, int rows_per_split, int split, int col0, int N) {
+    // (NT: columns of the whole output; this workgroup owns columns col0 .. col0 + N - 1 of it, N = the segment's block width --
+    //  the last block of an output may hold fewer: its surplus columns re-fetch valid ones and are not stored)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, g = lane >> 4;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+    const int nchunks = (r_end - r_begin) / TBR;                     // R and rows_per_split are multiples of TBR
+    const int a_st = (TBR * M * 4 + 1023) & ~1023, b_st = (TBR * N * 4 + 1023) & ~1023;     // bytes per stage
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) void*)smem);
+    const int nrt = (M + 15) >> 4;                                   // MFMA row tiles of the output
+    int nvt = nrt - w * RT;                                          // row tiles of this wave
+    nvt = nvt < 0 ? 0 : (nvt > RT ? RT : nvt);
+
+    // DMA slots of this wave: instruction j = w + 4 i moves operand pieces 64 j .. 64 j + 63 of a chunk (piece = 16 bytes,
+    // row-major over the TBR x M block); lanes past the last piece re-fetch the last one into the stage's padding
+    const int pa = TBR * (M >> 2), pb = TBR * (N >> 2);
+    uint32_t aoff[RT], boff[2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        int q = (w + 4 * i) * 64 + lane;
+        q = q < pa ? q : pa - 1;
+        const int row = q / (M >> 2), cp = q - row * (M >> 2);
+        aoff[i] = (uint32_t)(row * lda + cp * 4) * 4u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int q = (w + 4 * i) * 64 + lane;
+        q = q < pb ? q : pb - 1;
+        const int row = q / (N >> 2), cp = q - row * (N >> 2);
+        const int col = col0 + cp * 4;
+        boff[i] = (uint32_t)(row * ldb + (col < NT ? col : col0)) * 4u;
+    }
+    auto issue = [&](int c) {
+        const int st = c & 1;
+        const float* ab = A + (int64_t)(r_begin + c * TBR) * lda;
+        const float* bb = B + (int64_t)(r_begin + c * TBR) * ldb;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+            if ((w + 4 * i) * 64 < pa) tall_dma(lds0 + st * a_st + (w + 4 * i) * 1024, aoff[i], ab);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if ((w + 4 * i) * 64 < pb) tall_dma(lds0 + 2 * a_st + st * b_st + (w + 4 * i) * 1024, boff[i], bb);
+    };
+
+    f32x4 acc[RT][7];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) csum[i] = 0.f;
+
+    const int a_lane = g * M + 16 * RT * w + fi, b_lane = g * N + fi;      // float offsets of the lane's fragment elements
+    if (nchunks > 0) issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c are in LDS ...
+        __syncthreads();                                      // ... and everybody's; stage (c + 1) & 1 is no longer being read
+        if (c + 1 < nchunks) issue(c + 1);
+        const float* as = smem + (c & 1) * (a_st >> 2) + a_lane;
+        const float* bs = smem + 2 * (a_st >> 2) + (c & 1) * (b_st >> 2) + b_lane;
+#pragma unroll
+        for (int ks = 0; ks < TBR / 4; ++ks) {
+            const float* ak = as + 4 * ks * M;
+            const float* bk = bs + 4 * ks * N;
+            float av[RT], bv[7];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) av[i] = ak[16 * i];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) bv[j] = bk[16 * j];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) csum[i] += av[i];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                if (i < nvt) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    float* P = part + (int64_t)split * M * NT;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int n = 16 * j + fi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * (RT * w + i) + 4 * g + r;
+                if (m < M && n < N && col0 + n < NT) P[(int64_t)m * NT + col0 + n] = acc[i][j][r];
+            }
+        }
+    if (colpart != nullptr && col0 == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            float v = csum[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int m = 16 * (RT * w + i) + fi;
+            if (g == 0 && m < M) colpart[(int64_t)split * M + m] = v;
+        }
+    }
+}
+
+// The launch of a big batch: tall segments (TnSegs: tiles = column blocks of the output, wide = their width >= 64, bshift unused)
+// first, the batch's other segments on the tiled bodies behind them in the SAME grid -- their short workgroups fill the CUs the
+// last tall ones leave idle (as a launch of their own they were 93 us of mostly empty chip at cfg5).
+__global__ __launch_bounds__(256, 2) void gemm_tn_tall_kernel(const TnSegs sq) {
+    extern __shared__ __attribute__((aligned(16))) float tall_smem[];
+    int p = 0;
+    while (p + 1 < sq.n && (int)blockIdx.x >= sq.wg_prefix[p + 1]) ++p;
+    const int local = blockIdx.x - sq.wg_prefix[p];
+    const int split = local / sq.tiles[p];
+    const int tile = local - split * sq.tiles[p];
+    if (sq.wide[p] >= 64) {
+#define TALL_ARGS tall_smem, sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p], \
+                  sq.rows_per_split[p], split, tile * sq.wide[p], sq.wide[p]
+        if (sq.M[p] > 128) gemm_tn_tall_body<7>(TALL_ARGS);
+        else gemm_tn_tall_body<2>(TALL_ARGS);
+#undef TALL_ARGS
+        return;
+    }
+    float(*As)[BR * LDA] = reinterpret_cast<float(*)[BR * LDA]>(tall_smem);
+    float* Bs = tall_smem + 2 * BR * LDA;
+    if (sq.wide[p])
+        gemm_tn_body<true>(As, Bs, sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p],
+                           sq.rows_per_split[p], sq.bshift[p], tile, split);
+    else
+        gemm_tn_body<false>(As, Bs, sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p],
+                            sq.rows_per_split[p], sq.bshift[p], tile, split);
+}
+
 __global__ void gemm_tn_batch_reduce_kernel(const TnOuts oq) {
     int p = 0;
     while (p + 1 < oq.n && (int)blockIdx.x >= oq.blk_prefix[p + 1]) ++p;
@@ -450,11 +609,12 @@ static bool tn_no_wide() { const char* e = getenv("MMDFN_TN_NO_WIDE"); return e 
 constexpr bool tn_no_wide() { return false; }
 #endif
 
-static int batch_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
-    double units = 0.0;                                  // sum over segments of output tiles x rows
+static bool tn_tall_shape1(int R, int M, int N);
+static int batch_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N, bool tall_on) {
+    double units = 0.0;                                  // sum over segments of output tiles x rows (tiled form only)
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
-        if (o < 0 || o >= nout) continue;
+        if (o < 0 || o >= nout || (tall_on && tn_tall_shape1(R[s], M[o], N[o]))) continue;
         units += (double)(((M[o] + TM - 1) / TM) * ((N[o] + TN - 1) / TN)) * R[s];
     }
     double wgs = 3072.0;
@@ -467,6 +627,58 @@ static int batch_rows_target(int nseg, const int* R, const int* out, int nout, c
     if (rt < 1000) rt = 1000;
     if (rt > rt_max) rt = rt_max;
     return rt;
+}
+
+// Tall form (gemm_tn_tall_kernel): the long segments of a BIG batch.  A segment qualifies by shape (rows a multiple of 16, at
+// least 8192; 64 .. 128 or 336 .. 448 output rows = 2 or 7 row tiles per wave; 64 .. 112 columns -- the kernel also cuts wider
+// outputs into column blocks, but the 100 x 200 / 200 x 512 segments of cfg5 measured slower that way than on the tiles: every
+// block re-reads the A rows and a 4 096-row projection makes too few workgroups); the form is used when the qualifying segments together hold enough matrix work to
+// put a 768-row workgroup of the 49-tile kind (or its equivalent) on most CUs -- the dialogue-graph batches (cfg2 .. cfg4: a few
+// thousand rows per segment) stay on the tiles above, whose many small workgroups fill the chip there.
+// Rows per workgroup (tools/bench_gemm_tn_tall.py, cfg5 with 8 and 32 dialogues): the batch time is flat between ~250 and ~1000
+// workgroups of the 49-tile kind and rises on both sides (fewer: CUs idle behind the last ones; more: partial outputs to write and
+// reduce), so aim at ~384 of them, 768 .. 3072 rows each; the lighter kinds 1536 .. 3072 rows.
+constexpr int TALL_MIN_R = 8192;
+constexpr double TALL_MIN_COST = 192.0 * 768 * 49;      // (rows x accumulator tiles per wave, summed over column blocks)
+static int tall_kind(int M) { return M > 128 ? 7 : 2; }
+static int tall_blocks(int N) { return (N + TALL_MAX_N - 1) / TALL_MAX_N; }
+static int tall_block_width(int N) { const int nb = tall_blocks(N); return ((N + nb - 1) / nb + 3) / 4 * 4; }
+static bool tn_tall_shape1(int R, int M, int N) {
+    return R >= TALL_MIN_R && (R % TBR) == 0 && N >= 64 && N <= TALL_MAX_N && M >= 64 && M <= TALL_MAX_M && !(M > 128 && M < 336);
+}
+struct TallPlan { bool on; int rows7, rows2; };
+// (from the segment shapes alone, so that the workspace query and the launch agree)
+static TallPlan tall_plan(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
+    double tot7 = 0.0, tot2 = 0.0, cost = 0.0;
+    for (int s = 0; s < nseg; ++s) {
+        const int o = out[s];
+        if (o < 0 || o >= nout || !tn_tall_shape1(R[s], M[o], N[o])) continue;
+        const int k = tall_kind(M[o]), nb = tall_blocks(N[o]);
+        (k == 7 ? tot7 : tot2) += (double)R[s] * nb;
+        cost += (double)R[s] * nb * 7 * k;
+    }
+    TallPlan p;
+    p.on = cost >= TALL_MIN_COST;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_TN_NO_TALL")) if (atoi(e)) p.on = false;
+#endif
+    p.rows7 = (int)(tot7 / 384.0);
+    p.rows2 = (int)(tot2 / 256.0);
+    p.rows7 = p.rows7 < 768 ? 768 : (p.rows7 > 3072 ? 3072 : p.rows7);
+    p.rows2 = p.rows2 < 1536 ? 1536 : (p.rows2 > 3072 ? 3072 : p.rows2);
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_TN_TALL_ROWS7")) p.rows7 = atoi(e);
+    if (const char* e = getenv("MMDFN_TN_TALL_ROWS2")) p.rows2 = atoi(e);
+#endif
+    return p;
+}
+static int tall_eff_splits(int R, int M, const TallPlan& plan, int* rps_out) {
+    const int target = M > 128 ? plan.rows7 : plan.rows2;
+    int splits = (R + target - 1) / (target > 0 ? target : 1);
+    if (splits < 1) splits = 1;
+    const int rps = ((R + splits - 1) / splits + TBR - 1) / TBR * TBR;
+    if (rps_out) *rps_out = rps;
+    return (R + rps - 1) / rps;
 }
 
 static int batch_eff_splits(int R, int M, int N, int rows_target, int* rps_out) {
@@ -483,11 +695,14 @@ static int batch_eff_splits(int R, int M, int N, int rows_target, int* rps_out) 
 extern "C" int64_t mmdfn_gemm_tn_batch_workspace(int nseg, const int* R, const int* out, int nout, const int* M,
                                                  const int* N) {
     int64_t total = 0;
-    const int rt = batch_rows_target(nseg, R, out, nout, M, N);
+    const TallPlan plan = tall_plan(nseg, R, out, nout, M, N);
+    const int rt = batch_rows_target(nseg, R, out, nout, M, N, plan.on);
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout) return -1;
-        total += (int64_t)batch_eff_splits(R[s], M[o], N[o], rt, nullptr) * ((int64_t)M[o] * N[o] + M[o]);
+        int eff = batch_eff_splits(R[s], M[o], N[o], rt, nullptr);
+        if (plan.on && tn_tall_shape1(R[s], M[o], N[o])) eff = std::max(eff, tall_eff_splits(R[s], M[o], plan, nullptr));   // (either form may run)
+        total += (int64_t)eff * ((int64_t)M[o] * N[o] + M[o]);
     }
     return total;
 }
@@ -501,7 +716,9 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     TnOuts oq;
     // pass 1: splits per output (its segments stack their slabs)
     int out_splits[TN_MAXOUT], seg_eff[TN_MAXSEG], seg_rps[TN_MAXSEG];
-    const int rt = batch_rows_target(nseg, R, out, nout, M, N);
+    bool seg_tall[TN_MAXSEG];
+    const TallPlan plan = tall_plan(nseg, R, out, nout, M, N);
+    const int rt = batch_rows_target(nseg, R, out, nout, M, N, plan.on);
     for (int o = 0; o < nout; ++o) {
         out_splits[o] = 0;
         if (M[o] <= 0 || N[o] <= 0 || (M[o] & 3) || (N[o] & 3) || ldc[o] < N[o]) return -1;
@@ -509,7 +726,9 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout || R[s] <= 0 || (lda[s] & 3) || (ldb[s] & 3) || lda[s] < M[o] || ldb[s] < N[o]) return -1;
-        seg_eff[s] = batch_eff_splits(R[s], M[o], N[o], rt, &seg_rps[s]);
+        seg_tall[s] = plan.on && tn_tall_shape1(R[s], M[o], N[o]) && (bshift == nullptr || bshift[s] == 0) &&
+                      (((uintptr_t)A[s] | (uintptr_t)B[s]) & 15) == 0;
+        seg_eff[s] = seg_tall[s] ? tall_eff_splits(R[s], M[o], plan, &seg_rps[s]) : batch_eff_splits(R[s], M[o], N[o], rt, &seg_rps[s]);
         out_splits[o] += seg_eff[s];
     }
     // workspace layout: per output [splits][M][N] then [splits][M]
@@ -543,29 +762,51 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     int used[TN_MAXOUT];
     for (int o = 0; o < nout; ++o) used[o] = 0;
     const bool use_wide = !tn_no_wide();
+    // order: tall segments first, the 49-tile kind before the 14-tile kind (longest workgroups first; alternating the two kinds
+    // measured 15 % slower), then the segments on the tiled bodies
+    int order[TN_MAXSEG], no = 0, ntall = 0;
+    for (int pass = 0; pass < 3; ++pass)
+        for (int s = 0; s < nseg; ++s) {
+            const int kind = !seg_tall[s] ? 2 : (tall_kind(M[out[s]]) == 7 ? 0 : 1);
+            if (kind != pass) continue;
+            order[no++] = s;
+            if (seg_tall[s]) ++ntall;
+        }
+    size_t tall_lds = ntall > 0 ? (size_t)(2 * BR * LDA + 2 * BS_FLOATS) * sizeof(float) : 0;    // (the tiled bodies' stages)
     sq.n = nseg;
     sq.wg_prefix[0] = 0;
-    for (int s = 0; s < nseg; ++s) {
+    for (int k = 0; k < nseg; ++k) {
+        const int s = order[k];
         const int o = out[s];
-        const bool wide = use_wide && tn_wide(N[o]);
+        const bool wide = !seg_tall[s] && use_wide && tn_wide(N[o]);
         const int tnw = wide ? TNW : TN;
-        const int tiles = ((M[o] + TM - 1) / TM) * ((N[o] + tnw - 1) / tnw);
-        sq.wide[s] = wide ? 1 : 0;
-        sq.A[s] = A[s]; sq.B[s] = B[s];
-        sq.part[s] = part_base[o] + (int64_t)used[o] * M[o] * N[o];
-        sq.colpart[s] = (oq.colsum[o] != nullptr) ? col_base[o] + (int64_t)used[o] * M[o] : nullptr;
+        const int tiles = seg_tall[s] ? tall_blocks(N[o]) : ((M[o] + TM - 1) / TM) * ((N[o] + tnw - 1) / tnw);
+        sq.wide[k] = seg_tall[s] ? tall_block_width(N[o]) : (wide ? 1 : 0);
+        sq.A[k] = A[s]; sq.B[k] = B[s];
+        sq.part[k] = part_base[o] + (int64_t)used[o] * M[o] * N[o];
+        sq.colpart[k] = (oq.colsum[o] != nullptr) ? col_base[o] + (int64_t)used[o] * M[o] : nullptr;
         used[o] += seg_eff[s];
-        sq.R[s] = R[s]; sq.lda[s] = lda[s]; sq.ldb[s] = ldb[s]; sq.bshift[s] = bshift ? bshift[s] : 0;
-        sq.rows_per_split[s] = seg_rps[s]; sq.tiles[s] = tiles; sq.M[s] = M[o]; sq.N[s] = N[o];
-        sq.wg_prefix[s + 1] = sq.wg_prefix[s] + tiles * seg_eff[s];
+        sq.R[k] = R[s]; sq.lda[k] = lda[s]; sq.ldb[k] = ldb[s]; sq.bshift[k] = bshift ? bshift[s] : 0;
+        sq.rows_per_split[k] = seg_rps[s]; sq.tiles[k] = tiles; sq.M[k] = M[o]; sq.N[k] = N[o];
+        sq.wg_prefix[k + 1] = sq.wg_prefix[k] + tiles * seg_eff[s];
+        if (seg_tall[s]) {
+            const int bw = tall_block_width(N[o]);
+            const size_t need = 2 * (size_t)(((TBR * M[o] * 4 + 1023) & ~1023) + ((TBR * bw * 4 + 1023) & ~1023)) + 1024;
+            if (need > tall_lds) tall_lds = need;
+        }
     }
     for (int s = nseg; s < TN_MAXSEG; ++s) {
-        sq.A[s] = sq.B[s] = nullptr; sq.part[s] = sq.colpart[s] = nullptr;
+        sq.A[s] = sq.B[s] = nullptr; sq.part[s] = sq.colpart[s] = nullptr; sq.wide[s] = 0;
         sq.R[s] = sq.lda[s] = sq.ldb[s] = sq.bshift[s] = sq.rows_per_split[s] = sq.tiles[s] = sq.M[s] = sq.N[s] = 0;
         sq.wg_prefix[s + 1] = sq.wg_prefix[nseg];
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
+    if (ntall > 0) {
+        if (int e = mmdfn_allow_big_lds(gemm_tn_tall_kernel)) return e;
+        hipLaunchKernelGGL(gemm_tn_tall_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), tall_lds, st, sq);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
+    }
     MMDFN_CHECK_LAUNCH();
     hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[nout]), dim3(256), 0, st, oq);
     MMDFN_CHECK_LAUNCH();

@@ -454,6 +454,59 @@ def test_weight_gradient_batch_kernel():
         assert rel_err(c3, Ad.sum(0)) < 1e-5, (Mo, No, Rr, sh)
 
 
+def test_weight_gradient_batch_tall_segments():
+    """A batch with enough long segments (cfg5-sized graph-stack backward) runs them on the one-workgroup-per-output-slab form
+    (gemm_tn_tall_kernel, LDS-DMA operand rows): 400 x 100 (7 row tiles per wave), 100 x 100 (2), 336 x 80 (the last wave holds
+    no row tile); in the same launch, on the tiled bodies: short, shifted, odd-row-count, 200-column and 200 x 512 segments; several
+    segments per output, strided views, column sums, accumulate -- against fp64."""
+    rs = np.random.RandomState(77)
+    t = lambda *shape: torch.from_numpy(rs.randn(*shape).astype(np.float32)).to(DEV)
+    H = 100
+    Rl = 8192 + 16 * 37
+    dG = [t(Rl, 4 * H), t(24576, 4 * H), t(640, 4 * H)]               # tall, tall (used by six segments), short (tiled form)
+    q = [t(Rl, 2 * H)[:, H:], t(24576, H), t(640, H)]                 # (a strided view as the B operand)
+    reps = [0, 1, 1, 1, 1, 1, 1, 2]
+    hi, dP = t(12288, H + 4)[:, 4:], t(12288, H)                     # 100 x 100
+    a5, b5 = t(9600, 336), t(9600, 80)
+    a6, b6 = t(16384, 100), t(16384, 200)
+    a7, b7 = t(8192, 400), t(8192, 100)                              # shifted: tiled form
+    a9, b9 = t(4096, 200), t(4096, 512)
+    a10, b10 = t(4100, 100), t(4100, 100)                            # rows not a multiple of 16: tiled form
+    w = [torch.empty(4 * H, H, device=DEV), t(H, H), torch.empty(336, 80, device=DEV), torch.empty(100, 200, device=DEV),
+         torch.empty(400, 100, device=DEV), torch.empty(200, 512, device=DEV), torch.empty(100, 100, device=DEV)]
+    b = [torch.empty(4 * H, device=DEV), torch.empty(4 * H, device=DEV), t(H), torch.empty(336, device=DEV),
+         torch.empty(200, device=DEV)]
+    old_w1, old_b2 = w[1].clone(), b[2].clone()
+    batch = [(dict(M=4 * H, N=H), w[0], [b[0], b[1]], 0, [(dG[i], q[i], 0) for i in reps]),
+             (dict(M=H, N=H), w[1], [b[2]], 1, [(hi, dP, 0)]),
+             (dict(M=336, N=80), w[2], [b[3]], 0, [(a5, b5, 0)]),
+             (dict(M=100, N=200), w[3], [], 0, [(a6, b6, 0)]),
+             (dict(M=400, N=100), w[4], [], 0, [(a7, b7, 3)]),
+             (dict(M=200, N=512), w[5], [b[4]], 0, [(a9, b9, 0)]),
+             (dict(M=100, N=100), w[6], [], 0, [(a10, b10, 0)])]
+    ops._launch_wgrad_batch(batch)
+    d = lambda x: x.double().cpu()
+    assert rel_err(w[0], sum(d(dG[i]).t() @ d(q[i]) for i in reps)) < 1e-5
+    assert rel_err(b[0], sum(d(dG[i]).sum(0) for i in reps)) < 1e-5 and torch.equal(b[0], b[1])
+    assert rel_err(w[1], d(old_w1) + d(hi).t() @ d(dP)) < 1e-5
+    assert rel_err(b[2], d(old_b2) + d(hi).sum(0)) < 1e-5
+    assert rel_err(w[2], d(a5).t() @ d(b5)) < 1e-5 and rel_err(b[3], d(a5).sum(0)) < 1e-5
+    assert rel_err(w[3], d(a6).t() @ d(b6)) < 1e-5
+    assert rel_err(w[4], d(a7)[:-3].t() @ d(b7)[3:]) < 1e-5
+    assert rel_err(w[5], d(a9).t() @ d(b9)) < 1e-5 and rel_err(b[4], d(a9).sum(0)) < 1e-5
+    assert rel_err(w[6], d(a10).t() @ d(b10)) < 1e-5
+    # non-finite values in one operand row reach exactly the outputs that row feeds (the tall form reads a few floats past a row's
+    # end into accumulator rows / columns that are never stored)
+    a8, b8 = t(8192, 100), t(8192, 100)
+    a8[4097, 99] = float("inf")
+    b8[:, 99] = 0.0
+    b8[5000, 99] = float("inf")
+    o8 = torch.empty(100, 100, device=DEV)
+    big = (dict(M=4 * H, N=H), w[0], [], 0, [(dG[1], q[1], 0)] * 7)      # (enough work in the batch for the tall form)
+    ops._launch_wgrad_batch([big, (dict(M=100, N=100), o8, [], 0, [(a8, b8, 0)])])
+    assert torch.isfinite(o8[:99, :99]).all() and not torch.isfinite(o8[99]).any() and not torch.isfinite(o8[:, 99]).any()
+
+
 @pytest.mark.parametrize("R,K,n1,n2", [(300, 200, 300, 300), (7040, 200, 300, 300), (129, 36, 4, 100), (2000, 100, 260, 52),
                                        (16640, 200, 300, 300)])      # (>= 16384 rows: the input gradient on the hand-written kernel)
 def test_two_block_projection(R, K, n1, n2):
