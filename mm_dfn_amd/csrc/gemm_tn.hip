@@ -296,15 +296,15 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_batch_kernel(const TnSegs sq) 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Tall form for LONG segments (BASELINE cfg5: 24 576 .. 98 304 rows into a 400 x 100 or 100 x 100 output).  At that length the
-// 64 x 112 tiles above are bound by the CU's vector-memory path, not by the matrix pipe: a tile moves (64 + 112) x 4 bytes per
-// row for 64 x 112 multiply-adds, three co-resident workgroups ask the L1 for ~38 of its 64 bytes per clock and the MFMA pipe
-// sits at ~52 % (hot and cold operands time the same: tools/bench_gemm_tn_tall.py).  Here ONE workgroup owns every output row of a
-// segment (up to 448 = 4 waves x 7 row tiles) x all (<= 112) columns: (400 + 100) x 4 bytes per row for 400 x 100 multiply-adds,
-// 2.5 x fewer bytes per MFMA.  The 49 accumulator tiles of a wave leave no registers for staging, so operand rows go global -> LDS
-// by LDS-DMA (global_load_lds_dwordx4: scalar chunk base + per-lane offset, destination lane-linear), rows stored back to back:
-// a row stride of M (N) floats with 16 <= M mod 64 <= 48 puts the four k rows of a fragment read in different bank groups, which is
-// what the launcher checks (400, 100, 300, 600 qualify; 200, 512 stay on the tiles above).  Columns past M / N of the last MFMA
-// tile read the next row's data: they only reach accumulator rows / columns that are never stored.
+// 64 x 112 tiles above keep the matrix pipe 64 % busy, a fifth of it on padding (400 rows = 7 x 64 = 448, 100 columns on 112), LDS
+// 43 % busy, and every tile moves (64 + 112) x 4 bytes per row through L1 for 64 x 112 multiply-adds (hot and cold operands time
+// the same: tools/bench_gemm_tn_tall.py; counters: profiles/r03_stack_kernels_pmc.md).  Here ONE workgroup owns every output row
+// of a segment (up to 448 = 4 waves x 7 row tiles; a 400-row output is issued as 25 row tiles) x all (<= 112) columns: (400 + 100)
+// x 4 bytes per row for 400 x 100 multiply-adds, 2.5 x fewer bytes per MFMA, a third of the LDS cycles, 10 % fewer MFMA cycles.
+// The 49 accumulator tiles of a wave leave no registers for staging, so operand rows go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: scalar chunk base + per-lane offset, destination lane-linear), rows stored back to back (row stride M
+// or N floats: the fragment reads conflict ~40 % of the time at 400 / 100, which costs ~1 % here).  Columns past M / N of the last
+// MFMA tile read the next row's data: they only reach accumulator rows / columns that are never stored.
 constexpr int TBR = 16;                        // rows per staged chunk
 constexpr int TALL_MAX_M = 448, TALL_MAX_N = 112;
 
