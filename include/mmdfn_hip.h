@@ -341,6 +341,9 @@ int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W,
  *                               layer-shared LSTM gate (model_GCN.py:466) gets one segment per GCN layer and no
  *                               gradient-accumulation kernel.
  * nseg, nout <= 40.  All arrays are HOST arrays.  workspace: mmdfn_gemm_tn_batch_workspace(...) floats.
+ * Kernel form per batch (an implementation choice, results do not depend on it beyond fp32 summation order): 64 x 64 / 64 x 112
+ * output tiles with the rows split over workgroups, or -- when the batch holds enough long segments (>= 8192 rows, a multiple
+ * of 16, 64-128 or 336-448 output rows, 64-112 columns, no shift) -- one workgroup per whole-output slab for those.
  * ------------------------------------------------------------------------- */
 int64_t mmdfn_gemm_tn_batch_workspace(int nseg, const int* R, const int* out, int nout, const int* M, const int* N);
 int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
