@@ -314,7 +314,8 @@ __device__ __forceinline__ void tall_dma(uint32_t m0v, uint32_t off, const void*
                  : "=&s"(keep) : "s"(m0v), "v"(off), "s"(base) : "memory");
 }
 
-template <int RT>
+// ABL (tuning build, timing only): 1 no operand DMA, 2 no wait / barrier, 4 no fragment reads, 8 no MFMAs
+template <int RT, int ABL = 0>
 __device__ __forceinline__ void gemm_tn_tall_body(float* smem, const float* __restrict__ A, const float* __restrict__ B,
                                                   float* __restrict__ part, float* __restrict__ colpart, int R, int M, int NT,
                                                   int lda, int ldb, int rows_per_split, int split, int col0, int N) {
@@ -374,9 +375,11 @@ __device__ __forceinline__ void gemm_tn_tall_body(float* smem, const float* __re
     const int a_lane = g * M + 16 * RT * w + fi, b_lane = g * N + fi;      // float offsets of the lane's fragment elements
     if (nchunks > 0) issue(0);
     for (int c = 0; c < nchunks; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c are in LDS ...
-        __syncthreads();                                      // ... and everybody's; stage (c + 1) & 1 is no longer being read
-        if (c + 1 < nchunks) issue(c + 1);
+        if (!(ABL & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c are in LDS ...
+            __syncthreads();                                      // ... and everybody's; stage (c + 1) & 1 is no longer being read
+        }
+        if (c + 1 < nchunks && !(ABL & 1)) issue(c + 1);
         const float* as = smem + (c & 1) * (a_st >> 2) + a_lane;
         const float* bs = smem + 2 * (a_st >> 2) + (c & 1) * (b_st >> 2) + b_lane;
 #pragma unroll
@@ -384,18 +387,27 @@ __device__ __forceinline__ void gemm_tn_tall_body(float* smem, const float* __re
             const float* ak = as + 4 * ks * M;
             const float* bk = bs + 4 * ks * N;
             float av[RT], bv[7];
+            if (ABL & 4) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i) av[i] = ak[16 * i];
+                for (int i = 0; i < RT; ++i) av[i] = 1.0f + i + (float)c;
 #pragma unroll
-            for (int j = 0; j < 7; ++j) bv[j] = bk[16 * j];
+                for (int j = 0; j < 7; ++j) bv[j] = 2.0f + j + (float)c;
+            } else {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) av[i] = ak[16 * i];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) bv[j] = bk[16 * j];
+            }
 #pragma unroll
             for (int i = 0; i < RT; ++i) csum[i] += av[i];
 #pragma unroll
             for (int i = 0; i < RT; ++i)
                 if (i < nvt) {
 #pragma unroll
-                    for (int j = 0; j < 7; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 7; ++j) {
+                        if (ABL & 8) acc[i][j][0] += av[i] * bv[j];
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    }
                 }
         }
     }
@@ -426,6 +438,7 @@ __device__ __forceinline__ void gemm_tn_tall_body(float* smem, const float* __re
 // The launch of a big batch: tall segments (TnSegs: tiles = column blocks of the output, wide = their width >= 64, bshift unused)
 // first, the batch's other segments on the tiled bodies behind them in the SAME grid -- their short workgroups fill the CUs the
 // last tall ones leave idle (as a launch of their own they were 93 us of mostly empty chip at cfg5).
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void gemm_tn_tall_kernel(const TnSegs sq) {
     extern __shared__ __attribute__((aligned(16))) float tall_smem[];
     int p = 0;
@@ -436,8 +449,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tall_kernel(const TnSegs sq) {
     if (sq.wide[p] >= 64) {
 #define TALL_ARGS tall_smem, sq.A[p], sq.B[p], sq.part[p], sq.colpart[p], sq.R[p], sq.M[p], sq.N[p], sq.lda[p], sq.ldb[p], \
                   sq.rows_per_split[p], split, tile * sq.wide[p], sq.wide[p]
-        if (sq.M[p] > 128) gemm_tn_tall_body<7>(TALL_ARGS);
-        else gemm_tn_tall_body<2>(TALL_ARGS);
+        if (sq.M[p] > 128) gemm_tn_tall_body<7, ABL>(TALL_ARGS);
+        else gemm_tn_tall_body<2, ABL>(TALL_ARGS);
 #undef TALL_ARGS
         return;
     }
@@ -802,8 +815,23 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     }
     hipStream_t st = (hipStream_t)stream;
     if (ntall > 0) {
-        if (int e = mmdfn_allow_big_lds(gemm_tn_tall_kernel)) return e;
-        hipLaunchKernelGGL(gemm_tn_tall_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), tall_lds, st, sq);
+        void (*kern)(const TnSegs) = gemm_tn_tall_kernel<0>;
+#ifdef MMDFN_TUNING
+        if (const char* e = getenv("MMDFN_TN_TALL_ABL")) {       // tools/bench_gemm_tn_tall.py
+            switch (atoi(e)) {
+                case 1: kern = gemm_tn_tall_kernel<1>; break;
+                case 2: kern = gemm_tn_tall_kernel<2>; break;
+                case 4: kern = gemm_tn_tall_kernel<4>; break;
+                case 6: kern = gemm_tn_tall_kernel<6>; break;
+                case 7: kern = gemm_tn_tall_kernel<7>; break;
+                case 8: kern = gemm_tn_tall_kernel<8>; break;
+                case 12: kern = gemm_tn_tall_kernel<12>; break;
+                default: break;
+            }
+        }
+#endif
+        if (int e = mmdfn_allow_big_lds(kern)) return e;
+        hipLaunchKernelGGL(kern, dim3(sq.wg_prefix[nseg]), dim3(256), tall_lds, st, sq);
     } else {
         hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
     }

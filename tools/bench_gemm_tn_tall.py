@@ -23,13 +23,17 @@ def make_batch(hot):
         batch.append((dict(M=H, N=H), conv[i][:H], [], 0, [(hi[i % n], dP[i % n], 0)]))
         batch.append((dict(M=H, N=H), conv[i][H:], [], 0, [(h0, dP[i % n], 0)]))
     # the stack's input layer (100 x 200) and the six stream projections (200 x 512, B x 512 rows each)
+    if os.environ.get("TALL_ONLY"):      # only the 31 graph-stack segments
+        return batch
     dpre, xd = t(R, H), t(R, 2 * H)
     batch.append((dict(M=H, N=2 * H), t(H, 2 * H), [t(H)], 0, [(dpre, xd, 0)]))
     for m in range(6):
         batch.append((dict(M=2 * H, N=512), t(2 * H, 512), [t(2 * H)], 0, [(t(B * 512, 2 * H), t(B * 512, 512), 0)]))
     return batch
 
-flops = 2.0 * R * H * (4 * H * (2 * LAYERS - 1) + H * 2 * LAYERS) + 2.0 * R * H * 2 * H + 6 * 2.0 * B * 512 * 2 * H * 512
+flops = 2.0 * R * H * (4 * H * (2 * LAYERS - 1) + H * 2 * LAYERS)
+if not os.environ.get("TALL_ONLY"):
+    flops += 2.0 * R * H * 2 * H + 6 * 2.0 * B * 512 * 2 * H * 512
 for hot in (False, True):
     batch = make_batch(hot)
     for env in sys.argv[2:] or ["MMDFN_TN_NO_TALL=1", "MMDFN_TN_NO_TALL=0"]:
