@@ -1,6 +1,10 @@
 """Weight-gradient batch of a BASELINE cfg5 graph-stack backward (8 layers: LSTM-gate segments 400 x 100 from dG^T q and dG^T h,
 GCN-layer segments 100 x 100) timed as ONE mmdfn_gemm_tn_batch call: tall form against the 64 x 112 tiles
-(MMDFN_TN_NO_TALL=1, tuning build), rotating operand sets against one hot set.   python tools/bench_gemm_tn_tall.py [B]"""
+(MMDFN_TN_NO_TALL=1, tuning build), rotating operand sets against one hot set.
+    python tools/bench_gemm_tn_tall.py [B] [ENV=V[,ENV=V...] ...]     one timed run per argument after B
+TALL_ONLY=1 in the environment: only the 31 graph-stack segments.  MMDFN_TN_TALL_ABL=1|2|4|6|7|8|12: compile-time ablations of
+the tall form (1 no operand DMA, 2 no wait / barrier, 4 no fragment reads, 8 no MFMAs; timing only).  MMDFN_TN_TALL_ROWS7 /
+MMDFN_TN_TALL_ROWS2: rows per workgroup of the 49- / 14-tile kind."""
 import os, sys
 os.environ["MMDFN_TUNING_LIB"] = "1"
 import torch
