@@ -442,7 +442,8 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
         return small_rows ? launch<2, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s)
                           : launch<4, 8>(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len, 1, s);
     }
-    const int ov = tuning_override();   // 0-7: f32-MFMA tilings, 8: bf16-piece kernel, 9: never the bf16-piece kernel
+    // 0-7: f32-MFMA tilings, 8: bf16-piece kernel, 9: never a bf16-piece kernel, 10: producer / consumer bf16-piece kernel
+    const int ov = tuning_override();
     if (ov >= 0) {
         switch (ov) {
             case 0: return V2(4, 1, 7, 16, 1);
@@ -456,6 +457,12 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
             case 8: {
                 const int rc = mmdfn_launch_propagate_split(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d,
                                                             ldh, ldo, max_len, s);
+                if (rc != -2) return rc;
+                break;
+            }
+            case 10: {
+                const int rc = mmdfn_launch_propagate_pc(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d,
+                                                         ldh, ldo, max_len, s);
                 if (rc != -2) return rc;
                 break;
             }
