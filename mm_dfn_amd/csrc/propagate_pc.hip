@@ -21,13 +21,19 @@
 // One s_barrier per 32-wide chunk separates "stage s is being written" from "stage s is being read" (two stages).  The
 // matrix pipe therefore runs through prologue, cutting and epilogue of the neighbouring items instead of waiting for them.
 //
-// The producers only LOAD from global memory and the consumers only STORE (the finished rows go back through the LDS row
-// buffer: a producer adds the cross-modal terms in place, a consumer wave stores the slice one period later between two
-// MFMA groups).  gfx950 has one counter for loads and stores and hipcc falls back to s_waitcnt vmcnt(0) whenever both kinds
-// are in flight in a wave, which would serialise the row stores with the requests running four chunks ahead; with the
-// kinds separated the compiler's own counted waits are exact.  (A first version issued the producers' loads and stores
-// from inline asm with hand-counted waits: a register copy the compiler is free to insert between such a load and its
-// wait -- it believes the value is already there -- made it fault with one template instance; not kept.)
+// All vector-memory instructions of the producers are issued from inline asm and retired with hand-counted s_waitcnt:
+//   * gfx950 has one counter for loads and stores and hipcc falls back to vmcnt(0) whenever both kinds are in flight in a
+//     wave, which would serialise the row stores with the requests running four chunks ahead;
+//   * with compiler-managed loads the register allocator recycles a request's destination registers as temporaries as
+//     soon as the previous value is dead, and the waits it then has to insert keep barely one and a half chunks in
+//     flight (measured: the tile-strip producers became latency-bound, 129 us per launch).
+// Loads return in order among themselves, so "at most Y operations outstanding", Y = the number of loads issued after the
+// ones needed, is sufficient whatever the stores do.  The price: between such a load and its wait the compiler believes
+// the destination already holds the value, so it must never copy or touch it.  Every asm load therefore has exactly ONE
+// site per period in straight-line code (no load inside a branch whose result would meet another definition in a phi),
+// the register sets are never initialised (a phi with undef needs no copy), and tools/verify_pc_asm.py checks in the
+// generated ISA that the registers named by every wait are the ones written by the matching load and that nothing in
+// between mentions them (tests/test_pc_kernel_asm.py runs it on the library's own sources).
 //
 // Item order: item t <-> (dialogue, modality, row block) with t % 8 == dialogue % 8, workgroup g takes t = g, g + G, ...
 // (G a multiple of 8), so every tile of a dialogue is served by one XCD's L2 as in the other K6 kernels.
@@ -51,7 +57,7 @@ constexpr int PC_EOFF = 2 * PC_STAGE;      // row buffer of the finished item be
 constexpr int PC_ES = 116;                 // its row stride in floats (d <= 112)
 constexpr int PC_LDS = PC_EOFF + PC_BM * PC_ES * 4;   // 157 696 B
 constexpr int PC_NE = 8;                   // the finished item's rows leave in PC_NE slices (16 rows per period)
-constexpr int PC_MINP = PC_NE + 2;         // periods per item: the slices are finished in periods 0 .. NE-1 and stored in 1 .. NE, the next rows are parked in the last
+constexpr int PC_MINP = PC_NE + 1;         // periods per item (>= the slices + the period that parks the next rows)
 constexpr int PC_NS = 4;                   // register sets of chunk requests = how many periods they run ahead of the MFMAs
 constexpr int PC_LEAD = PC_NS;             // lead-in periods
 
@@ -66,8 +72,8 @@ __device__ __forceinline__ f32x16 pc_mfma(u32x4 a, u32x4 b, f32x16 c) {
 __device__ __forceinline__ void pc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- the stream of periods a workgroup walks through (identical, wave-uniform bookkeeping in all eight waves) ----
-//   lead-in (4 periods: the producers fill the pipeline)  ->  items (max(chunks, 10) periods each)  ->  drain (9 periods:
-//   the last item's rows are finished and stored)  ->  end
+//   lead-in (4 periods: the producers fill the pipeline)  ->  items (max(chunks, 9) periods each)  ->  drain (8 periods:
+//   the last item's rows are finished)  ->  end
 struct PcCursor {
     int state;          // 0 lead-in, 1 item, 2 drain, 3 end
     int c, P, nch;      // period inside the state, periods of the state, chunks of the item
@@ -112,7 +118,7 @@ __device__ __forceinline__ void pc_next_item(PcCursor& k, const PcArgs& a) {
     }
     k.state = 2;
     k.c = 0;
-    k.P = PC_NE + 1;
+    k.P = PC_NE;
     k.nch = 0;
 }
 
@@ -127,6 +133,16 @@ __device__ __forceinline__ void pc_advance(PcCursor& k, const PcArgs& a) {
     }
     pc_next_item(k, a);
 }
+
+// (the comment behind an instruction names its registers for tools/verify_pc_asm.py)
+#define PC_GLD4(DST, VOFF, SBASE) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 ; pc-load" : "=&v"(DST) : "v"(VOFF), "s"(SBASE) : "memory")
+#define PC_GLD1(DST, VOFF, SBASE) \
+    asm volatile("global_load_dword %0, %1, %2 ; pc-load" : "=&v"(DST) : "v"(VOFF), "s"(SBASE) : "memory")
+// (s_nop: a wide store's data registers must not be overwritten in the two issue slots behind it; hipcc's hazard
+// recogniser does not see instructions inside inline asm)
+#define PC_GST4(VOFF, SRC, SBASE) \
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(VOFF), "v"(SRC), "s"(SBASE) : "memory")
 
 template <int MX>   // MX = M - 1 other modalities (compile time: their rows are all in flight at once)
 __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
@@ -159,6 +175,9 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
 #define PC_STAMP(V) (void)0
 #endif
 
+#ifdef MMDFN_TUNING
+    if (w < 8 ? (abl & 256) : (abl & 128)) __builtin_amdgcn_s_setprio(3);     // 128: producers, 256: consumers at priority 3
+#endif
     if (w < 8) {
         // =========================== consumer: fragment reads + MFMAs ===========================
         // wave (rw = w & 3, ch = w >> 2): tile rows 32 rw .. + 31, feature columns 64 ch .. + 63 (two 32-column tiles).
@@ -187,33 +206,6 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
         // parked row (r) of accumulator tile ct: row 32 rw + 4 kg + (r & 3) + 8 (r >> 2), column 64 ch + 32 ct + l32
         float* const Ebuf = reinterpret_cast<float*>(pc_smem + PC_EOFF);
         const int ebase = (32 * rw + 4 * kg) * PC_ES + 64 * ch + l32;
-        // the finished item whose rows are in the LDS row buffer: slice c (rows 16 c .. + 15) gets its cross-modal terms from
-        // the producers in the next item's period c and is stored by the consumers in period c + 1: wave w takes rows
-        // 16 c + 2 w + (lane >> 5), 16 bytes at column 4 (lane & 31)
-        bool has_prev = false;
-        int prev_m = 0, prev_grow0 = 0, prev_rows = 0;
-        const int c4 = lane & 31;
-        const int cw4 = d >> 2;
-        const int c4c = c4 < cw4 ? c4 : cw4 - 1;
-
-        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float* sdst = out;
-        bool sok = false;
-        auto load_slice = [&]() {
-            const bool sact = has_prev && (cons.state == 1 || cons.state == 2) && cons.c >= 1 && cons.c <= PC_NE && !(abl & 4);
-            sok = false;
-            if (sact) {
-                const int rl = 16 * (cons.c - 1) + 2 * w + (lane >> 5);
-                sok = (rl < prev_rows) && (c4 < cw4);
-                const int rlc = rl < prev_rows ? rl : prev_rows - 1;
-                sv = *reinterpret_cast<const f32x4*>(Ebuf + rlc * PC_ES + 4 * c4c);
-                sdst = out + ((long long)prev_m * N + prev_grow0 + rlc) * ldo + 4 * c4c;
-            }
-        };
-        auto store_slice = [&]() {
-            if (sok) *reinterpret_cast<f32x4*>(sdst) = sv;
-            sok = false;
-        };
         auto chunk = [&](auto par_) {
             constexpr int PAR = decltype(par_)::value;
             const unsigned char* S = pc_smem + PAR * PC_STAGE;
@@ -239,8 +231,7 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
             lda(1, 2); ldb(1, 0);
             __builtin_amdgcn_sched_barrier(0);
             mm(0, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            store_slice();                          // (its LDS read was issued in front of the fragment reads)
+
             __builtin_amdgcn_sched_barrier(0);
             lda(1, 1); lda(1, 0); ldb(1, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -259,7 +250,6 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
 #endif
         auto period = [&](auto par_) {
             PC_STAMP(s0);
-            load_slice();
             if (cons.state == 1) {
                 if (cons.c == 0) {
 #pragma unroll
@@ -268,9 +258,8 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
                         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
                 }
                 if (cons.c < cons.nch && !(abl & 1)) chunk(par_);
-                store_slice();                      // (a period without a chunk)
                 if (cons.c == cons.P - 1) {
-                    // park the finished rows (the previous item's last slice was stored >= 1 period ago)
+                    // park the finished rows (the producers read the previous item's last slice >= 1 period ago)
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
                         if (64 * ch + 32 * ct + l32 < d) {
@@ -280,19 +269,12 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
                         }
                 }
             }
-            store_slice();                          // (drain periods)
             PC_STAMP(s1);
             pc_barrier();
             PC_STAMP(s2);
 #ifdef MMDFN_TUNING
             if (cons.state == 1 && cons.c < cons.nch) { tm_chunk += s1 - s0; tm_bar += s2 - s1; tm_n += 1; }
 #endif
-            if (cons.state == 1 && cons.c == cons.P - 1) {
-                has_prev = true;
-                prev_m = cons.m;
-                prev_grow0 = cons.rs + cons.r0;
-                prev_rows = cons.L - cons.r0 < PC_BM ? cons.L - cons.r0 : PC_BM;
-            }
             pc_advance(cons, args);
         };
         while (cons.state != 3) {   // four periods per trip like the producers (two LDS stages, four request sets)
@@ -337,11 +319,7 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
     const int b_lds = PC_OPER + 4 * cg * 64 + (((hB >> 1) ^ (cg & 3)) << 4) + ((hB & 1) << 3);
     const int b_x = cg & 3;
 
-    f32x4 raw[PC_NS][4];
-#pragma unroll
-    for (int s = 0; s < PC_NS; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) raw[s][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 raw[PC_NS][4];      // (never initialised: see the note on asm loads at the top)
 
     // the request cursor runs PC_NS periods ahead of the consumers; what it pointed at PC_NS - 1 periods ago is cut now
     PcCursor ldc = cons;
@@ -363,25 +341,27 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
 
     // ---- chunk requests, one load at a time (spread over the cutting work of a period: every load holds the wave at
     // issue for as long as the compute unit's address path takes to accept it, ~70 cycles with all producers loading)
-    const float* ld_ptr = H;               // B: this lane's next row;  A: this lane's column of the strip
-    long long ld_step = 0;
+    uint32_t ld_voff = 0, ld_step = 0;     // B: running row offset;  A: column offset of the chunk
     int ld_left = 0;
+    const float* ld_base = H;
     auto begin_loads = [&](auto isb_) {
         constexpr bool isB = decltype(isb_)::value;
-        // a bubble period re-reads the cursor's last item (its fields stay valid): every period issues the same loads
+        // a bubble period re-reads the cursor's last item (its fields stay valid): unconditional loads keep the counts exact
         const int k0 = (ldc.state == 1 && ldc.c < ldc.nch) ? ldc.c * PC_BK : 0;
         if (isB) {
+            ld_base = H + ((long long)ldc.m * N + ldc.rs) * ldh;
             // rows past the dialogue: the last one again (masked when they are cut)
             int kr = k0 + 4 * hB;
             kr = kr < ldc.L ? kr : ldc.L - 1;
-            ld_ptr = H + ((long long)ldc.m * N + ldc.rs + kr) * ldh + 4 * cgc;
-            ld_step = ldh;
+            ld_voff = (uint32_t)kr * (uint32_t)ldh * 4u + b_voff;
+            ld_step = (uint32_t)ldh * 4u;
             ld_left = ldc.L - 1 - kr;          // rows that follow inside the dialogue
         } else {
+            ld_base = tiles + ldc.tb;
             int ka = k0 + 4 * qA;
             ka = ka < ldc.ld - 4 ? ka : ldc.ld - 4;
-            ld_ptr = tiles + ldc.tb + ka;
-            ld_step = ldc.ld;
+            ld_voff = (uint32_t)ka * 4u;
+            ld_step = (uint32_t)ldc.ld * 4u;
             ld_left = ldc.L - 1;
         }
     };
@@ -389,13 +369,17 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
         constexpr bool isB = decltype(isb_)::value;
         constexpr int SET = decltype(set_)::value;
         constexpr int J = decltype(j_)::value;
+        auto& raw_ = raw;      // (clang: operands of an asm statement inside a generic lambda do not capture by themselves)
+        const float* const ld_base_ = ld_base;
         if (isB) {
-            raw[SET][J] = *reinterpret_cast<const f32x4*>(ld_ptr);
-            ld_ptr += (J < ld_left) ? ld_step : 0;
+            const uint32_t voff = ld_voff;
+            PC_GLD4(raw_[SET][J], voff, ld_base_);
+            ld_voff += (J < ld_left) ? ld_step : 0u;
         } else {
             int row = ldc.r0 + arow0 + 8 * J;
             row = row < ld_left ? row : ld_left;
-            raw[SET][J] = *reinterpret_cast<const f32x4*>(ld_ptr + row * ld_step);
+            const uint32_t voff = (uint32_t)row * ld_step + ld_voff;
+            PC_GLD4(raw_[SET][J], voff, ld_base_);
         }
     };
 
@@ -442,6 +426,16 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
         *reinterpret_cast<u32x2*>(dst + 2 * PC_PIECE) = p3;
     };
 
+    // wait until at most Y vector-memory operations are outstanding (Y = loads issued after the ones tied here)
+    auto wait_raw = [&](auto set_, auto y_) {
+        constexpr int SET = decltype(set_)::value;
+        constexpr int Y = decltype(y_)::value;
+        auto& raw_ = raw;
+        asm volatile("s_waitcnt vmcnt(%[y]) ; pc-wait %0 %1 %2 %3"
+                     : "+v"(raw_[SET][0]), "+v"(raw_[SET][1]), "+v"(raw_[SET][2]), "+v"(raw_[SET][3])
+                     : [y] "i"(Y) : "memory");
+    };
+
 #ifdef MMDFN_TUNING
     long long tp_issue = 0, tp_wait = 0, tp_cut = 0, tp_epi = 0, tp_bar = 0;
 #endif
@@ -455,42 +449,76 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
         constexpr int SET = decltype(set_)::value;
         using CUTSET = std::integral_constant<int, (SET + 1) % PC_NS>;     // chunk p + 1, requested PC_NS - 1 periods ago
         using CUTSTAGE = std::integral_constant<int, PAR ^ 1>;
-        // ---- a slice of the previous item's rows (16 bytes of one row per thread): + the cross-modal diagonals, in place
+        // ---- a slice of the previous item's rows (16 bytes of one row per thread)
         const bool eact = has_prev && (cons.state == 1 || cons.state == 2) && cons.c < PC_NE && !(abl & 4);
         f32x4 eh[MX];
         float ew[MX];
-        float* eptr = const_cast<float*>(Ebuf);
+        uint32_t eo = 0, ehoff = 0, ewoff = 0;
+        int erow = 0;
+        bool ev = false;
+        uint32_t sH[MX], sW[MX];       // byte offsets of the other modalities' H blocks / pair diagonals (scalar)
+#pragma unroll
+        for (int q = 0; q < MX; ++q) { sH[q] = 0; sW[q] = 0; }
         if (eact) {
-            const int rl = 16 * cons.c + 2 * pw + (lane >> 5);
-            const int rlc = rl < prev_rows ? rl : prev_rows - 1;     // (rows past the item: a valid row again, never stored)
-            const long long grow = prev_grow0 + rlc;
-            eptr = const_cast<float*>(Ebuf) + rlc * PC_ES + 4 * c4c;
 #pragma unroll
             for (int q = 0; q < MX; ++q) {
                 const int n = q + (q >= prev_m ? 1 : 0);
                 const int pk = (prev_m < n) ? mmdfn_pair_index(prev_m, n, M) : mmdfn_pair_index(n, prev_m, M);
-                eh[q] = *reinterpret_cast<const f32x4*>(H + ((long long)n * N + grow) * ldh + 4 * c4c);
-                ew[q] = cross[(long long)pk * N + grow];
+                sH[q] = (uint32_t)n * (uint32_t)N * (uint32_t)ldh * 4u;
+                sW[q] = (uint32_t)pk * (uint32_t)N * 4u;
             }
+            const int rl = 16 * cons.c + 2 * pw + (lane >> 5);
+            erow = rl;
+            ev = (rl < prev_rows) && (c4 < cw4);
+            const int rlc = rl < prev_rows ? rl : prev_rows - 1;
+            const uint32_t grow = (uint32_t)(prev_grow0 + rlc);
+            ehoff = (grow * (uint32_t)ldh + 4u * (uint32_t)c4c) * 4u;
+            ewoff = grow * 4u;
+            eo = (grow * (uint32_t)ldo + 4u * (uint32_t)c4c) * 4u;
         }
+        // slice loads q, spread over items 0 and 1 (ONE asm site per load: the values meet nothing but undef at the join)
+        auto slice_loads = [&](auto j_) {
+            constexpr int J = decltype(j_)::value;
+            auto& eh_ = eh;
+            auto& ew_ = ew;
+            const float* const H_ = H;
+            const float* const cross_ = cross;
+            if (J < 2 && eact) {
+#pragma unroll
+                for (int q = (MX * J) / 2; q < (MX * (J + 1)) / 2; ++q) {
+                    const uint32_t ho = ehoff + sH[q];
+                    const uint32_t wo = ewoff + sW[q];
+                    PC_GLD4(eh_[q], ho, H_);
+                    PC_GLD1(ew_[q], wo, cross_);
+                }
+            }
+        };
         begin_loads(isb_);
         cut_lim = cutq_L[0] - cutq_k0[0] - (isB ? 4 * hB : 4 * qA);    // ragged last chunk: strip columns / H rows >= L are zero
         const bool docut = cutq_real[0] && !(abl & 2);
         PC_STAMP(q1);
+        // ---- chunk p + 1 (requested PC_NS - 1 periods ago): the 4 (PC_NS - 2) requests of chunks p + 2 .. p + PC_NS - 1
+        //      are younger
+        wait_raw(CUTSET{}, std::integral_constant<int, 4 * (PC_NS - 2)>{});
         PC_STAMP(q2);
-        // ---- chunk p + 1 (requested PC_NS - 1 periods ago) is cut, chunk p + PC_NS requested, one quarter at a time
+        // ---- it is cut and chunk p + PC_NS requested, one quarter at a time (the loads stand OUTSIDE the branch)
         auto item = [&](auto j_) {
             if (docut) cut_item(isb_, CUTSET{}, CUTSTAGE{}, j_);
             issue_load(isb_, set_, j_);
+            slice_loads(j_);
         };
         item(I0{});
         item(I1{});
         item(I2{});
         item(I3{});
         PC_STAMP(q3);
-        // ---- finish the slice (the consumers store it one period later)
+        // ---- finish the slice: chunk loads 2 and 3 are younger than its operands
         if (eact) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(eptr);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < MX; ++q) asm volatile("; pc-wait %0 %1" : "+v"(eh[q]), "+v"(ew[q]));
+            const float* ob = out + (long long)prev_m * N * ldo;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ebuf + erow * PC_ES + 4 * c4c);
 #pragma unroll
             for (int q = 0; q < MX; ++q) {
                 const float cwt = ew[q];
@@ -500,7 +528,7 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
                 v.z = fmaf(cwt, h.z, v.z);
                 v.w = fmaf(cwt, h.w, v.w);
             }
-            *reinterpret_cast<f32x4*>(eptr) = v;
+            if (ev && !(abl & 8)) PC_GST4(eo, v, ob);
         }
         PC_STAMP(q4);
         pc_barrier();
@@ -543,6 +571,7 @@ __global__ __launch_bounds__(1024, 4) void propagate_pc_kernel(
             period(std::false_type{}, I1{}, I3{});
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MMDFN_TUNING
     if ((abl & 64) && (tid == 512 || tid == 768)) {
         float* o = out + blockIdx.x * 16 + (tid == 512 ? 5 : 10);
@@ -580,7 +609,7 @@ int pc_num_cus() {
 int mmdfn_launch_propagate_pc(const float* tiles, const float* cross, const float* H, float* out,
                               const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                               int B, int M, int N, int d, int ldh, int ldo, int max_len, hipStream_t s) {
-    if ((d & 3) || d > 112 || d < 4 || M < 2 || M > 6) return -2;
+    if ((d & 3) || d > 112 || d < 4 || (M != 2 && M != 3 && M != 6)) return -2;
     // 32-bit byte offsets from the base pointers inside the kernel
     const long long big = (long long)M * N * (ldh > ldo ? ldh : ldo) * 4;
     const long long pairs = (long long)M * (M - 1) / 2 * N * 4;
@@ -596,12 +625,11 @@ int mmdfn_launch_propagate_pc(const float* tiles, const float* cross, const floa
         hipLaunchKernelGGL((propagate_pc_kernel<MXV>), dim3(G), dim3(1024), PC_LDS, s, tiles, cross, H, out, dia_len, \
                            row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, n_items, pc_ablation());              \
     } while (0)
-    switch (M) {
+    switch (M) {                 // (instantiated for the modality counts of the reference and of BASELINE cfg5)
         case 2: PC_LAUNCH(1); break;
         case 3: PC_LAUNCH(2); break;
-        case 4: PC_LAUNCH(3); break;
-        case 5: PC_LAUNCH(4); break;
-        default: PC_LAUNCH(5); break;
+        case 6: PC_LAUNCH(5); break;
+        default: return -2;
     }
 #undef PC_LAUNCH
     MMDFN_CHECK_LAUNCH();
