@@ -196,6 +196,21 @@ class DevicePrefetcher:
         with torch.cuda.stream(stream):
             dev = []
             for t in tensors:
+                if t.dim() == 3 and t.dtype == torch.float32 and t.shape[-1] % 4:
+                    # feature width not a multiple of 4 (1582-d audio, 342-d visual features): the pinned staging buffer
+                    # is row-padded to the next multiple of 4 (pad columns zero), so the device copy is the operand the
+                    # MFMA kernels fetch in 16-byte units (ops.py "row padding") -- no pad launch on the device
+                    from . import ops
+                    K, Kp = t.shape[-1], ops.pad4(t.shape[-1])
+                    h = torch.empty(t.shape[0], t.shape[1], Kp, dtype=torch.float32, pin_memory=True)
+                    hn = h.numpy()
+                    hn[..., :K] = t.numpy()
+                    hn[..., K:] = 0.0
+                    base = ops.register_row_padded(h.to(self.device, non_blocking=True))
+                    view = base[..., :K]
+                    view._mmdfn_padbase = base
+                    dev.append(view)
+                    continue
                 h = t if t.is_pinned() else t.pin_memory()
                 dev.append(h.to(self.device, non_blocking=True))
             ev = torch.cuda.Event()

@@ -69,6 +69,68 @@ def bucket_order(model, live):
     return out
 
 
+# ---- flat-buffer slots.  A parameter occupies ``slot_size(p)`` floats of the flat gradient / parameter / moment buffers:
+# its element count rounded up to a multiple of 4 (every slot starts 16-byte aligned: the kernels fetch weight rows in
+# 16-byte units), or rows x padded width for a dense weight whose contraction width is not a multiple of 4 (ops.py,
+# "row padding": the parameter and its gradient are (N, K) views of (N, Kp) blocks whose pad columns are zero).
+def _row_padded(p):
+    return p.dim() == 2 and p.shape[1] % 4 != 0
+
+
+def slot_size(p):
+    if _row_padded(p):
+        return p.shape[0] * ((p.shape[1] + 3) & ~3)
+    return (p.numel() + 3) & ~3
+
+
+def slot_view(flat, off, p):
+    """The tensor of p's shape that lives in flat[off : off + slot_size(p)]."""
+    if _row_padded(p):
+        Kp = (p.shape[1] + 3) & ~3
+        return flat[off:off + p.shape[0] * Kp].view(p.shape[0], Kp)[:, :p.shape[1]]
+    return flat[off:off + p.numel()].view_as(p)
+
+
+_ZERO_PAD = {}     # (device, n) -> n zeros: the tail of a slot whose parameter has numel % 4 != 0 (entries are never replaced)
+
+
+def slot_pieces(t, p):
+    """1-D tensors that, concatenated, hold ``t`` (a value of p's shape) in slot layout: no copy when ``t`` already has
+    that layout (a row-padded view written by the weight-gradient batch; an aligned contiguous tensor), a cached run of
+    zeros behind a value whose element count is not a multiple of 4 (so packing stays ONE torch.cat per step)."""
+    n = slot_size(p)
+    if _row_padded(p):
+        Kp = (p.shape[1] + 3) & ~3
+        full = None
+        if t.is_cuda:
+            from . import ops
+            full = ops.row_padded_view(t)
+        if full is None:
+            full = t.new_zeros(p.shape[0], Kp)
+            full[:, :p.shape[1]].copy_(t)
+        return [full.reshape(-1)]
+    flat = t.reshape(-1)
+    if n == flat.numel():
+        return [flat]
+    key = (t.device, n - flat.numel())
+    z = _ZERO_PAD.get(key)
+    if z is None:
+        z = _ZERO_PAD[key] = torch.zeros(n - flat.numel(), dtype=t.dtype, device=t.device)
+    return [flat, z]
+
+
+def register_slots(flat, params):
+    """Tell ops.py which blocks of ``flat`` are row-padded weights (their pad columns are zero and nobody writes them)."""
+    if not flat.is_cuda:
+        return
+    from . import ops
+    off = 0
+    for p in params:
+        if _row_padded(p):
+            ops.register_row_padded(flat, (flat.storage_offset() + off, p.shape[0], (p.shape[1] + 3) & ~3))
+        off += slot_size(p)
+
+
 class GradientBucket:
     """Flat fp32 gradient bucket over the parameters that receive gradients.
 
@@ -98,9 +160,10 @@ class GradientBucket:
             raise RuntimeError("GradientBucket: the set of parameters receiving gradients changed since the first step "
                                "(new: %s; missing: %s)" % (sorted(names[i] for i in now - was),
                                                            sorted(names[i] for i in was - now)))
-        grads = [p.grad.reshape(-1) for p in self.params]
+        grads = [piece for p in self.params for piece in slot_pieces(p.grad, p)]
         if self.flat is None:
             self.flat = torch.cat(grads)
+            register_slots(self.flat, self.params)
         else:
             torch.cat(grads, out=self.flat)
         self.attach_views()
@@ -109,9 +172,8 @@ class GradientBucket:
     def attach_views(self):
         off = 0
         for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+            p.grad = slot_view(self.flat, off, p)
+            off += slot_size(p)
 
     def reduce_flat(self):
         dist.all_reduce(self.flat)

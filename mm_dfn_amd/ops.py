@@ -24,6 +24,144 @@ def _rows_view(t, rows):
     return t
 
 
+
+# ---------------------------------------------------------------------------------------------------
+# Contraction widths that are not multiples of 4 (the reference's own feature widths: 1582-d IS10 audio, 342-d denseface,
+# run_train_erc.py:359-362).  The MFMA kernels fetch operand rows in 16-byte units, so such a layer runs as the layer of
+# the next multiple of 4 whose extra input features are exactly zero: the rows of both operands live in storage padded to
+# that width (pad columns zero), and every kernel -- projection, weight gradient, optimizer -- sees the padded width.  The
+# result is bit-identical to the unpadded contraction (the extra terms are 0 * 0) and no step launches anything extra:
+#   * the PARAMETER keeps its (N, K) shape and state_dict entry but is a row-strided view of an (N, Kp) buffer
+#     (ensure_row_padded re-points .data once, like gru._stacked_view does for the GRU weight pairs); its gradient is the
+#     same kind of view; FlatAdam / GradientBucket give such a parameter an N * Kp slot;
+#   * FEATURES arrive padded from whoever stages them (data.DevicePrefetcher's pinned buffer, the static input buffers of
+#     train.StepGraphCache, synthetic.make_batch); a plain contiguous (..., K) tensor handed to the modules is copied into
+#     a padded buffer first (pad_rows: the one place where an odd width costs a launch).
+# Only buffers registered here are trusted to have zero pad columns.
+# ---------------------------------------------------------------------------------------------------
+_PAD_REG = {}      # storage data_ptr -> [(weakref to the owning (rows, Kp) tensor, storage offset, rows, Kp)]
+
+
+def pad4(n):
+    return (int(n) + 3) & ~3
+
+
+def register_row_padded(base, region=None):
+    """``base``: a contiguous (..., Kp) fp32 tensor whose columns past the logical width are zero and stay zero (nobody
+    writes them).  Views of its leading columns are recognised as row-padded operands WHILE THE ``base`` OBJECT IS ALIVE
+    (the registry holds a weak reference: whoever stages the buffer keeps it).  ``region = (storage offset, rows, Kp)``
+    registers a padded block inside a larger flat buffer ``base`` (FlatAdam's parameter slots)."""
+    import weakref
+    if region is None:
+        b2 = base.view(-1, base.shape[-1])
+        region = (b2.storage_offset(), b2.shape[0], b2.shape[1])
+    key = base.untyped_storage().data_ptr()
+    live = [e for e in _PAD_REG.get(key, []) if e[0]() is not None and (e[0]() is not base or e[1:] != tuple(region))]
+    live.append((weakref.ref(base),) + tuple(int(v) for v in region))
+    _PAD_REG[key] = live
+    if len(_PAD_REG) > 4096:                      # stale keys of freed buffers
+        for k in [k for k, v in _PAD_REG.items() if all(e[0]() is None for e in v)]:
+            del _PAD_REG[k]
+    return base
+
+
+def padded_zeros(shape, device, keep=None):
+    """Logical (..., K) view of a fresh zero buffer whose last dimension is padded to a multiple of 4.  The caller must keep
+    the returned BASE alive for as long as views of it are used (``keep``: a list it is appended to); returns the view."""
+    *lead, K = shape
+    Kp = pad4(K)
+    base = torch.zeros(*lead, Kp, dtype=torch.float32, device=device)
+    if Kp == K:
+        return base
+    register_row_padded(base)
+    if keep is not None:
+        keep.append(base)
+    view = base[..., :K]
+    view._mmdfn_padbase = base          # (keeps the base alive while this particular view object lives)
+    return view
+
+
+def pad_rows(x, keep=None):
+    """A row-padded copy of ``x`` (..., K) (one zero fill + one copy): the generic entry for features that do not come
+    from a padded staging buffer."""
+    v = padded_zeros(tuple(x.shape), x.device, keep)
+    v.copy_(x)
+    return v
+
+
+def row_padded_view(x2):
+    """(R, Kp) view of a registered row-padded operand ``x2`` (R, K), or None."""
+    if x2.dim() != 2 or x2.dtype != torch.float32 or (x2.shape[1] > 1 and x2.stride(1) != 1):
+        return None
+    R, K = x2.shape
+    Kp = pad4(K)
+    ents = _PAD_REG.get(x2.untyped_storage().data_ptr())
+    if not ents or x2.data_ptr() % 16:
+        return None
+    for ref, off, rows, width in ents:
+        if ref() is None or width != Kp:
+            continue
+        rel = x2.storage_offset() - off
+        if rel < 0 or rel % Kp or rel // Kp + R > rows or (R > 1 and x2.stride(0) != Kp):
+            continue
+        return x2.as_strided((R, Kp), (Kp, 1))
+    return None
+
+
+def row_operand(x2, keep=None):
+    """The (R, K') operand the kernels contract over: ``x2`` itself when K % 4 == 0, else its zero-padded form (the
+    registered view, or a padded copy)."""
+    if x2.shape[1] % 4 == 0:
+        return x2
+    v = row_padded_view(x2)
+    if v is None:
+        v = row_padded_view(pad_rows(x2, keep))
+    return v
+
+
+def ensure_row_padded(p):
+    """Parameter (N, K) with K % 4 != 0: re-point ``p.data`` ONCE at the leading columns of a zero-padded (N, Kp) buffer
+    (same values, same shape, same state_dict entry).  Parameters laid out by FlatAdam already are."""
+    if p.dim() != 2 or p.shape[1] % 4 == 0 or row_padded_view(p.data) is not None:
+        return p
+    if getattr(p, "_mmdfn_flat", False):
+        raise _hip.HipLibraryError("a flat-laid-out parameter lost its row padding")
+    with torch.no_grad():
+        base = torch.zeros(p.shape[0], pad4(p.shape[1]), dtype=p.dtype, device=p.device)
+        base[:, :p.shape[1]].copy_(p.data)
+        register_row_padded(base)
+        p.data = base[:, :p.shape[1]]
+        p._mmdfn_padbase = base
+        if p.grad is not None:
+            p.grad = None if not p.grad.any() else padded_grad_like(p, p.grad)
+    return p
+
+
+def padded_grad_like(p, g=None):
+    """Gradient tensor for a row-padded parameter: (N, K) view of a zero (N, Kp) buffer (optionally holding ``g``)."""
+    base = torch.zeros(p.shape[0], pad4(p.shape[1]), dtype=torch.float32, device=p.device)
+    register_row_padded(base)
+    view = base[:, :p.shape[1]]
+    view._mmdfn_padbase = base
+    if g is not None:
+        view.copy_(g)
+    return view
+
+
+def weight_operand(w):
+    """(N, K') form of a dense layer's weight (N, K): the parameter itself when K % 4 == 0, else the padded view of its
+    storage (leaf parameters are re-laid once, ensure_row_padded; anything else is copied)."""
+    if w.shape[1] % 4 == 0:
+        return w
+    v = row_padded_view(w.detach() if w.requires_grad else w)
+    if v is not None:
+        return v
+    if w.is_leaf and w.requires_grad and not getattr(w, "_mmdfn_flat", False):
+        ensure_row_padded(w)
+        return row_padded_view(w.detach())
+    return row_padded_view(pad_rows(w.detach()))
+
+
 def propagate_raw(tiles, cross, H, lay, transpose=False, out=None):
     """out = A . H  (or A^T . H) for block-tile A; H: (M*N, d) fp32 (row-strided views accepted)."""
     _hip.require_cuda(tiles, H)
@@ -558,33 +696,38 @@ def linear_group_supported(R, K, N):
 def dense_nk(x2, weight, bias=None, act=0, out=None, accumulate=False):
     """act(x2 W^T + b) (+ out) for W stored (N, K).  Engine per shape, both hand-written: the many-row kernels where they
     win (linear_preferred: csrc/linear.hip, linear_split.hip), the LDS-staged few-row kernel (csrc/linear_small.hip)
-    otherwise.  Only a contraction width that is not a multiple of 4 (rows that cannot be fetched in 16-byte units) is
-    left to the library GEMM."""
+    otherwise.  A contraction width that is not a multiple of 4 runs on the zero-padded operands (row_operand /
+    weight_operand above): there is no library GEMM on any path."""
+    if weight.shape[1] % 4:
+        x2, weight = row_operand(x2), weight_operand(weight)
     N, K = weight.shape
-    if K % 4 == 0 and K >= 4:
-        if linear_preferred(x2.shape[0], K, N):
-            return linear_raw(x2, weight, bias, act, out=out, accumulate=accumulate)
-        q = dict(x=x2, w=weight, b=bias)
-        if out is not None:
-            q.update(out=out, accumulate=accumulate)
-        return linear_group_raw([q], act)[0]
-    y = torch.nn.functional.linear(x2, weight, bias)
-    if accumulate:
-        y = out.add_(y)
-    return torch.relu_(y) if act else y
+    if K < 4:
+        raise _hip.HipLibraryError("dense_nk: empty contraction")
+    if linear_preferred(x2.shape[0], K, N):
+        return linear_raw(x2, weight, bias, act, out=out, accumulate=accumulate)
+    q = dict(x=x2, w=weight, b=bias)
+    if out is not None:
+        q.update(out=out, accumulate=accumulate)
+    return linear_group_raw([q], act)[0]
 
 
 def dense_kn(x2, wk):
     """x2 @ wk for wk stored (K, N) (an input gradient dX = dY . W read as stored; GraphConvolution.weight): the few-row
-    kernel's K-major form; widths that are not multiples of 4 go to the library GEMM."""
+    kernel's K-major form.  K (the rows of wk) not a multiple of 4: the contraction runs over zero-padded copies; N (the
+    row length of wk) not a multiple of 4: over the row-padded form of wk, the result is cut back to N columns."""
     K, N = wk.shape
-    if K % 4 == 0 and K >= 4 and N % 4 == 0:
-        return linear_group_raw([dict(x=x2, wk=wk)])[0]
-    return x2 @ wk
+    if K % 4:
+        x2 = row_operand(x2)
+        wkp = torch.zeros(pad4(K), wk.shape[1], dtype=wk.dtype, device=wk.device)
+        wkp[:K].copy_(wk)
+        wk = wkp
+    if N % 4:
+        return linear_group_raw([dict(x=x2, wk=weight_operand(wk))])[0][:, :N]
+    return linear_group_raw([dict(x=x2, wk=wk)])[0]
 
 
 def linear_supported(x, weight):
-    return x.is_cuda and x.dtype == torch.float32 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 4
+    return x.is_cuda and x.dtype == torch.float32 and weight.shape[1] >= 4
 
 
 def linear_preferred(rows, K, N):
@@ -746,7 +889,8 @@ def queue_wgrad(A, B, weight, biases=(), shift=0, rows=None):
         if all(b is not x for x in out["biases"]):
             out["biases"].append(b)
     if (len(out["biases"]) > 2 or (A.shape[1], B.shape[1]) != (out["M"], out["N"]) or out["rows"] != (r0, r1)
-            or r1 - r0 != out["M"] or weight.shape[1] != out["N"] or (rows is not None and biases)):
+            or r1 - r0 != out["M"] or pad4(weight.shape[1]) != pad4(out["N"]) or out["N"] < weight.shape[1]
+            or (rows is not None and biases)):
         raise RuntimeError("queue_wgrad: inconsistent contributions to one parameter")
     out["segs"].append((A, B, int(shift)))
     if not _WGQ["armed"]:
@@ -799,17 +943,28 @@ def _flush_outs(outs, side):
         have = [w.grad is not None and id(w) not in fresh] + [b.grad is not None for b in o["biases"]]
         acc = any(have)
         full = o["rows"] == (0, w.shape[0])
+        padded = o["N"] != w.shape[1]            # odd-width layer: the batch writes the row-padded (rows, Kp) gradient
         if w.grad is None:
             # row ranges that together cover the parameter (GraphConvolution.weight: [hi^T dP ; h0^T dP]) need no
             # zero fill; a range that leaves rows nobody writes does
             whole = covered[id(w)] >= w.shape[0]
-            w.grad = (torch.empty if (whole and not acc) else torch.zeros)(tuple(w.shape), dtype=torch.float32, device=dev)
+            if padded:
+                w.grad = padded_grad_like(w)
+            else:
+                w.grad = (torch.empty if (whole and not acc) else torch.zeros)(tuple(w.shape), dtype=torch.float32, device=dev)
             fresh.add(id(w))
             if whole and not acc:
                 fresh.add(("written", id(w)))
+        elif padded:
+            if row_padded_view(w.grad) is None:
+                w.grad = padded_grad_like(w, w.grad)
         elif not w.grad.is_contiguous():
             w.grad = w.grad.contiguous()
-        C = w.grad if full else w.grad[o["rows"][0]:o["rows"][1]]
+        if padded:
+            gfull = row_padded_view(w.grad)
+            C = gfull if full else gfull[o["rows"][0]:o["rows"][1]]
+        else:
+            C = w.grad if full else w.grad[o["rows"][0]:o["rows"][1]]
         if id(w) in fresh and not full:
             acc_here = 0 if ("written", id(w)) in fresh else 1       # zero-initialised: adding is the same as writing
         else:
@@ -887,20 +1042,29 @@ def set_async_weight_grads(flag):
 
 
 def _wgrad_inline(dy2, x2, want_b):
-    """(dW = dy2^T x2, db = column sums of dy2 or None) computed now and returned to autograd."""
-    if gemm_tn_supported(dy2.shape[1], x2.shape[1]):
-        return gemm_tn(dy2, x2, want_colsum=want_b)
-    return torch.mm(dy2.t(), x2), (dy2.sum(0) if want_b else None)
+    """(dW = dy2^T x2, db = column sums of dy2 or None) computed now and returned to autograd.  x2 may be the row-padded
+    operand of an odd-width layer: the caller cuts dW back to the parameter's columns.  An output width that is not a
+    multiple of 4 (no layer of the model: the class scores go through the head kernel) contracts over a zero-padded copy
+    of dY and cuts the rows back."""
+    M = dy2.shape[1]
+    if M % 4:
+        dw, db = gemm_tn(row_operand(dy2), row_operand(x2), want_colsum=want_b)
+        return dw[:M], (db[:M] if want_b else None)
+    return gemm_tn(dy2, row_operand(x2), want_colsum=want_b)
 
 
 def _wgrad(dy2, x2, weight, bias):
     """dW = dy2^T x2 (+ db = column sums of dy2): queued for the end-of-backward batch when the targets are leaf
-    parameters (returns (None, None): the batch writes .grad itself), computed in line otherwise."""
+    parameters (returns (None, None): the batch writes .grad itself), computed in line otherwise.  ``x2`` is the operand
+    the forward contracted over (row-padded for an odd-width layer: its gradient then has the padded layout too)."""
     want_b = bias is not None
     if _queueable(weight, [bias] if want_b else [], dy2.shape[1], x2.shape[1]):
         queue_wgrad(dy2, x2, weight, [bias] if want_b else [])
         return None, None
-    return _wgrad_inline(dy2, x2, want_b)
+    dw, db = _wgrad_inline(dy2, x2, want_b)
+    if dw.shape[1] != weight.shape[1]:
+        dw = dw[:, :weight.shape[1]]
+    return dw, db
 
 
 class _Linear(torch.autograd.Function):
@@ -910,20 +1074,21 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, base):
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1])
-        N, K = weight.shape
-        mfma = linear_supported(x2, weight) and linear_preferred(x2.shape[0], K, N)
+        x2 = row_operand(x.reshape(-1, shp[-1]))          # (an odd contraction width: the zero-padded operands)
+        wop = weight_operand(weight)
+        N, K = wop.shape
+        mfma = linear_supported(x2, wop) and linear_preferred(x2.shape[0], K, N)
         if mfma:
             if base is not None:
-                y = linear_raw(x2, weight, bias, 0, out=base.reshape(-1, N).clone(), accumulate=True)
+                y = linear_raw(x2, wop, bias, 0, out=base.reshape(-1, N).clone(), accumulate=True)
                 if act:
                     y = torch.relu_(y)
             else:
-                y = linear_raw(x2, weight, bias, act)
+                y = linear_raw(x2, wop, bias, act)
         elif base is not None:
-            y = dense_nk(x2, weight, bias, act, out=base.reshape(-1, N).clone(), accumulate=True)
+            y = dense_nk(x2, wop, bias, act, out=base.reshape(-1, N).clone(), accumulate=True)
         else:
-            y = dense_nk(x2, weight, bias, act)
+            y = dense_nk(x2, wop, bias, act)
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.has_base = base is not None
@@ -943,7 +1108,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _wgrad(dy2, x2, ctx.weight_ref, ctx.bias_ref)         # dW and db in one pass over dY
         if ctx.needs_input_grad[0]:
-            dx = _linear_dx(dy2, weight).view(*dy.shape[:-1], K)
+            dx = _linear_dx(dy2, weight_operand(weight))[:, :K].reshape(*dy.shape[:-1], K)
         dbase = dy2.view(dy.shape) if ctx.has_base and ctx.needs_input_grad[4] else None
         return dx, dw, db, None, dbase
 
@@ -995,18 +1160,20 @@ class _LinearGroup(torch.autograd.Function):
             n, force = n[0], True
         xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
         ys, saved = [], []
-        x2s = [x.reshape(-1, x.shape[-1]) for x in xs]
+        # (an odd contraction width -- 1582-d audio, 342-d visual features -- runs on the zero-padded operands)
+        x2s = [row_operand(x.reshape(-1, x.shape[-1])) for x in xs]
+        wops = [weight_operand(w) for w in ws]
         ctx.force = force
         if force or (1 < n <= 8 and all(x2.shape[0] <= GROUP_ROWS and linear_group_supported(x2.shape[0], w.shape[1], w.shape[0])
-                               and not linear_preferred(x2.shape[0], w.shape[1], w.shape[0]) for x2, w in zip(x2s, ws))):
-            if force and not all(linear_group_supported(x2.shape[0], w.shape[1], w.shape[0]) for x2, w in zip(x2s, ws)):
-                raise ValueError("linear_group(hip=True): a contraction wider than 768 or not a multiple of 4")
+                               and not linear_preferred(x2.shape[0], w.shape[1], w.shape[0]) for x2, w in zip(x2s, wops))):
+            if force and not all(linear_group_supported(x2.shape[0], w.shape[1], w.shape[0]) for x2, w in zip(x2s, wops)):
+                raise ValueError("linear_group(hip=True): a contraction wider than 768")
             # few rows (BASELINE cfg2 / cfg3 / cfg4: 1 056 .. 3 520): all projections of the group in ONE launch of the
             # few-row kernel (csrc/linear_small.hip) instead of n library GEMMs (cfg2: 16.7 us against 18.3 us for three
             # hipBLASLt launches, tools/bench_linear_group.py)
-            outs = linear_group_raw([dict(x=x2, w=w, b=b) for x2, w, b in zip(x2s, ws, bs)], act)
+            outs = linear_group_raw([dict(x=x2, w=w, b=b) for x2, w, b in zip(x2s, wops, bs)], act)
         else:
-            outs = [_linear_forward(x2, w, b, act) for x2, w, b in zip(x2s, ws, bs)]
+            outs = [_linear_forward(x2, w, b, act) for x2, w, b in zip(x2s, wops, bs)]
         for x, x2, w, y in zip(xs, x2s, ws, outs):
             saved += [x2, w, y if act else None]
             ys.append(y.view(*x.shape[:-1], w.shape[0]))
@@ -1032,14 +1199,16 @@ class _LinearGroup(torch.autograd.Function):
             # input gradients dX_g = dY_g . W_g of the whole group in one launch: the weight is read as stored ((N, K) = the
             # K-major form of the product over N)
             need = [g for g in range(n) if ctx.needs_input_grad[2 + g]]
-            outs = linear_group_raw([dict(x=dy2s[g], wk=sv[3 * g + 1]) for g in need]) if need else []
+            outs = linear_group_raw([dict(x=dy2s[g], wk=weight_operand(sv[3 * g + 1])) for g in need]) if need else []
             dxs = [None] * n
             for g, o in zip(need, outs):
-                dxs[g] = o.view(*dys[g].shape[:-1], sv[3 * g + 1].shape[1]) if dys[g] is not None else o
+                K = sv[3 * g + 1].shape[1]
+                dxs[g] = o[:, :K].reshape(*dys[g].shape[:-1], K) if dys[g] is not None else o[:, :K]
         else:
             for g in range(n):
                 w = sv[3 * g + 1]
-                dxs.append(_linear_dx(dy2s[g], w).view(*dys[g].shape[:-1], w.shape[1]) if ctx.needs_input_grad[2 + g] else None)
+                dxs.append(_linear_dx(dy2s[g], weight_operand(w))[:, :w.shape[1]].reshape(*dys[g].shape[:-1], w.shape[1])
+                           if ctx.needs_input_grad[2 + g] else None)
         return (None, None) + tuple(dxs) + tuple(r[0] for r in wg) + tuple(r[1] for r in wg)
 
 

@@ -9,7 +9,7 @@ get no gradient and are left untouched, exactly like torch.optim.Adam skips ``gr
 import torch
 
 from . import _hip
-from .distributed import GradientBucket
+from .distributed import GradientBucket, register_slots, slot_pieces, slot_size, slot_view
 
 
 class FlatAdam:
@@ -28,13 +28,15 @@ class FlatAdam:
 
     def _materialise(self):
         params = self.bucket.params
-        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        # one slot per parameter (16-byte aligned starts; a row-padded block for weights of odd contraction width,
+        # distributed.slot_size): the same layout as the gradient bucket, so the update is one elementwise pass
+        flat = torch.cat([piece for p in params for piece in slot_pieces(p.detach(), p)])
+        register_slots(flat, params)
         off = 0
         for p in params:
-            n = p.numel()
-            p.data = flat[off:off + n].view_as(p)
+            p.data = slot_view(flat, off, p)
             p._mmdfn_flat = True       # this storage layout is owned here: nobody may re-point the parameter
-            off += n
+            off += slot_size(p)
         self.flat_p = flat
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
@@ -63,10 +65,9 @@ class FlatAdam:
         if self.flat_p is not None:
             off = 0
             for p in self.bucket.params:
-                n = p.numel()
-                state[names[id(p)]] = dict(exp_avg=self.m[off:off + n].view_as(p).clone(),
-                                           exp_avg_sq=self.v[off:off + n].view_as(p).clone())
-                off += n
+                state[names[id(p)]] = dict(exp_avg=slot_view(self.m, off, p).contiguous().clone(),
+                                           exp_avg_sq=slot_view(self.v, off, p).contiguous().clone())
+                off += slot_size(p)
         grp = self.param_groups[0]
         return dict(step=self.t, lr=float(grp["lr"]), betas=self.betas, eps=self.eps,
                     weight_decay=float(grp["weight_decay"]), state=state)
@@ -87,8 +88,7 @@ class FlatAdam:
         names = {id(p): n for n, p in self.model.named_parameters()}
         off = 0
         for p in self.bucket.params:
-            n = p.numel()
             st = sd["state"][names[id(p)]]
-            self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
-            self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-            off += n
+            slot_view(self.m, off, p).copy_(st["exp_avg"].view_as(p))
+            slot_view(self.v, off, p).copy_(st["exp_avg_sq"].view_as(p))
+            off += slot_size(p)

@@ -54,7 +54,15 @@ def make_batch(seed, B, L, P, C, D_t, D_a, D_v, ragged=False, lengths=None, devi
         qmask[np.arange(n), b, spk[:n, b]] = 1
         umask[b, :n] = 1
         lab[b, n:] = 0
-    t = lambda a: torch.from_numpy(a).to(device)
+    def t(a):
+        x = torch.from_numpy(a).to(device)
+        if x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and x.shape[-1] % 4:
+            # a feature width that is not a multiple of 4 (1582-d audio, 342-d visual): staged row-padded, as the data
+            # pipeline does (ops.py "row padding"; same values, the modules see the (L, B, D) view)
+            from . import ops
+            return ops.pad_rows(x)
+        return x
+
     return dict(textf=t(textf), visuf=t(visuf), acouf=t(acouf), qmask=t(qmask), umask=t(umask), label=t(lab),
                 lengths=[int(x) for x in lens])
 
@@ -101,7 +109,15 @@ def make_stream_batch(seed, B, L, P, C, D_streams, ragged=False, lengths=None, d
         qmask[np.arange(n), b, spk[:n, b]] = 1
         umask[b, :n] = 1
         lab[b, n:] = 0
-    t = lambda a: torch.from_numpy(a).to(device)
+    def t(a):
+        x = torch.from_numpy(a).to(device)
+        if x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and x.shape[-1] % 4:
+            # a feature width that is not a multiple of 4 (1582-d audio, 342-d visual): staged row-padded, as the data
+            # pipeline does (ops.py "row padding"; same values, the modules see the (L, B, D) view)
+            from . import ops
+            return ops.pad_rows(x)
+        return x
+
     return dict(streams=[t(s_) for s_ in streams], qmask=t(qmask), umask=t(umask), label=t(lab),
                 lengths=[int(x) for x in lens])
 

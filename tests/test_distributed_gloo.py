@@ -69,7 +69,7 @@ def test_two_rank_gradient_equals_single_process(tmp_path):
     lengths, xs, ys = make_data()
     FocalLoss(gamma=0.5)(model(torch.cat(xs)), torch.cat(ys)).backward()
     assert got["n_global"] == sum(lengths)
-    assert got["bucket"] == sum(p.numel() for n, p in model.named_parameters() if not n.startswith("dead"))
+    assert got["bucket"] == sum(distributed.slot_size(p) for n, p in model.named_parameters() if not n.startswith("dead"))
     assert "dead.weight" not in got["grads"]
     for k, p in model.named_parameters():
         if k.startswith("dead"):
@@ -147,7 +147,7 @@ def seq_worker(rank, world, port, out):
     off, views_ok = 0, True
     for p in bucket.params:
         views_ok &= p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * off
-        off += p.numel()
+        off += distributed.slot_size(p)        # (every slot starts 16-byte aligned)
     # a parameter coming alive after the layout was frozen must raise on every rank (before any collective is issued)
     model.zero_grad(set_to_none=True)
     (loss_f(model([xs[i] for i in mine]), y) + model.dead(torch.ones(1, 3)).sum()).backward()
@@ -177,7 +177,7 @@ def test_two_rank_bucket_order_keeps_gru_direction_pairs_adjacent(tmp_path):
     for g in got:
         order = g["order"]
         assert g["views_ok"] and "dead" in g["raised"] and not any(n.startswith("dead") for n in order)
-        assert g["bucket"] == sum(p.numel() for n, p in model.named_parameters() if not n.startswith("dead"))
+        assert g["bucket"] == sum(distributed.slot_size(p) for n, p in model.named_parameters() if not n.startswith("dead"))
         for layer in range(2):
             for kind in ("weight_ih", "bias_ih"):
                 n = "enc.%s_l%d" % (kind, layer)

@@ -252,7 +252,7 @@ def test_real_model_gradient_bucket_through_rccl_and_flat_adam():
         bucket.flatten()
         opt._materialise()
         live = [p for p in m_dp.parameters() if p.grad is not None]
-        assert bucket.flat.numel() == sum(p.numel() for p in live) and len(live) == 48
+        assert bucket.flat.numel() == sum(distributed.slot_size(p) for p in live) and len(live) == 48   # 16-byte aligned slots
         try:
             cap = CapturedStep(m_dp, lambda: fb(m_dp), warmup=1, bucket=bucket, reduce_in_graph=True)
             in_graph = True
@@ -364,14 +364,26 @@ def test_weight_gradient_queue_survives_a_backward_that_raises():
             assert float((p.grad - want[n]).abs().max()) / (float(want[n].abs().max()) + 1e-12) < 1e-5, n
 
 
-@pytest.mark.parametrize("lengths", [(20, 13, 7), tuple([110] * 16)])
-def test_training_step_launches_no_library_gemm(lengths):
+REF_DIMS = dict(P=2, C=6, nlayers=2, D_t=100, D_a=1582, D_v=342)        # the reference's IEMOCAP features (run_train_erc.py:359-362)
+CFG3 = dict(P=9, C=7, nlayers=4, D_t=600, D_a=300, D_v=342)            # BASELINE cfg3 (MELD-like)
+RAGGED_CFG3 = (33, 3, 17, 31, 9, 27, 12, 33, 5, 21, 30, 8, 16, 2, 25, 11, 33, 7, 19, 29, 4, 14, 23, 10, 32, 6, 18, 28, 13, 22, 1, 26)
+
+
+@pytest.mark.parametrize("lengths,cfg", [((20, 13, 7), CFG), (tuple([110] * 16), CFG), ((20, 13, 7), REF_DIMS),
+                                         (tuple([110] * 16), REF_DIMS), (RAGGED_CFG3, CFG3)],
+                         ids=["small", "cfg2", "small-1582-342", "cfg2-1582-342", "cfg3"])
+def test_training_step_launches_no_library_gemm(lengths, cfg):
     """Every dense product of a training step (forward, input gradients, weight gradients) runs on this package's MFMA
-    kernels: no Tensile (`Cijk_*`: hipBLASLt / rocBLAS) kernel in the device trace, for a few-row batch and for the
-    BASELINE cfg2 shape (16 x 110: the context GRU's 1 760-row and the party GRU's 7 040-row products)."""
+    kernels: no Tensile (`Cijk_*`: hipBLASLt / rocBLAS) kernel and no ATen matmul in the device trace -- for a few-row batch,
+    the BASELINE cfg2 shape (16 x 110: the context GRU's 1 760-row and the party GRU's 7 040-row products),
+    the reference's own feature widths (1582-d audio, 342-d visual: contraction widths that are not multiples of 4 run on
+    row-padded operands, ops.py) and BASELINE cfg3."""
     from torch.profiler import ProfilerActivity, profile
-    m = _model(dropout=0.1).train()
-    b, flat = _step_inputs(lengths=lengths)
+    m = synthetic.build_model(dropout=0.1, **cfg)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 5))
+    m = m.cuda().train()
+    b = synthetic.make_batch(11, lengths=list(lengths), device="cuda", B=len(lengths), L=max(lengths), **cfg)
+    flat = T.flatten_labels(b["label"], b["lengths"])
 
     def step():
         m.zero_grad(set_to_none=True)
@@ -384,3 +396,77 @@ def test_training_step_launches_no_library_gemm(lengths):
     names = [e.key for e in prof.key_averages()]
     assert any("linear_lds_kernel" in n for n in names) and any("gru_seq" in n for n in names), names
     assert not [n for n in names if n.startswith("Cijk_") or ("gemm" in n.lower() and "gemm_tn" not in n)], names
+
+
+@pytest.mark.parametrize("padded_inputs", [True, False], ids=["staged-padded", "plain-contiguous"])
+def test_odd_feature_widths_forward_and_gradients_against_oracle(padded_inputs):
+    """The reference's IEMOCAP feature widths (1582 / 342: neither a multiple of 4) through the row-padded path: log-probs and
+    ALL live parameter gradients against the CPU oracle, with features staged row-padded (the data pipeline's form) and as
+    plain contiguous tensors (copied into a padded buffer by the module); state_dict round trip keeps the reference's shapes;
+    the weight-gradient batch and plain autograd agree."""
+    import mmdfn_oracle as O
+    from util import rel_err
+    lengths = [23, 9, 17]
+    m = synthetic.build_model(dropout=0.0, **REF_DIMS)
+    sd = synthetic.seeded_state_dict(m.state_dict(), 3)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    b = synthetic.make_batch(21, lengths=lengths, device="cuda", B=3, L=23, **REF_DIMS)
+    if not padded_inputs:
+        b["acouf"], b["visuf"] = b["acouf"].contiguous(), b["visuf"].contiguous()
+    flat = T.flatten_labels(b["label"], b["lengths"])
+    logp = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+    T.backward(FocalLoss(gamma=0.5)(logp, flat))
+    assert tuple(m.linear_a.weight.shape) == (200, 1582) and tuple(m.linear_a.weight.grad.shape) == (200, 1582)
+    assert m.linear_a.weight.stride(0) == 1584 and m.linear_v.weight.stride(0) == 344       # the padded storage
+    got = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+    # oracle (CPU, reference op structure; aten engine: autograd through torch's own GRU)
+    cpu = {k: v.cpu() for k, v in b.items() if torch.is_tensor(v)}
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    want_logp = O.forward(P, cpu["textf"], cpu["qmask"], cpu["umask"], lengths, cpu["acouf"], cpu["visuf"],
+                          O.default_cfg(nlayers=2), engine="aten")
+    assert float((logp.detach().cpu() - want_logp).abs().max()) < 1e-4
+    O.focal_loss(want_logp, O.flatten_labels(cpu["label"], lengths), gamma=0.5).backward()
+    for n in ("linear_a.weight", "linear_v.weight", "linear_l.weight", "linear_a.bias", "lstm_l.weight_ih_l0",
+              "graph_model.graph_net.convs.0.weight", "smax_fc.weight"):
+        assert rel_err(got[n], P[n].grad) < 1e-4, n
+    # plain autograd (no batch): same gradients
+    m.zero_grad(set_to_none=True)
+    FocalLoss(gamma=0.5)(m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0], flat).backward()
+    for n in ("linear_a.weight", "linear_v.weight"):
+        assert rel_err(dict(m.named_parameters())[n].grad.cpu(), got[n]) < 1e-5, n
+    # the state_dict keeps the reference's shapes and loads back
+    out = m.state_dict()
+    assert tuple(out["linear_a.weight"].shape) == (200, 1582)
+    m2 = synthetic.build_model(dropout=0.0, **REF_DIMS)
+    m2.load_state_dict({k: v.cpu() for k, v in out.items()})
+    assert torch.equal(m2.linear_a.weight.detach(), sd["linear_a.weight"])
+
+
+def test_odd_feature_widths_training_trajectory_flat_adam_vs_torch_adam():
+    """Three optimizer steps at the reference's feature widths: FlatAdam (row-padded slots in the flat buffers) follows
+    torch.optim.Adam on the padded parameters, through the captured-step cache."""
+    from mm_dfn_amd.optim import FlatAdam
+    lengths = [23, 9, 17]
+    sd = None
+    traj = {}
+    for kind in ("torch", "flat"):
+        m = synthetic.build_model(dropout=0.0, **REF_DIMS)
+        sd = sd or synthetic.seeded_state_dict(m.state_dict(), 3)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        opt = (torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4) if kind == "torch"
+               else FlatAdam(m, lr=3e-4, weight_decay=1e-4))
+        cache = T.StepGraphCache(m, FocalLoss(gamma=0.5))
+        losses = []
+        for step in range(3):
+            b = synthetic.make_batch(21 + step, lengths=lengths, device="cuda", B=3, L=23, **REF_DIMS)
+            loss, _, _ = cache.step((b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"]), lengths, True)
+            losses.append(float(loss))
+            opt.step()
+        traj[kind] = (losses, m.linear_a.weight.detach().cpu().clone(), m.linear_v.weight.detach().cpu().clone())
+    for a, c in zip(traj["torch"][0], traj["flat"][0]):
+        assert abs(a - c) < 2e-4 * max(1.0, abs(a))
+    for i in (1, 2):
+        assert float((traj["torch"][i] - traj["flat"][i]).abs().max()) < 5e-5
+        assert float((traj["torch"][i] - sd["linear_a.weight" if i == 1 else "linear_v.weight"]).abs().max()) > 1e-5   # it moved
