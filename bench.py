@@ -511,7 +511,7 @@ def main():
         if world == 1 and not a.no_extra and not use_dp:
             out["other_workloads"] = []
             legs = [lambda c=c, r=r: quick_leg(c, r, a.dropout) for c, r in
-                    (("cfg2", True), ("cfg3", True), ("cfg4", False), ("cfg4", True))]
+                    (("cfg2", True), ("cfg2_refdims", False), ("cfg3", True), ("cfg4", False), ("cfg4", True))]
             legs += [lambda: cfg5_leg("cfg5", a.dropout), lambda: cfg5_leg("cfg5_b32", a.dropout, steps=4, warmup=1),
                      lambda: streamed_leg("cfg2", a.dropout)]
             for leg in legs:

@@ -137,9 +137,11 @@ def ensure_row_padded(p):
     return p
 
 
-def padded_grad_like(p, g=None):
-    """Gradient tensor for a row-padded parameter: (N, K) view of a zero (N, Kp) buffer (optionally holding ``g``)."""
-    base = torch.zeros(p.shape[0], pad4(p.shape[1]), dtype=torch.float32, device=p.device)
+def padded_grad_like(p, g=None, zero=True):
+    """Gradient tensor for a row-padded parameter: (N, K) view of an (N, Kp) buffer -- zero-filled (optionally holding
+    ``g``), or uninitialised when the caller's kernel writes every one of the Kp columns (the weight-gradient batch does:
+    the pad columns come out as dY^T . 0)."""
+    base = (torch.zeros if zero else torch.empty)(p.shape[0], pad4(p.shape[1]), dtype=torch.float32, device=p.device)
     register_row_padded(base)
     view = base[:, :p.shape[1]]
     view._mmdfn_padbase = base
@@ -949,7 +951,7 @@ def _flush_outs(outs, side):
             # zero fill; a range that leaves rows nobody writes does
             whole = covered[id(w)] >= w.shape[0]
             if padded:
-                w.grad = padded_grad_like(w)
+                w.grad = padded_grad_like(w, zero=not (whole and not acc))
             else:
                 w.grad = (torch.empty if (whole and not acc) else torch.zeros)(tuple(w.shape), dtype=torch.float32, device=dev)
             fresh.add(id(w))

@@ -15,6 +15,9 @@ CONFIGS = {
     "cfg2": dict(B=16, L=110, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512),
     "cfg3": dict(B=32, L=33, P=9, C=7, nlayers=4, D_t=600, D_a=300, D_v=342),
     "cfg4": dict(B=32, L=110, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512),  # per-GPU shard of 256
+    # cfg2's batch at the reference's own IEMOCAP feature widths (run_train_erc.py:359-362: 1582-d IS10 audio, 342-d
+    # denseface): neither is a multiple of 4, the projections run on row-padded operands (ops.py)
+    "cfg2_refdims": dict(B=16, L=110, P=2, C=6, nlayers=2, D_t=100, D_a=1582, D_v=342),
 }
 
 # BASELINE.json config 5: long-dialogue stress, six modality streams of 512-d inputs, 8 GCN layers (graph hidden
