@@ -31,10 +31,14 @@ class CapturedStep:
                 bucket.flatten()
                 if reduce_in_graph:
                     bucket.reduce_flat()
-        # the warm-up passes and the capture draw dropout flags: put the device generator back afterwards, so that building
-        # a captured step consumes no random numbers and its first replay draws what one eager step would have drawn
-        dev_index = torch.cuda.current_device()
+        # the warm-up passes and the capture draw dropout flags: put BOTH generators back afterwards -- torch's CUDA generator
+        # and the package's device-resident Philox state (ops.draw_flags), which replays advance on the device -- so that
+        # building a captured step consumes no random numbers.  Replays then move torch's generator by what the graph
+        # consumed (recorded here), so an eager draw that follows (the warm-up of the next cache miss) continues the stream
+        # instead of re-seeding it from a stale offset (overlapping dropout masks during the first epoch).
+        dev_index = self._dev_index = torch.cuda.current_device()
         rng_state = torch.cuda.get_rng_state(dev_index)
+        flag_snap = ops.flag_state_snapshot(dev_index)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -46,6 +50,7 @@ class CapturedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         model.zero_grad(set_to_none=True)
+        consumed0 = ops.flags_consumed(dev_index)
         from . import dialogue_model, layout
         # the graph bakes raw pointers of the cached index tensors (dialogue layout, pad-strip index): keep every
         # cache entry used during the capture alive for as long as this object lives, whatever the caches evict
@@ -55,7 +60,9 @@ class CapturedStep:
                 self.loss = step_fn()
                 tail()
         self._pinned = list(used)
+        self._rng_per_replay = ops.flags_consumed(dev_index) - consumed0      # Philox counters one replay consumes
         torch.cuda.set_rng_state(rng_state, dev_index)
+        ops.flag_state_restore(dev_index, flag_snap)
         self.grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
         # the parameter storages are baked in as well: a later re-pointing of p.data (FlatAdam._materialise, .to(),
         # load_state_dict(assign=True)) would make the graph update stale memory -- checked on every replay
@@ -66,5 +73,9 @@ class CapturedStep:
             if p.data_ptr() != ptr:
                 raise RuntimeError("CapturedStep: a parameter's storage moved after the capture (optimizer "
                                    "materialisation / .to() / load_state_dict(assign=True)); capture again")
+        if self._rng_per_replay:
+            ops.flag_state_sync(self._dev_index)           # torch.manual_seed / a restored RNG state since the last draw
         self.graph.replay()
+        if self._rng_per_replay:
+            ops.flags_advance_host(self._dev_index, self._rng_per_replay)
         return self.loss

@@ -1466,6 +1466,57 @@ def keep_scale(p):
 
 
 _FLAG_STATE = {}       # device index -> [device state (seed, offset, workgroup counter), host mirror (seed, offset)]
+_FLAG_CONSUMED = {}    # device index -> Philox counters consumed so far (eager and captured launches alike; host-side tally)
+
+
+def flags_consumed(idx):
+    return _FLAG_CONSUMED.get(idx, 0)
+
+
+def flag_state_snapshot(idx):
+    """(device state clone, host mirror) of the keep-flag generator, or None before the first draw on the device."""
+    ent = _FLAG_STATE.get(idx)
+    return None if ent is None else (ent[0].clone(), ent[1])
+
+
+def flag_state_restore(idx, snap):
+    """Put the keep-flag generator back where ``flag_state_snapshot`` found it (graphs.CapturedStep: building a captured
+    step consumes no random numbers).  With no earlier state the device generator is re-seeded from torch's CUDA generator."""
+    ent = _FLAG_STATE.get(idx)
+    if ent is None:
+        return
+    if snap is None:
+        ent[1] = None
+        flag_state_sync(idx)
+    else:
+        ent[0].copy_(snap[0])
+        ent[1] = snap[1]
+
+
+def flag_state_sync(idx):
+    """Re-seed the device generator from torch's CUDA generator if the two disagree (torch.manual_seed, a restored RNG
+    state, torch's own random ops since the last draw).  Eager draws do this themselves; a captured step calls it before a
+    replay, whose launches read the device state as it is."""
+    ent = _FLAG_STATE.get(idx)
+    if ent is None:
+        return
+    gen = torch.cuda.default_generators[idx]
+    now = (int(gen.initial_seed()), int(gen.get_offset()))
+    if ent[1] != now:
+        seed = now[0] - (1 << 64) if now[0] >= (1 << 63) else now[0]
+        ent[0].copy_(torch.tensor([seed, now[1], 0, 0], dtype=torch.int64), non_blocking=False)
+        ent[1] = now
+
+
+def flags_advance_host(idx, counters):
+    """After a replay that consumed ``counters`` Philox counters on the device: move torch's generator (and the host mirror)
+    by the same amount, so that the next eager draw continues the stream instead of re-seeding it backwards."""
+    ent = _FLAG_STATE.get(idx)
+    if ent is None or counters <= 0:
+        return
+    gen = torch.cuda.default_generators[idx]
+    gen.set_offset(int(gen.get_offset()) + int(counters))
+    ent[1] = (int(gen.initial_seed()), int(gen.get_offset()))
 
 
 def draw_flags(n, p, device):
@@ -1492,6 +1543,7 @@ def draw_flags(n, p, device):
         # leave torch's generator behind the counters this launch consumes (its offset moves in multiples of 4)
         gen.set_offset(now[1] + 4 * ((n8 + 3) // 4))
         ent[1] = (now[0], int(gen.get_offset()))
+    _FLAG_CONSUMED[idx] = _FLAG_CONSUMED.get(idx, 0) + 4 * ((n8 + 3) // 4)
     out = torch.empty(n, dtype=torch.float32, device=device)
     _hip.check(_hip.lib().mmdfn_keep_flags(_hip.ptr(out), n, float(1.0 - p), _hip.ptr(ent[0]), _hip.stream()), "mmdfn_keep_flags")
     return out

@@ -115,6 +115,45 @@ def test_flat_adam_state_dict_roundtrip_and_lr_schedule():
         assert float((a - c).abs().max()) < 1e-7, k
 
 
+def test_dropout_stream_is_not_rewound_by_captured_steps():
+    """building a captured step must consume no random numbers and replays must move torch's generator along,
+    so that two signatures captured and stepped back to back (every step of a first epoch is a cache miss) draw their keep
+    flags from DISJOINT counter ranges, and torch.manual_seed restarts the stream for replays as it does for eager steps."""
+    from mm_dfn_amd import ops
+    m = _model(17, dropout=0.5).train()
+    loss_f = FocalLoss(gamma=0.5)
+    cache = T.StepGraphCache(m, loss_f)
+    idx = torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+
+    def state():
+        torch.cuda.synchronize()
+        dev = ops._FLAG_STATE[idx][0].cpu().tolist()
+        return dev[1], int(gen.get_offset())
+
+    def run(seed, lengths):
+        b = synthetic.make_batch(seed, lengths=list(lengths), device="cuda", B=len(lengths), L=max(lengths), **CFG)
+        before = state() if idx in ops._FLAG_STATE else None
+        loss, logp, _ = cache.step((b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"]), list(lengths), True)
+        return before, state(), logp.detach().clone()
+
+    torch.manual_seed(123)
+    _, s0, _ = run(1, (9, 4))                       # the very first draw on the device + first capture
+    assert s0[0] == s0[1] and s0[0] > 0             # device offset == torch offset, one step's worth consumed
+    b1, s1, lp_a = run(2, (11, 5, 3))               # a second signature: cache miss, warm-up + capture + replay
+    assert b1 == s0                                 # (nothing moved in between)
+    assert s1[0] == s1[1] and s1[0] > s0[0]         # continues behind the first step: not rewound to the capture's start
+    b2, s2, lp_a2 = run(2, (11, 5, 3))              # replay of the second signature
+    assert s2[0] == s2[1] and s2[0] - s1[0] == s1[0] - s0[0]      # every step of a signature consumes the same amount
+    assert float((lp_a - lp_a2).abs().max()) > 1e-6              # different masks on the same inputs
+    # torch.manual_seed restarts the stream for replays too (the reference re-seeds every pass, run_train_erc.py:164)
+    torch.manual_seed(123)
+    _, s3, _ = run(1, (9, 4))
+    assert s3 == s0
+    _, s4, lp_b = run(2, (11, 5, 3))
+    assert s4 == s1 and torch.equal(lp_b, lp_a)
+
+
 def test_captured_step_pins_cached_index_tensors_and_detects_moved_parameters():
     from mm_dfn_amd import layout, dialogue_model
     from mm_dfn_amd.graphs import CapturedStep
