@@ -535,11 +535,18 @@ class _ProjectGather(torch.autograd.Function):
         dXs = [None] * Mn
         need = [m for m in range(Mn) if ctx.needs_input_grad[7 + m]]
         if need:
-            outs = []
+            outs, seen = [], set()
             for m in need:
                 d = dpass[m] if m < len(dpass) else None
-                if d is not None and not (d.is_contiguous() and d.data_ptr() % 16 == 0):
-                    d = d.contiguous()
+                # the accumulation below writes INTO the incoming gradient of the passthrough alias: only a buffer that is
+                # private to this node may be used that way.  The same tensor reaching two aliases (X_a' + X_v' downstream:
+                # add's backward hands one tensor to both) would be written by two problems of the one grouped launch, so
+                # every duplicate -- and anything that is not a plain aligned buffer -- is copied first.
+                if d is not None and (not (d.is_contiguous() and d.data_ptr() % 16 == 0) or d.data_ptr() in seen
+                                      or d._base is not None):
+                    d = d.clone(memory_format=torch.contiguous_format)
+                if d is not None:
+                    seen.add(d.data_ptr())
                 outs.append(d)
             if wcat is not None:
                 probs = []
@@ -664,14 +671,16 @@ def linear_group_raw(problems, act=0):
             x = x.contiguous()
         if "wk" in q:
             w = q["wk"]
-            w = w if (w.stride(1) == 1) else w.contiguous()
+            w = w if (w.stride(1) == 1 and w.data_ptr() % 16 == 0 and w.stride(0) % 4 == 0) else w.contiguous().clone()
             k_, n_ = w.shape
             W.append(w); W2.append(None); B1.append(None); B2.append(None); N1.append(n_); km.append(1); ldw.append(w.stride(0))
         else:
             w, w2 = q["w"], q.get("w2")
-            w = w if w.is_contiguous() else w.contiguous()
-            if w2 is not None and not w2.is_contiguous():
-                w2 = w2.contiguous()
+            # (16-byte aligned rows: the LDS-DMA form fetches them in 16-byte units, the register form refuses K > 768;
+            # FlatAdam's slots and freshly allocated parameters are aligned, an odd view of somebody else's buffer is copied)
+            w = w if (w.is_contiguous() and w.data_ptr() % 16 == 0) else w.contiguous().clone()
+            if w2 is not None and not (w2.is_contiguous() and w2.data_ptr() % 16 == 0):
+                w2 = w2.contiguous().clone()
             n_, k_ = w.shape[0] + (w2.shape[0] if w2 is not None else 0), w.shape[1]
             W.append(w); W2.append(w2); B1.append(q.get("b")); B2.append(q.get("b2")); N1.append(w.shape[0]); km.append(0)
             ldw.append(k_)
@@ -818,7 +827,10 @@ def gemm_tn_grouped(problems):
 # opt-in by scope and per parameter:
 #   * outside a scope (a plain ``loss.backward()``, ``torch.autograd.grad(...)``) every node computes its weight
 #     gradients in line and RETURNS them: autograd.grad sees them, nothing is written to .grad behind its back;
-#   * a parameter with tensor hooks or post-accumulate-grad hooks (DDP reducers, user hooks) always takes the in-line path;
+#   * a parameter with Python tensor hooks or post-accumulate-grad hooks always takes the in-line path.  torch's
+#     DistributedDataParallel registers its reducer on the AccumulateGrad node in C++, which is NOT visible here: do not run
+#     train.backward / ops.wgrad_batch() on a DDP-wrapped model (the queued parameters would bypass the reducer) -- use the
+#     package's own GradientBucket (distributed.py), or a plain loss.backward();
 #   * non-leaf weights always take the in-line path.
 # The queue belongs to one backward pass: entering the outermost scope drops anything a failed backward left behind, and
 # leaving it flushes what the engine callback did not (or clears the queue when the backward raised).

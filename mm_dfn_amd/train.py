@@ -149,7 +149,7 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
             optimizer.zero_grad()         # (a replayed step hands over fresh gradient tensors: nothing to reset)
         textf, visuf, acouf, qmask, umask, label = [d.cuda() for d in data[:6]] if cuda_flag else data[:6]
         lengths = getattr(data, "lengths", None) or lengths_from_umask(umask)
-        if graph_cache is not None:
+        if graph_cache is not None and not test_label:      # (the --test_label dumps call .cpu() / np.save: never captured)
             loss, log_prob, flat = graph_cache.step((textf, visuf, acouf, qmask, umask, label), lengths, train_flag,
                                                     test_label)
             preds.append(torch.argmax(log_prob, 1))

@@ -355,6 +355,17 @@ def test_test_label_dumps_the_reference_activation_files(tmp_path, capsys):
     for m in range(3):
         assert np.allclose(multi[:, 300 * m + 200:300 * (m + 1)], layer[m * N:(m + 1) * N], atol=1e-6)
     assert "# deepGCN layer 0" in capsys.readouterr().out
+    # model.py:1331-1335: the class scores behind smax_fc; their log-softmax is what the pass returned
+    scores = np.load(str(tmp_path / "1080_v3_test_output_multi_after_relu-fc_15.npy"))
+    assert scores.shape == (N, 6)
+    assert np.allclose(torch.log_softmax(torch.from_numpy(scores), 1).numpy(), dumped.cpu().numpy(), atol=1e-6)
+    # through the pass loop with a captured-step cache: the dumping pass is not captured (it calls .cpu() / np.save)
+    from mm_dfn_amd import FocalLoss, train
+    batch = [b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"]]
+    cache = train.StepGraphCache(model, FocalLoss(gamma=0.5))
+    out = train.train_or_eval_graph_model(model, FocalLoss(gamma=0.5), [batch], train_flag=False, test_label=True,
+                                          graph_cache=cache)
+    assert cache.misses == 0 and len(out[5]) == N
 
 
 def test_fusion_modules_run_without_library_gemms():
