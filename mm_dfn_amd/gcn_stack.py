@@ -17,6 +17,10 @@ import torch
 from . import _hip, ops
 
 ROW_LIMIT = 32768
+# test tap: a list to which every forward of the fused node appends references to its ReLU decisions (h0, the per-layer
+# gate masks, the output) -- tests/util.relu_flips_from_tap compares them with the oracle's pre-activations to find the
+# units whose pre-activation is within rounding of zero and landed on the other side.  None (the default): nothing is kept.
+TAP = None
 
 
 def eligible(x, nfeat, nhidden, nlayers, params, lamda=1.0):
@@ -79,6 +83,8 @@ class _GcnStack(torch.autograd.Function):
             rec.update(zin=zin, hi=hi, gmask=gmask, theta=theta)
             layers.append(rec)
             cur = dst
+        if TAP is not None:
+            TAP.append(dict(h0=h0, gmask=[rec["gmask"] for rec in layers], out=out.detach()))
         ctx.layers = layers
         # (xd is a detached alias: holding the output itself would tie this node and its output into a reference cycle)
         ctx.misc = dict(lay=lay, symmetric=symmetric, alpha=alpha, reason=reason, use_residue=use_residue, R=R, F=F, H=H,

@@ -33,6 +33,42 @@ COS_SHRINK = 0.99999  # model_mm.py:149,166
 
 
 # ----------------------------------------------------------------------------
+# ReLU probe (a test aid of the oracle itself, no counterpart in the reference).  At the BASELINE batch sizes a model
+# holds ~10^6 ReLU pre-activations; one of them within fp32 rounding of zero is the normal case, and two correct fp32
+# evaluations (this oracle's summation order, a device kernel's) then sit on different linear pieces of the network: same
+# forward values, different gradients.  With a probe installed every ReLU site records its pre-activations, and the units
+# listed in ``flips`` are evaluated on the OTHER side of their kink, so a test can differentiate the piece the device is
+# on (tests/util.relu_flips_from_tap) instead of picking seeds that happen to avoid kinks.
+# ----------------------------------------------------------------------------
+class ReluProbe:
+    def __init__(self, flips=None):
+        self.pre = {}                      # site -> pre-activations (detached)
+        self.flips = flips or {}           # site -> LongTensor (k, 2) of (row, column) positions to evaluate on the other side
+
+
+_RELU_PROBE = None
+
+
+def set_relu_probe(probe):
+    global _RELU_PROBE
+    prev, _RELU_PROBE = _RELU_PROBE, probe
+    return prev
+
+
+def relu_site(pre, site):
+    probe = _RELU_PROBE
+    if probe is None:
+        return torch.relu(pre)
+    probe.pre[site] = pre.detach()
+    fl = probe.flips.get(site)
+    if fl is None or len(fl) == 0:
+        return torch.relu(pre)
+    mask = pre.detach() > 0
+    mask[fl[:, 0], fl[:, 1]] = ~mask[fl[:, 0], fl[:, 1]]
+    return pre * mask.to(pre.dtype)
+
+
+# ----------------------------------------------------------------------------
 # recurrent cells (the equations torch.nn.GRU / torch.nn.LSTM document; the
 # reference calls those modules at model.py:866,868 and model_GCN.py:433)
 # ----------------------------------------------------------------------------
@@ -274,7 +310,7 @@ def gcnii_stack(x, adj, params, prefix, nlayers, lamda, alpha, dropout=0.0, trai
                 reason_flag=True, use_residue=True):
     """GCNII_lyc.forward with an explicit adjacency (return_feature=True)."""
     x = F.dropout(x, dropout, training)
-    h0 = torch.relu(F.linear(x, params[prefix + "fcs.0.weight"], params[prefix + "fcs.0.bias"]))
+    h0 = relu_site(F.linear(x, params[prefix + "fcs.0.weight"], params[prefix + "fcs.0.bias"]), prefix + "fcs0")
     cur = F.dropout(h0, dropout, training)
     h = torch.zeros_like(cur)
     c = torch.zeros_like(cur)
@@ -284,8 +320,8 @@ def gcnii_stack(x, adj, params, prefix, nlayers, lamda, alpha, dropout=0.0, trai
             h, c = lstm_cell(q, h, c, params[prefix + "rnn.weight_ih_l0"], params[prefix + "rnn.weight_hh_l0"],
                              params[prefix + "rnn.bias_ih_l0"], params[prefix + "rnn.bias_hh_l0"])
             cur = h
-        cur = torch.relu(graph_convolution(cur, adj, h0, lamda, alpha, i + 1,
-                                           params[prefix + "convs.%d.weight" % i]))
+        cur = relu_site(graph_convolution(cur, adj, h0, lamda, alpha, i + 1,
+                                          params[prefix + "convs.%d.weight" % i]), prefix + "conv%d" % i)
         cur = F.dropout(cur, dropout, training)
         if reason_flag:
             cur = cur + q
@@ -351,7 +387,7 @@ def mm_gcn(feats, dia_len, params, cfg, training=False):
 # head + loss (model.py:1328-1337, loss.py:14-34)
 # ----------------------------------------------------------------------------
 def head(feat, params, dropout=0.0, training=False):
-    z = torch.relu(F.dropout(feat, dropout, training))
+    z = relu_site(F.dropout(feat, dropout, training), "head")
     return F.log_softmax(F.linear(z, params["smax_fc.weight"], params["smax_fc.bias"]), 1)
 
 

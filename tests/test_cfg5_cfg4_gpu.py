@@ -165,26 +165,52 @@ def test_cfg5_whole_batch_properties():
 # (iii) the cfg5 module stack at full dialogue length
 # ------------------------------------------------------------------------------------------------------------------
 def test_cfg5_stack_two_long_dialogues_all_gradients_against_oracle():
-    """L = 512, M = 6, 8 layers, B = 2: log-probs and every live parameter gradient against the oracle (dense 6144^2)."""
+    """L = 512, M = 6, 8 layers, B = 2: log-probs and every live parameter gradient against the oracle (dense 6144^2).
+
+    The model holds ~11 M ReLU pre-activations (projections + 8 layers x 6 144 x 200); where one lies within fp32 rounding of
+    zero two correct fp32 summation orders disagree on its side and every gradient upstream of that unit moves (1e-2
+    relative on one parameter; of the batch seeds 1502..1511 five have such a unit against this oracle's summation order,
+    1502 -- used here, the first of them -- with |pre| = 8.5e-8 in stream 4).  Instead of picking a seed that happens to
+    agree the test reads the device's own ReLU decisions, requires every disagreement to be a pre-activation
+    below 1e-5 and differentiates the oracle on the linear piece the device is on (tests/util.relu_flips_from_tap)."""
+    from mm_dfn_amd import gcn_stack
+    from util import relu_flips_from_tap
     cfg = dict(synthetic.STREAM_CONFIGS["cfg5"], B=2)
     m, sd = _stream_model(cfg, 1501)
     m.train()
-    # The batch seed matters: the model holds ~11 M ReLU pre-activations (projections + 8 layers x 6 144 x 200), and where one
-    # lies within fp32 rounding of zero two correct fp32 summation orders disagree on its sign; the weight-gradient rows it
-    # feeds then differ by that sample's contribution (1e-2 relative on one parameter).  Of the seeds 1502..1511 five have
-    # such a flip against the oracle's summation order (1502: |pre| = 8.5e-8 in stream 4) and five agree to 2e-6 everywhere;
-    # 1503 is one of the latter (tools note in DESIGN.md section 3).
-    b = synthetic.make_stream_batch(1503, **cfg)
-    logp = _run_streams(m, b)
-    w = torch.from_numpy(np.random.RandomState(1503).randn(*logp.shape).astype(np.float32))
+    b = synthetic.make_stream_batch(1502, **cfg)
+    gcn_stack.TAP = []
+    try:
+        logp = _run_streams(m, b)
+    finally:
+        tap, gcn_stack.TAP = gcn_stack.TAP, None
+    w = torch.from_numpy(np.random.RandomState(1502).randn(*logp.shape).astype(np.float32))
     (logp * w.to(DEV)).sum().backward()
-    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    want = O.forward_streams(params, b["streams"], b["lengths"], O.default_cfg(8))
-    (want * w).sum().backward()
+
+    def oracle(flips=None):
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        probe = O.ReluProbe(flips)
+        prev = O.set_relu_probe(probe)
+        try:
+            want = O.forward_streams(params, b["streams"], b["lengths"], O.default_cfg(8))
+            (want * w).sum().backward()
+        finally:
+            O.set_relu_probe(prev)
+        return want.detach(), {k: v.grad for k, v in params.items()}, probe
+
+    want, grads, probe = oracle()
     assert abs_err(logp, want) < 1e-4
-    for k, p in m.named_parameters():
-        if p.grad is not None:
-            assert rel_err(p.grad, params[k].grad) < 1e-4, k
+    named = [(k, p) for k, p in m.named_parameters() if p.grad is not None]
+    if not all(rel_err(p.grad, grads[k]) < 1e-4 for k, p in named):
+        assert len(tap) == 1
+        flips = relu_flips_from_tap(tap[0], probe, "graph_model.graph_net.", 6, sum(b["lengths"]))
+        assert flips, "gradients differ although device and oracle agree on every ReLU"
+        print("ReLU units evaluated on the device's side of the kink: %s"
+              % {k: [(int(r), int(c), float(probe.pre[k][r, c])) for r, c in v] for k, v in flips.items()})
+        _, grads, _ = oracle(flips)
+    assert len(named) >= 20
+    for k, p in named:
+        assert rel_err(p.grad, grads[k]) < 1e-4, k
 
 
 def test_cfg5_stack_full_batch_eval_against_oracle_slice():
