@@ -48,6 +48,12 @@ def parse():
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-part-bucket", action="store_true",
+                    help="data parallel: reduce the graph / head half of the gradient bucket while the encoders' backward is "
+                         "still running (distributed.GradientBucket(parts=2)); off by default until measured on a multi-GPU node")
+    ap.add_argument("--predict-scaling", type=int, default=0, metavar="N",
+                    help="single GPU: shard one global ragged batch of 32 N dialogues by sum(L^2) as --gpus N --ragged would, "
+                         "time every rank's shard on THIS GPU and print the predicted N-GPU throughput / efficiency")
     ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs (cfg2 ragged, cfg3, cfg4 shard, cfg5, streamed)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the K6 roofline legs (profiling runs of the step alone)")
     ap.add_argument("--only-roofline", action="store_true", help="profiling aid: run only the K6 roofline legs (clean rocprof traces)")
@@ -204,6 +210,63 @@ def quick_leg(cfgname, ragged, dropout, steps=12, warmup=4):
             "utterances_per_s": n / dt, "steps": steps}
 
 
+def predict_scaling(world, cfgname, dropout, steps=12, warmup=4):
+    """What `--gpus N --ragged` would measure, predicted on ONE GPU: the global ragged batch of B x N dialogues (same seed as
+    the real run) is sharded by sum(L^2) exactly as distributed.shard_dialogues does, every rank's shard is stepped on this
+    GPU as its own captured step, and the N-GPU step time is modelled as max over ranks (the barrier) + the ring
+    all-reduce of the flat gradient bucket over xGMI (2 (N-1)/N x bytes / 153 GB/s per link + 20 us).
+    The equal-shard figure (every rank a fixed-length cfg4 shard) is printed next to it: their ratio is the price of the
+    ragged imbalance alone.  Gives the first real 8-GPU run a number to be checked against."""
+    import numpy as np
+    import torch
+    from mm_dfn_amd import FocalLoss, distributed, synthetic, train
+    from mm_dfn_amd.graphs import CapturedStep
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = dict(synthetic.CONFIGS[cfgname])
+    glens = synthetic.make_lengths(np.random.RandomState(2021), cfg["B"] * world, cfg["L"], True)
+    model = synthetic.build_model(dropout=dropout, **cfg)
+    model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
+    model = model.to(dev).train()
+    loss_f = FocalLoss(gamma=0.5)
+
+    def time_shard(lengths, seed):
+        batch = synthetic.make_batch(seed, lengths=lengths, device=dev, **cfg)
+        label = train.flatten_labels(batch["label"], lengths)
+
+        def fwd_bwd():
+            logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
+            loss = loss_f(logp, label)
+            train.backward(loss)
+            return loss
+        dt = timed_replays(CapturedStep(model, fwd_bwd, warmup=2), steps, warmup)
+        torch.cuda.empty_cache()
+        return dt
+
+    ranks = []
+    for r in range(world):
+        mine = distributed.shard_dialogues(glens, world, r)
+        lens = [glens[i] for i in mine]
+        ranks.append({"rank": r, "dialogues": len(lens), "utterances": sum(lens), "sumL2": sum(x * x for x in lens),
+                      "ms_per_step": time_shard(lens, 2021 + r) * 1e3})
+    fixed_ms = time_shard([cfg["L"]] * cfg["B"], 2021) * 1e3
+    live = [p for p in model.parameters() if p.grad is not None]
+    bucket_bytes = 4 * sum(distributed.slot_size(p) for p in live)
+    comm_ms = 0.0 if world == 1 else (2.0 * (world - 1) / world * bucket_bytes / 153e9 + 20e-6) * 1e3
+    slow = max(x["ms_per_step"] for x in ranks)
+    total = sum(x["utterances"] for x in ranks)
+    one = ranks[0]["utterances"] / (ranks[0]["ms_per_step"] * 1e-3) if world == 1 else None
+    mean_rate = sum(x["utterances"] / (x["ms_per_step"] * 1e-3) for x in ranks) / world      # what one GPU does on such a shard
+    return {"mode": "predict-scaling", "n_gpus_modelled": world, "config": cfgname, "ranks": ranks,
+            "gradient_bucket_bytes": bucket_bytes, "allreduce_model_ms": comm_ms,
+            "predicted_ms_per_step": slow + comm_ms, "predicted_value": total / ((slow + comm_ms) * 1e-3),
+            "predicted_efficiency_vs_one_gpu_on_its_shard": total / ((slow + comm_ms) * 1e-3) / (world * mean_rate),
+            "imbalance_only": sum(x["ms_per_step"] for x in ranks) / world / slow,
+            "fixed_length_shard": {"ms_per_step": fixed_ms, "predicted_ms_per_step": fixed_ms + comm_ms,
+                                   "predicted_efficiency": fixed_ms / (fixed_ms + comm_ms)},
+            "single_gpu_rate": one, "unit": "utterances/s",
+            "note": "all-reduce modelled, not measured (one GPU per box); not overlapped with the backward pass (one-part bucket)"}
+
+
 def cfg5_leg(name, dropout, steps=6, warmup=2):
     """BASELINE config 5 through the module stack (mm_dfn_amd.MultiStreamGraphModel: six 512-d streams, L = 512,
     8 GCN layers, d = 100): fwd + FocalLoss + bwd of the whole model as one captured step."""
@@ -328,7 +391,7 @@ def cpu_baseline(cfg, batch, state, threads, dropout, budget_s):
 def main():
     a = parse()
     if a.config is None:
-        a.config = "cfg2" if a.gpus == 1 else "cfg4"
+        a.config = "cfg2" if (a.gpus == 1 and not a.predict_scaling) else "cfg4"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
     # stdout carries ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner
@@ -352,6 +415,10 @@ def main():
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # eager + captured steps share parameters
 
+    if a.predict_scaling:
+        out = predict_scaling(a.predict_scaling, a.config if a.config in ("cfg2", "cfg4") else "cfg4", a.dropout)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
     if a.only_roofline:
         out = {"note": "K6 roofline legs only (profiling aid)"}
         cfg = dict(synthetic.CONFIGS[a.config])
@@ -387,7 +454,7 @@ def main():
     label = train.flatten_labels(batch["label"], lengths)
     loss_f = FocalLoss(gamma=0.5)
     # sum-reduce with the 1/world factor folded into the loss scale below: no separate averaging kernel after the all-reduce
-    dp = distributed.GradientBucket(model, average=False) if use_dp else None
+    dp = distributed.GradientBucket(model, average=False, parts=2 if a.two_part_bucket else 1) if use_dp else None
     total_utt = distributed.all_reduce_scalar(n_utt) if use_dp else n_utt
 
     scale = (n_utt / total_utt) if dp is not None else 1.0   # local mean -> this rank's share of the GLOBAL mean
@@ -397,6 +464,7 @@ def main():
         loss = loss_f(logp, label)
         if dp is not None:
             loss = loss * scale        # the summed bucket is then the gradient of the mean over ALL ranks' utterances
+            dp.arm()                   # (two-part bucket: its first collective starts inside this backward pass)
         train.backward(loss)
         return loss
 
@@ -425,7 +493,7 @@ def main():
                       file=sys.stderr)
                 torch.cuda.synchronize()
                 captured = None
-                dp = distributed.GradientBucket(model, average=False)
+                dp = distributed.GradientBucket(model, average=False, parts=2 if a.two_part_bucket else 1)
         if captured is None:
             try:
                 captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)

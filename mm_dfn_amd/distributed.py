@@ -131,26 +131,51 @@ def register_slots(flat, params):
         off += slot_size(p)
 
 
+# parameters whose gradients are complete when the graph part of the backward pass ends (graph stack, fusion modules, head):
+# the first part of a two-part bucket
+EARLY_PREFIXES = ("graph_model.", "graph_net_", "smax_fc.", "mfn.", "gatedatt.")
+
+
 class GradientBucket:
     """Flat fp32 gradient bucket over the parameters that receive gradients.
 
     ``flatten()`` packs all live gradients into ONE contiguous buffer with a single multi-tensor copy
     (torch.cat -> one or two launches instead of one add/copy per parameter) and re-points every ``.grad``
     at its slice, so the all-reduce result is what the optimizer reads.  Backward passes therefore always
-    run with ``.grad = None`` (autograd hands over its buffers, no accumulation kernels)."""
+    run with ``.grad = None`` (autograd hands over its buffers, no accumulation kernels).
 
-    def __init__(self, model, average=True):
+    ``parts=2`` (off by default; bench.py --two-part-bucket): the flat buffer is laid out [graph stack + head | encoders]
+    and, from the second step on, reduced as TWO collectives -- the first is packed and started where the graph part of
+    the backward pass ends (ops.set_graph_backward_done_hook; the weight gradients queued so far leave first) and runs
+    while the encoders' backward (the GRU recurrences, ~40 % of a step) is still computing; the second follows the
+    backward pass.  Element-wise sums: the reduced buffer equals the one-collective result (bit for bit at two ranks,
+    tests/test_distributed_gloo.py; up to the ring's summation order beyond)."""
+
+    def __init__(self, model, average=True, parts=1):
         self.model = model
         self.average = average
+        self.parts = int(parts)
         self.flat = None
         self.params = None
+        self.split = 0                 # floats of the first part
+        self._early = None             # state of the step in progress: None | "packed" (first part packed and reduced / in flight)
+        self._work = None
+        self._comm_stream = None
 
-    def flatten(self):
-        live = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
-        if self.params is None:
-            self.params = bucket_order(self.model, live)
-            self._ids = [id(p) for p in live]
-        elif [id(p) for p in live] != self._ids:
+    # ---- layout
+    def _layout(self, live):
+        self.params = bucket_order(self.model, live)
+        if self.parts == 2:
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            early = [p for p in self.params if names[id(p)].startswith(EARLY_PREFIXES)]
+            late = [p for p in self.params if not names[id(p)].startswith(EARLY_PREFIXES)]
+            self.params = early + late
+            self._n_early = len(early)
+            self.split = sum(slot_size(p) for p in early)
+        self._ids = [id(p) for p in live]
+
+    def _check_live(self, live):
+        if [id(p) for p in live] != self._ids:
             # the bucket layout is frozen at the first step (flat optimizer state and all-reduce offsets depend on
             # it); a parameter that starts / stops receiving a gradient later would silently never be reduced or
             # updated -- or crash in the pack.  The reference's Adam skips grad-less parameters step by step
@@ -160,12 +185,24 @@ class GradientBucket:
             raise RuntimeError("GradientBucket: the set of parameters receiving gradients changed since the first step "
                                "(new: %s; missing: %s)" % (sorted(names[i] for i in now - was),
                                                            sorted(names[i] for i in was - now)))
-        grads = [piece for p in self.params for piece in slot_pieces(p.grad, p)]
-        if self.flat is None:
-            self.flat = torch.cat(grads)
-            register_slots(self.flat, self.params)
+
+    def flatten(self):
+        live = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+        if self.params is None:
+            self._layout(live)
         else:
-            torch.cat(grads, out=self.flat)
+            self._check_live(live)
+        if self._early == "packed":
+            # the first part left during the backward pass: only the encoders' gradients are packed now
+            late = self.params[self._n_early:]
+            torch.cat([piece for p in late for piece in slot_pieces(p.grad, p)], out=self.flat[self.split:])
+        else:
+            grads = [piece for p in self.params for piece in slot_pieces(p.grad, p)]
+            if self.flat is None:
+                self.flat = torch.cat(grads)
+                register_slots(self.flat, self.params)
+            else:
+                torch.cat(grads, out=self.flat)
         self.attach_views()
         return self.flat
 
@@ -175,8 +212,43 @@ class GradientBucket:
             p.grad = slot_view(self.flat, off, p)
             off += slot_size(p)
 
+    # ---- two-part protocol
+    def arm(self):
+        """Call before a backward pass (train.backward does not know about buckets): registers the hook that packs and
+        reduces the first part where the graph part of that backward pass ends.  A no-op for one-part buckets and
+        before the layout exists (the first step)."""
+        self._early, self._work = None, None
+        if self.parts == 2 and self.flat is not None:
+            from . import ops
+            ops.set_graph_backward_done_hook(self.early_part)
+
+    def early_part(self):
+        """The graph stack's and the head's gradients are complete: pack them and start their all-reduce."""
+        from . import ops
+        ops.set_graph_backward_done_hook(None)
+        if self.parts != 2 or self.flat is None or self._early is not None:
+            return
+        early = self.params[:self._n_early]
+        ops.flush_queued_wgrads_now()                  # weight gradients queued so far (all of them belong to this part)
+        if any(p.grad is None for p in early):
+            return                                     # not complete (an unusual graph): this step reduces in one piece
+        torch.cat([piece for p in early for piece in slot_pieces(p.grad, p)], out=self.flat[:self.split])
+        self._early = "packed"
+        part = self.flat[:self.split]
+        if dist.is_initialized():
+            if part.is_cuda:
+                self._work = dist.all_reduce(part, async_op=True)      # RCCL's stream: overlaps the encoders' backward
+            else:
+                dist.all_reduce(part)
+
     def reduce_flat(self):
-        dist.all_reduce(self.flat)
+        if self._early == "packed":
+            dist.all_reduce(self.flat[self.split:])
+            if self._work is not None:
+                self._work.wait()
+            self._early, self._work = None, None
+        else:
+            dist.all_reduce(self.flat)
         if self.average:
             self.flat.div_(dist.get_world_size())
         return self.flat

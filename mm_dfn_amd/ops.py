@@ -920,11 +920,33 @@ def _join_side():
     _WGQ["held"] = []
 
 
+_GRAPH_DONE_HOOK = [None]
+
+
+def set_graph_backward_done_hook(fn):
+    """``fn()`` is called ONCE where the graph part of the next backward pass ends (the adjacency builder's backward: the
+    graph stack's, the fusion modules' and the head's gradients are complete, the encoders' nodes follow).  A two-part
+    gradient bucket (distributed.GradientBucket(parts=2)) starts its first all-reduce there."""
+    _GRAPH_DONE_HOOK[0] = fn
+
+
+def flush_queued_wgrads_now():
+    """Issue the weight gradients queued so far on the current stream (the end-of-backward callback flushes the rest)."""
+    if _WGQ["outs"]:
+        outs = list(_WGQ["outs"].values())
+        _WGQ["outs"] = {}                    # 'armed' stays set: the end-of-backward callback still runs for the rest
+        _flush_outs(outs, None)
+
+
 def flush_queued_wgrads_early():
     """Called where the graph part of the backward pass ends (the adjacency builder's backward): what is queued so far
     leaves NOW on a side stream, concurrently with the encoder backward that follows on the main stream.  Gradient
     buffers and the workspace are allocated on the main stream (the caching allocator's stream of record), the operands
     stay referenced until the main stream has waited for the side stream (end-of-backward callback)."""
+    hook = _GRAPH_DONE_HOOK[0]
+    if hook is not None:
+        hook()                               # (a two-part bucket: flushes what is queued and starts its first collective)
+        return
     if not (EARLY_WGRAD and _WGQ["scope"] > 0 and _WGQ["outs"]):
         return
     outs = list(_WGQ["outs"].values())

@@ -188,3 +188,92 @@ def test_two_rank_bucket_order_keeps_gru_direction_pairs_adjacent(tmp_path):
         for k, p in model.named_parameters():
             if not k.startswith("dead"):
                 assert (g["grads"][k] - p.grad).abs().max() < 1e-6, k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# two-part bucket: the graph / head half is packed and reduced where the graph part of the backward pass ends
+# ------------------------------------------------------------------------------------------------------------------
+class _GraphDone(torch.autograd.Function):
+    """Identity between the 'encoder' and the 'graph' half of the stand-in below; its backward is where the product's
+    adjacency builder calls ops.flush_queued_wgrads_early() (-> the hook a two-part bucket registers)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from mm_dfn_amd import ops
+        ops.flush_queued_wgrads_early()
+        return g
+
+
+class TinyTwoHalves(torch.nn.Module):
+    """Parameter names of the real model's two halves: an encoder (projection + bidirectional GRU: late part) feeding
+    'graph_model.' / 'smax_fc.' layers (early part)."""
+
+    def __init__(self):
+        super().__init__()
+        self.linear_l = torch.nn.Linear(8, 8)
+        self.lstm_l = torch.nn.GRU(8, 4, num_layers=1, bidirectional=True)
+        self.graph_model = torch.nn.Sequential(torch.nn.Linear(8, 10), torch.nn.ReLU(), torch.nn.Linear(10, 7))
+        self.smax_fc = torch.nn.Linear(7, 6)
+        self.fired = 0
+
+    def forward(self, xs):
+        outs = []
+        for x in xs:
+            y, _ = self.lstm_l(self.linear_l(x).unsqueeze(1))
+            outs.append(y.squeeze(1))
+        h = _GraphDone.apply(torch.cat(outs))
+        return torch.log_softmax(self.smax_fc(self.graph_model(h)), 1)
+
+
+def two_part_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    distributed.init(backend="gloo")
+    lengths, xs, ys = make_data()
+    mine = distributed.shard_dialogues(lengths, world, rank)
+    y = torch.cat([ys[i] for i in mine])
+    loss_f = FocalLoss(gamma=0.5)
+    res = {}
+    for parts in (1, 2):
+        torch.manual_seed(0)
+        model = TinyTwoHalves()
+        bucket = distributed.GradientBucket(model, average=True, parts=parts)
+        started_early = []
+        for step in range(3):
+            model.zero_grad(set_to_none=True)
+            bucket.arm()
+            loss_f(model([xs[i] for i in mine]), y).backward()
+            started_early.append(bucket._early == "packed")
+            bucket.all_reduce()
+        names = {id(p): n for n, p in model.named_parameters()}
+        res[parts] = dict(flat=bucket.flat.clone(), order=[names[id(p)] for p in bucket.params], split=bucket.split,
+                          early=started_early, grads={n: p.grad.clone() for n, p in model.named_parameters()})
+    if rank == 0:
+        torch.save(res, out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_part_bucket_reduces_to_the_same_bits_as_one_collective(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(two_part_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    one, two = res[1], res[2]
+    # the first step lays the bucket out (one collective); from the second step on the graph / head half leaves early
+    assert two["early"] == [False, True, True] and one["early"] == [False, False, False]
+    n_early = sum(1 for n in two["order"] if n.startswith(distributed.EARLY_PREFIXES))
+    assert n_early == 6 and all(n.startswith(distributed.EARLY_PREFIXES) for n in two["order"][:n_early])
+    assert not any(n.startswith(distributed.EARLY_PREFIXES) for n in two["order"][n_early:])
+    assert 0 < two["split"] < two["flat"].numel()
+    # same reduced gradients, bit for bit (two ranks: a + b in either collective)
+    for n, g in one["grads"].items():
+        assert torch.equal(g, two["grads"][n]), n
+    # and the flat buffers hold the same values in their own orders
+    assert torch.equal(one["flat"].sort().values, two["flat"].sort().values)

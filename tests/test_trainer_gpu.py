@@ -369,6 +369,58 @@ def test_parameter_hooks_fire_under_the_weight_gradient_batch():
     assert m.lstm_l.weight_hh_l0.grad is not None       # un-hooked parameters still went through the batch
 
 
+def test_two_part_bucket_on_the_real_model_starts_its_first_collective_inside_backward():
+    """GradientBucket(parts=2) on the real model through RCCL (world size 1): from the second step on the graph / head
+    half is packed and reduced where the adjacency builder's backward ends (the hook fires inside loss.backward), the
+    gradients equal the one-part bucket's, eager and as nodes of a captured step."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from mm_dfn_amd import distributed
+    from mm_dfn_amd.graphs import CapturedStep
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+    s.close()
+    dist.init_process_group(backend="nccl")
+    try:
+        b, flat = _step_inputs(lengths=(20, 13, 7))
+        grads = {}
+        for parts in (1, 2):
+            m = _model(13).train()
+            bucket = distributed.GradientBucket(m, average=True, parts=parts)
+            early = []
+            for _ in range(3):
+                m.zero_grad(set_to_none=True)
+                bucket.arm()
+                T.backward(_loss(m, b, flat))
+                early.append(bucket._early == "packed")
+                bucket.all_reduce()
+            assert early == ([False, True, True] if parts == 2 else [False] * 3)
+            grads[parts] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+            if parts == 2:
+                names = {id(p): n for n, p in m.named_parameters()}
+                order = [names[id(p)] for p in bucket.params]
+                ne = sum(n.startswith(distributed.EARLY_PREFIXES) for n in order)
+                assert 0 < ne < len(order) and all(n.startswith(distributed.EARLY_PREFIXES) for n in order[:ne])
+                assert "lstm_l.weight_hh_l0" in order[ne:] and "graph_model.graph_net.rnn.weight_ih_l0" in order[:ne]
+
+                def fwd_bwd():
+                    bucket.arm()
+                    loss = _loss(m, b, flat)
+                    T.backward(loss)
+                    return loss
+                cap = CapturedStep(m, fwd_bwd, warmup=1, bucket=bucket, reduce_in_graph=True)
+                cap.replay()
+                torch.cuda.synchronize()
+                for n, g in grads[2].items():
+                    assert float((dict(m.named_parameters())[n].grad - g).abs().max()) <= 1e-6 * float(g.abs().max() + 1e-30), n
+        for n, g in grads[1].items():
+            assert torch.equal(g, grads[2][n]), n
+    finally:
+        dist.destroy_process_group()
+
+
 def test_weight_gradient_queue_survives_a_backward_that_raises():
     """A backward pass that raises leaves queued segments behind (the engine never runs the end-of-backward callback);
     the next step must not inherit them (every queued parameter silently lost its .grad for the rest of
