@@ -177,13 +177,39 @@ class DevicePrefetcher:
     computes; the consumer stream waits on the copy's event only.  Yields the reference's batch list with the six
     tensors resident on ``device`` (the trainer is then called with cuda_flag=False: nothing left to move)."""
 
-    def __init__(self, loader, device="cuda", depth=2):
+    def __init__(self, loader, device="cuda", depth=2, recycle=True, graph_cache=None, train_flag=False):
+        """``graph_cache`` (a train.StepGraphCache) + ``train_flag``: a batch whose signature has a captured step is copied
+        from pinned host memory STRAIGHT INTO that step's static input buffers (no device-side staging copy; the pass loop
+        receives those very tensors and copies nothing)."""
         self.loader = loader
+        self.recycle = recycle
+        self.graph_cache = graph_cache
+        self.train_flag = bool(train_flag)
         self.device = torch.device(device)
         self.depth = max(1, depth)
+        # device staging buffers are recycled (depth + 2 sets, each tensor slot grown to the largest batch seen): ragged
+        # batches otherwise ask the caching allocator for a new size every step and every other step ends in a hipMalloc
+        self._ring = [dict() for _ in range(self.depth + 2)]
+        self._ring_free = [None] * (self.depth + 2)      # event on the consumer's stream: the set's last batch has been used
+        self._turn = 0
+
+    def _device_buffer(self, slot, shape, dtype):
+        """A (shape) view of this turn's staging buffer for tensor ``slot`` (grown when a larger batch arrives)."""
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        ring = self._ring[self._turn % len(self._ring)]
+        buf = ring.get((slot, dtype))
+        if buf is None or buf.numel() < numel:
+            buf = ring[(slot, dtype)] = torch.empty(max(numel, 1), dtype=dtype, device=self.device)
+        return buf[:numel].view(*shape)
 
     def __len__(self):
         return len(self.loader)
+
+    def bind_graph_cache(self, graph_cache, train_flag):
+        """Called by train.train_or_eval_graph_model at the start of a pass that replays captured steps."""
+        self.graph_cache, self.train_flag = graph_cache, bool(train_flag)
 
     def _stage(self, batch, stream):
         tensors, rest = batch[:6], batch[6:]
@@ -193,9 +219,37 @@ class DevicePrefetcher:
         # the 256-thread host of the GPU box, tools/prof_stream.py)
         um = tensors[4].numpy()
         lengths = [int(v) for v in ((um == 1) * np.arange(1, um.shape[1] + 1)[None, :]).max(1)]
+        ent = None
+        if self.graph_cache is not None:
+            ent = self.graph_cache.claim_static([t.shape for t in tensors], lengths, self.train_flag)
+        if ent is not None:
+            if ent.get("done") is not None:
+                stream.wait_event(ent["done"])       # the entry's last replay has read its inputs
+            with torch.cuda.stream(stream):
+                dev = []
+                for t, dst in zip(tensors, ent["static"]):
+                    h = t if t.is_pinned() else t.pin_memory()
+                    base = getattr(dst, "_mmdfn_padbase", None)
+                    if base is not None:             # row-padded static buffer: pad on the host, one contiguous copy
+                        K = t.shape[-1]
+                        hp = torch.empty(tuple(base.shape), dtype=torch.float32, pin_memory=True)
+                        hn = hp.numpy()
+                        hn[..., :K] = t.numpy()
+                        hn[..., K:] = 0.0
+                        base.copy_(hp, non_blocking=True)
+                    else:
+                        dst.copy_(h, non_blocking=True)
+                    dev.append(dst)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            return dev, list(rest), ev, lengths, None
+        self._turn += 1
+        free = self._ring_free[self._turn % len(self._ring)]
+        if free is not None:
+            stream.wait_event(free)          # the copy engine must not overwrite a set the consumer's stream still reads
         with torch.cuda.stream(stream):
             dev = []
-            for t in tensors:
+            for slot, t in enumerate(tensors):
                 if t.dim() == 3 and t.dtype == torch.float32 and t.shape[-1] % 4:
                     # feature width not a multiple of 4 (1582-d audio, 342-d visual features): the pinned staging buffer
                     # is row-padded to the next multiple of 4 (pad columns zero), so the device copy is the operand the
@@ -212,10 +266,15 @@ class DevicePrefetcher:
                     dev.append(view)
                     continue
                 h = t if t.is_pinned() else t.pin_memory()
-                dev.append(h.to(self.device, non_blocking=True))
+                if not self.recycle:
+                    dev.append(h.to(self.device, non_blocking=True))
+                    continue
+                d = self._device_buffer(slot, tuple(h.shape), h.dtype)
+                d.copy_(h, non_blocking=True)
+                dev.append(d)
             ev = torch.cuda.Event()
             ev.record(stream)
-        return dev, list(rest), ev, lengths
+        return dev, list(rest), ev, lengths, self._turn % len(self._ring)
 
     def __iter__(self):
         stream = torch.cuda.Stream(device=self.device)
@@ -227,10 +286,11 @@ class DevicePrefetcher:
         except StopIteration:
             pass
         while queue:
-            dev, rest, ev, lengths = queue.pop(0)
+            dev, rest, ev, lengths, ring_slot = queue.pop(0)
             torch.cuda.current_stream(self.device).wait_event(ev)
-            for t in dev:
-                t.record_stream(torch.cuda.current_stream(self.device))
+            if not self.recycle:
+                for t in dev:
+                    t.record_stream(torch.cuda.current_stream(self.device))
             try:
                 queue.append(self._stage(next(it), stream))
             except StopIteration:
@@ -238,6 +298,11 @@ class DevicePrefetcher:
             out = DeviceBatch(dev + rest)
             out.lengths = lengths
             yield out
+            # the consumer has enqueued everything that reads this batch: its staging set may be refilled after that
+            if ring_slot is not None:
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                self._ring_free[ring_slot] = done
 
 
 def write_synthetic_pickle(path, dataset="IEMOCAP", n_train=24, n_test=8, max_len=40, min_len=3, D_t=100, D_a=100,

@@ -186,7 +186,9 @@ class GradientBucket:
                                "(new: %s; missing: %s)" % (sorted(names[i] for i in now - was),
                                                            sorted(names[i] for i in was - now)))
 
-    def flatten(self):
+    def flatten(self, attach=True):
+        """``attach=False``: pack only (the fused optimizer reads the flat buffer; ``.grad`` keeps pointing at the tensors
+        the backward pass produced -- ~100 fewer view operations on the host per step)."""
         live = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
         if self.params is None:
             self._layout(live)
@@ -203,7 +205,8 @@ class GradientBucket:
                 register_slots(self.flat, self.params)
             else:
                 torch.cat(grads, out=self.flat)
-        self.attach_views()
+        if attach:
+            self.attach_views()
         return self.flat
 
     def attach_views(self):

@@ -45,7 +45,8 @@ class FlatAdam:
     def step(self, grads_already_flat=False):
         """Pack gradients (unless the caller already did, e.g. after the data-parallel all-reduce) and update."""
         if not grads_already_flat:
-            self.bucket.flatten()
+            # (single process: nothing reads the gradients as views of the bucket, so they are only packed)
+            self.bucket.flatten(attach=self.flat_p is None)
         g = self.bucket.flat
         _hip.require_cuda(g)
         if self.flat_p is None:

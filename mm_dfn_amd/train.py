@@ -74,11 +74,27 @@ class StepGraphCache:
         self.entries = OrderedDict()
         self.hits = self.misses = self.recaptures = 0
 
+    @staticmethod
+    def signature(shapes, lengths, train_flag, test_label=False):
+        return (bool(train_flag), bool(test_label), tuple(int(x) for x in lengths)) + tuple(tuple(s_) for s_ in shapes)
+
+    def claim_static(self, shapes, lengths, train_flag, test_label=False):
+        """For a loader that stages batches on the device (data.DevicePrefetcher(graph_cache=...)): the static input
+        buffers of the captured step this batch will replay, or None (signature not captured yet, or its buffers are
+        already promised to a staged batch that has not been stepped).  The caller copies the batch INTO them (after
+        waiting for ``entry["done"]``, the event behind the entry's last replay) and hands exactly these tensors to
+        ``step``, which then has nothing to copy."""
+        ent = self.entries.get(self.signature(shapes, lengths, train_flag, test_label))
+        if ent is None or ent.get("reserved"):
+            return None
+        ent["reserved"] = True
+        return ent
+
     def step(self, inputs, lengths, train_flag, test_label=False):
         """inputs = (textf, visuf, acouf, qmask, umask, label) on the device.  Returns (loss, log_prob, flat_labels):
         tensors owned by the cache entry -- consume (or clone) them before this signature is stepped again."""
         from .graphs import CapturedStep
-        key = (bool(train_flag), bool(test_label), tuple(int(x) for x in lengths)) + tuple(tuple(t.shape) for t in inputs)
+        key = self.signature([t.shape for t in inputs], lengths, train_flag, test_label)
         ent = self.entries.get(key)
         if ent is None:
             self.misses += 1
@@ -97,6 +113,7 @@ class StepGraphCache:
             def fn():
                 torch.index_select(label.reshape(-1), 0, pos, out=flat)     # inside the graph: this batch's labels
                 out["log_prob"] = model(textf, qmask, umask, lengths, acouf, visuf, test_label)[0]
+                out["pred"] = torch.argmax(out["log_prob"], 1)          # (the pass loop's per-step metric input)
                 loss = loss_f(out["log_prob"], flat)
                 if train_flag:
                     backward(loss)
@@ -109,15 +126,23 @@ class StepGraphCache:
             model.train(mode)
             # everything the graph reads that was allocated OUTSIDE the capture must live as long as the graph: the
             # static inputs, the label gather index and the flattened labels (the closure itself is kept by cap)
-            ent = dict(static=static, cap=cap, out=out, flat=flat, pos=pos)
+            ent = dict(static=static, cap=cap, out=out, flat=flat, pos=pos, pending=None)
             self.entries[key] = ent
             while len(self.entries) > self.max_entries:
                 self.entries.popitem(last=False)
         else:
             self.hits += 1
             self.entries.move_to_end(key)
-            for dst, src in zip(ent["static"], inputs):
-                dst.copy_(src, non_blocking=True)
+            if ent.get("pending") is not None:
+                ent["pending"]()               # results of this entry's previous step are still referenced: copy them out first
+                ent["pending"] = None
+            # the batch goes into the entry's static buffers as ONE multi-tensor copy per dtype (two launches instead of six)
+            fl = [(d, s_) for d, s_ in zip(ent["static"], inputs) if d.is_floating_point() and d is not s_]
+            it = [(d, s_) for d, s_ in zip(ent["static"], inputs) if not d.is_floating_point() and d is not s_]
+            for grp in (fl, it):
+                if grp:
+                    torch._foreach_copy_([g[0] for g in grp], [g[1] for g in grp], non_blocking=True)
+        ent["reserved"] = False
         cap = ent["cap"]
         try:
             loss = cap.replay()
@@ -132,6 +157,12 @@ class StepGraphCache:
         if train_flag:
             for name, p in self.model.named_parameters():
                 p.grad = cap.grads.get(name)
+        self.last_entry = ent
+        if loss.is_cuda:
+            done = ent.get("done")
+            if done is None:
+                done = ent["done"] = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(loss.device))       # the static inputs may be refilled after this
         return loss, ent["out"]["log_prob"], ent["flat"]
 
 
@@ -144,6 +175,10 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
     model.train() if train_flag else model.eval()
     seed_everything(seed)
     vids = []
+    if hasattr(dataloader, "bind_graph_cache"):
+        # a device-staging loader copies every batch whose signature is already captured straight into that step's static
+        # input buffers (data.DevicePrefetcher): nothing is left to copy on the device
+        dataloader.bind_graph_cache(graph_cache if not test_label else None, train_flag)
     for data in dataloader:
         if train_flag and graph_cache is None:
             optimizer.zero_grad()         # (a replayed step hands over fresh gradient tensors: nothing to reset)
@@ -152,9 +187,18 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
         if graph_cache is not None and not test_label:      # (the --test_label dumps call .cpu() / np.save: never captured)
             loss, log_prob, flat = graph_cache.step((textf, visuf, acouf, qmask, umask, label), lengths, train_flag,
                                                     test_label)
-            preds.append(torch.argmax(log_prob, 1))
-            labels.append(flat.clone())
-            losses.append(loss.detach().clone())
+            # metrics are deferred to the end of the pass: the step's predictions, labels and loss stay where the graph
+            # wrote them (no per-step copy launches) unless this cache entry is stepped again before the pass ends, in
+            # which case they are copied out first (StepGraphCache runs the entry's ``pending`` closure)
+            ent = graph_cache.last_entry
+            slot = len(preds)
+            preds.append(ent["out"]["pred"])
+            labels.append(flat)
+            losses.append(loss.detach())
+
+            def materialise(slot=slot):
+                preds[slot], labels[slot], losses[slot] = preds[slot].clone(), labels[slot].clone(), losses[slot].clone()
+            ent["pending"] = materialise
         else:
             log_prob, e_i, e_n, e_t, e_l = model(textf, qmask, umask, lengths, acouf, visuf, test_label)
             flat = flatten_labels(label, lengths)
@@ -173,6 +217,9 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
             vids = data[6]
     if not preds:
         return [], [], float('nan'), float('nan'), [], [], float('nan'), []
+    if graph_cache is not None:
+        for ent in graph_cache.entries.values():
+            ent["pending"] = None             # everything is consumed right below
     preds = torch.cat(preds).cpu().numpy()
     labels = torch.cat(labels).cpu().numpy()
     losses = torch.stack(losses).cpu().numpy()

@@ -115,6 +115,33 @@ def test_flat_adam_state_dict_roundtrip_and_lr_schedule():
         assert float((a - c).abs().max()) < 1e-7, k
 
 
+def test_prefetcher_stages_straight_into_captured_static_buffers(tmp_path):
+    """Pass loop + StepGraphCache + DevicePrefetcher: from the second pass on every batch is copied from pinned host memory
+    directly into its captured step's static input buffers (the step receives those very tensors), deferred metrics survive
+    a signature that repeats inside a pass, and the results equal the eager pass loop's."""
+    p = D.write_synthetic_pickle(str(tmp_path / "f.pkl"), n_train=4, n_test=18, max_len=24, seed=8)
+    names = ['hap', 'sad', 'neu', 'ang', 'exc', 'fru']
+    _, _, te = D.get_IEMOCAP_loaders(p, batch_size=3, valid_rate=0.0)
+    batches = [list(b) for b in te]
+    batches = batches + [batches[1]]                 # one signature twice in a pass: its outputs must be copied out in time
+    m = _model(19)
+    loss_f = FocalLoss(gamma=0.5)
+    want = T.train_or_eval_graph_model(m, loss_f, batches, cuda_flag=True, target_names=names)
+    cache = T.StepGraphCache(m, loss_f)
+    pre = D.DevicePrefetcher(batches, depth=2)
+    first = T.train_or_eval_graph_model(m, loss_f, pre, target_names=names, graph_cache=cache)
+    assert cache.misses == len(batches) - 1 and cache.hits == 1
+    claimed = []
+    orig = cache.claim_static
+    cache.claim_static = lambda *a, **k: claimed.append(orig(*a, **k)) or claimed[-1]
+    second = T.train_or_eval_graph_model(m, loss_f, D.DevicePrefetcher(batches, depth=2), target_names=names, graph_cache=cache)
+    # every batch found its captured entry; the repeated signature was staged the ordinary way while its buffers were promised
+    assert len(claimed) == len(batches) and sum(c is not None for c in claimed) >= len(batches) - 1
+    for got in (first, second):
+        assert got[3] == want[3] and got[6] == want[6] and np.array_equal(got[5], want[5])
+        assert abs(got[2] - want[2]) < 1e-3
+
+
 def test_dropout_stream_is_not_rewound_by_captured_steps():
     """building a captured step must consume no random numbers and replays must move torch's generator along,
     so that two signatures captured and stepped back to back (every step of a first epoch is a cache miss) draw their keep
