@@ -8,7 +8,8 @@ kernels: h0 feeds every layer (the kernels accumulate dh0 in place), the adjacen
 accumulates dA in place) and the LSTM cell is shared by all layers (its weight gradients are extra segments of one
 reduction in the end-of-backward batch, ops.queue_wgrad).  Parameters must be leaf tensors (their gradients are
 written to ``.grad`` by that batch); GCNII_lyc falls back to the op-by-op path otherwise, and for launches of more
-than ROW_LIMIT rows, where the unfused contractions run on the bf16-piece pipeline instead of 16-row exact-f32 blocks.
+than ROW_LIMIT rows (beyond anything measured: the fused node is ahead of the op-by-op path with its bf16-piece GEMMs from
+5 280 to 98 304 rows, tools/time_stack_paths.py).
 """
 import math
 
@@ -16,7 +17,7 @@ import torch
 
 from . import _hip, ops
 
-ROW_LIMIT = 32768
+ROW_LIMIT = 131072        # measured to 98 304 rows (cfg5 B = 32): the fused node is 8-9 % ahead of the op-by-op path at every size (round 4)
 # test tap: a list to which every forward of the fused node appends references to its ReLU decisions (h0, the per-layer
 # gate masks, the output) -- tests/util.relu_flips_from_tap compares them with the oracle's pre-activations to find the
 # units whose pre-activation is within rounding of zero and landed on the other side.  None (the default): nothing is kept.

@@ -1,5 +1,13 @@
 """Per-step time by kernel family from a rocprofv3 --kernel-trace --stats CSV of `bench.py --no-extra --no-roofline
---no-cpu-baseline` (one workload per CSV).    python tools/step_breakdown.py <kernel_stats.csv> <out.json> [label]"""
+--no-cpu-baseline` (one workload per CSV).    python tools/step_breakdown.py <kernel_stats.csv> <out.json> [label] [T]
+
+T = timesteps of the recurrent encoders (the padded dialogue length): with it the GRU recurrence -- the family that
+dominates the BASELINE cfg2-cfg4 steps and is bound by neither HBM nor the matrix pipe -- gets a stated bound: the serial
+chain of T timesteps per launch, priced (a) by the measured floor of the ablation skeleton (the time loop with nothing but
+the h write and the per-step barrier: 0.185 us per timestep, profiles/r03_gru_kernels.md) and (b) by the dependent chain of
+a full timestep (barrier release -> h broadcast load -> 13 FMA groups -> 2-level add -> DPP add -> r, z, n gates -> h ->
+LDS write: ~20 dependent VALU results at ~9 cycles, 4 transcendentals at ~25, 3 LDS latencies at ~100 and 330 cycles of
+FMA issue = ~0.41 us at 2.2 GHz)."""
 import csv
 import json
 import re
@@ -44,6 +52,20 @@ def main():
            "families": {k: {"us_per_step": round(v["us_per_step"], 1), "share": round(v["us_per_step"] / total, 3),
                             "launches_per_step": round(v["launches_per_step"], 1)}
                         for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["us_per_step"]) if v["us_per_step"] > 0}}
+    T = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    g = out["families"].get("gru_recurrence")
+    if T and g:
+        launches = g["launches_per_step"]
+        floor_us, chain_us = 0.185, 0.41
+        out["families"]["gru_recurrence"]["bound"] = {
+            "kind": "latency: T serial timesteps per launch (no HBM / MFMA roofline applies)", "T": T,
+            "recurrence_launches_per_step": launches,
+            "skeleton_floor_us_per_timestep": floor_us, "bound_us_per_step": round(launches * T * floor_us, 1),
+            "frac": round(launches * T * floor_us / g["us_per_step"], 3),
+            "dependent_chain_us_per_timestep": chain_us, "chain_bound_us_per_step": round(launches * T * chain_us, 1),
+            "chain_frac": round(launches * T * chain_us / g["us_per_step"], 3),
+            "achieved_us_per_timestep": round(g["us_per_step"] / (launches * T), 3),
+            "source": "profiles/r03_gru_kernels.md (compile-time ablations of gru_seq_fwd_io_kernel)"}
     dom = next(iter(out["families"]))
     out["dominant"] = "%s: %.0f us of %.0f us kernel time per step (%.0f %%)" % (
         dom, out["families"][dom]["us_per_step"], total, 100 * out["families"][dom]["share"])

@@ -11,7 +11,7 @@ from mm_dfn_amd import GCNII_lyc, gcn_stack, ops  # noqa: E402
 from mm_dfn_amd.graphs import CapturedStep  # noqa: E402
 
 dev = "cuda"
-for B, L, M, nl in ((16, 110, 3, 2), (32, 110, 3, 2), (48, 110, 3, 2), (4, 512, 6, 8), (8, 512, 6, 8), (16, 512, 6, 8)):
+for B, L, M, nl in [tuple(int(v) for v in c.split("x")) for c in os.environ.get("CASES", "16x110x3x2,32x110x3x2,48x110x3x2,4x512x6x8,8x512x6x8,16x512x6x8,32x512x6x8").split(",")]:
     lengths = [L] * B
     N = L * B
     feats = torch.randn(M, N, 200, device=dev, requires_grad=True)
