@@ -1122,6 +1122,15 @@ inline bool gate_ws(int R) {
     return R >= 64;
 }
 
+// bf16-piece form of the K8 forward (lstm_gate_split.hip) from GATE_SPLIT_ROWS rows on (tuning build: MMDFN_GATE_SPLIT=0|1 forces)
+constexpr int GATE_SPLIT_ROWS = 16384;
+inline bool gate_split(int R, int H) {
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GATE_SPLIT")) return atoi(e) != 0;
+#endif
+    return R >= GATE_SPLIT_ROWS && H >= 32;
+}
+
 inline int row_groups(int R, int column_blocks) {
     const int nrb = (R + RB - 1) / RB;
     int gq = (256 + column_blocks - 1) / column_blocks;     // ~ one workgroup per CU (LDS holds one weight slice per CU)
@@ -1166,6 +1175,12 @@ extern "C" int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* 
                                    const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
                                    void* stream) {
     if (bad_dims(R, H) || (h == nullptr) != (c == nullptr)) return -1;
+    if (gate_split(R, H)) {
+        // many rows: the contraction on the bf16 matrix path, cell math from the accumulators (lstm_gate_split.hip)
+        const int rc = mmdfn_launch_lstm_gate_fwd_split(q, h, c, Wih, Whh, bsum, bsum2, gates, h_out, c_out, R, H,
+                                                        (hipStream_t)stream);
+        if (rc != -2) return rc;
+    }
     const int ncb = (H + UB - 1) / UB;
     if (gate_ws(R)) {
         const size_t ldsw = ((size_t)(4 * UB + 2 * RB) * lds_stride(h ? 2 * H : H) + 2 * 4 * RB * (UB + 4)) * sizeof(float);

@@ -626,7 +626,9 @@ def test_gcn_input_stage_kernels(R, F, H, masked, residue):
 @pytest.mark.parametrize("R,H,first", [(37, 100, False), (37, 100, True), (600, 36, False), (3, 4, True), (2000, 96, False),
                                        (5280, 100, False),
                                        # larger launches (ragged last block, first layer, narrow H, BASELINE cfg5 rows)
-                                       (4097, 100, False), (4100, 100, True), (4111, 36, False), (24576, 100, False)])
+                                       (4097, 100, False), (4100, 100, True), (4111, 36, False), (24576, 100, False),
+                                       # the bf16-piece forward (>= 16 384 rows): first layer, ragged last tile, narrow / odd unit blocks
+                                       (24576, 100, True), (16500, 36, False), (17001, 96, True), (16385, 68, False)])
 def test_lstm_gate_kernels(R, H, first):
     from mm_dfn_amd import _hip
     lib, P, st = _hip.lib(), _hip.ptr, _hip.stream
@@ -673,6 +675,36 @@ def test_lstm_gate_kernels(R, H, first):
     assert lib.mmdfn_lstm_gate_bwd(P(gates), P(c), P(c_out), P(dh_a), None, None, P(Wih), P(Whh), None, P(dG), P(dcp),
                                    P(dq), P(dhp), R, H, 0 if first else 1, 0, st()) == 0
     assert torch.isfinite(dq).all()
+
+
+def test_lstm_gate_forward_bf16_piece_form_against_the_exact_f32_form(kernel_variants):
+    """The many-row K8 forward (csrc/lstm_gate_split.hip: three exact bf16 pieces per operand, six MFMA products, cell math from
+    the accumulators) against the exact-f32 producer / consumer kernel on the same inputs, both against fp64: its error is at
+    most 4x the exact-f32 kernel's (+ the transcendental units' 3e-7); also forced on a launch below its row threshold."""
+    from mm_dfn_amd import _hip
+    P, st = _hip.ptr, _hip.stream
+    for R, H, first in ((24576, 100, False), (300, 100, False), (1000, 36, True)):
+        rs = np.random.RandomState(84)
+        q = _rnd(rs, R, H)
+        h, c = (None, None) if first else (_rnd(rs, R, H), _rnd(rs, R, H))
+        Wih, Whh, b_ih, b_hh = _rnd(rs, 4 * H, H, scale=0.2), _rnd(rs, 4 * H, H, scale=0.2), _rnd(rs, 4 * H), _rnd(rs, 4 * H)
+        res = {}
+        for mode in ("0", "1"):
+            kernel_variants.setenv("MMDFN_GATE_SPLIT", mode)
+            gates, h_out, c_out = (torch.empty(R, n, device=DEV) for n in (4 * H, H, H))
+            assert _hip.lib().mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(Wih), P(Whh), P(b_ih), P(b_hh), P(gates), P(h_out),
+                                                  P(c_out), R, H, st()) == 0
+            res[mode] = (gates, h_out, c_out)
+        d = lambda t: None if t is None else t.double().cpu()
+        G = d(q) @ d(Wih).t() + d(b_ih) + d(b_hh) + (0 if first else d(h) @ d(Whh).t())
+        i, f, g, o = (torch.sigmoid(G[:, :H]), torch.sigmoid(G[:, H:2 * H]), torch.tanh(G[:, 2 * H:3 * H]), torch.sigmoid(G[:, 3 * H:]))
+        c_w = i * g + (0 if first else f * d(c))
+        want = (torch.cat([i, f, g, o], 1), o * torch.tanh(c_w), c_w)
+        for k in range(3):
+            e_f32 = float((res["0"][k].double().cpu() - want[k]).abs().max())
+            e_bf = float((res["1"][k].double().cpu() - want[k]).abs().max())
+            assert e_bf <= 4 * e_f32 + 3e-7, (R, H, first, k, e_bf, e_f32)
+        assert float((res["0"][1] - res["1"][1]).abs().max()) > 0.0          # it really was another kernel
 
 
 @pytest.mark.parametrize("R,H,masked,has_q,ldo", [(37, 100, True, True, 300), (500, 100, False, False, 100), (9, 36, True, True, 36),
