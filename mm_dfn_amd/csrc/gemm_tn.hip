@@ -705,16 +705,58 @@ static int batch_eff_splits(int R, int M, int N, int rows_target, int* rps_out) 
     return (R + rps - 1) / rps;
 }
 
+// bf16-piece form (gemm_tn_split.hip): every segment of the batch on 128 x 112 tiles of v_mfma_f32_16x16x32_bf16.  One workgroup
+// of 8 waves per CU (110 KB of LDS), so the batch is cut into about TNS_WGS workgroups of equal length: rows per split =
+// (sum over segments of output tiles x rows) / TNS_WGS, between 256 and 4 096 rows.
+#ifdef MMDFN_TUNING
+static bool tns_enabled() { const char* e = getenv("MMDFN_TN_SPLIT"); return !e || atoi(e) != 0; }
+#else
+constexpr bool tns_enabled() { return true; }
+#endif
+static int tns_tiles(int M, int N, int* nblocks) {
+    const int nb = (N + MMDFN_TNS_TN - 1) / MMDFN_TNS_TN;
+    if (nblocks) *nblocks = nb;
+    return ((M + MMDFN_TNS_TM - 1) / MMDFN_TNS_TM) * nb;
+}
+static int tns_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
+    double units = 0.0;
+    for (int s = 0; s < nseg; ++s) {
+        const int o = out[s];
+        if (o < 0 || o >= nout) continue;
+        units += (double)tns_tiles(M[o], N[o], nullptr) * R[s];
+    }
+    double wgs = 512.0;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_TNS_WGS")) wgs = atof(e);
+#endif
+    int rt = (int)(units / wgs);
+    rt = rt < 256 ? 256 : (rt > 4096 ? 4096 : rt);
+    return rt;
+}
+static int tns_eff_splits(int R, int rows_target, int* rps_out) {
+    // a multiple of 8 (one split per XCD and round), nearest to rows / target; short segments: at least two chunks per split
+    int splits = 8 * ((R + 4 * rows_target) / (8 * rows_target));
+    if (splits < 8) splits = 8;
+    const int max_s = (R + 2 * MMDFN_TNS_BK - 1) / (2 * MMDFN_TNS_BK);
+    if (splits > max_s) splits = max_s;
+    if (splits < 1) splits = 1;
+    const int rps = ((R + splits - 1) / splits + MMDFN_TNS_BK - 1) / MMDFN_TNS_BK * MMDFN_TNS_BK;
+    if (rps_out) *rps_out = rps;
+    return (R + rps - 1) / rps;
+}
+
 extern "C" int64_t mmdfn_gemm_tn_batch_workspace(int nseg, const int* R, const int* out, int nout, const int* M,
                                                  const int* N) {
     int64_t total = 0;
     const TallPlan plan = tall_plan(nseg, R, out, nout, M, N);
     const int rt = batch_rows_target(nseg, R, out, nout, M, N, plan.on);
+    const int rt_split = tns_rows_target(nseg, R, out, nout, M, N);
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout) return -1;
         int eff = batch_eff_splits(R[s], M[o], N[o], rt, nullptr);
         if (plan.on && tn_tall_shape1(R[s], M[o], N[o])) eff = std::max(eff, tall_eff_splits(R[s], M[o], plan, nullptr));   // (either form may run)
+        eff = std::max(eff, tns_eff_splits(R[s], rt_split, nullptr));
         total += (int64_t)eff * ((int64_t)M[o] * N[o] + M[o]);
     }
     return total;
@@ -736,12 +778,19 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
         out_splits[o] = 0;
         if (M[o] <= 0 || N[o] <= 0 || (M[o] & 3) || (N[o] & 3) || ldc[o] < N[o]) return -1;
     }
+    // the bf16-piece form takes the whole batch when every operand is 16-byte aligned (its loads are float4 like the tiled
+    // form's, which the launch checks of that form never enforced on the base pointers)
+    bool split_form = tns_enabled();
+    for (int s = 0; s < nseg && split_form; ++s)
+        if ((((uintptr_t)A[s] | (uintptr_t)B[s]) & 15) != 0) split_form = false;
+    const int rt_split = tns_rows_target(nseg, R, out, nout, M, N);
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout || R[s] <= 0 || (lda[s] & 3) || (ldb[s] & 3) || lda[s] < M[o] || ldb[s] < N[o]) return -1;
-        seg_tall[s] = plan.on && tn_tall_shape1(R[s], M[o], N[o]) && (bshift == nullptr || bshift[s] == 0) &&
+        seg_tall[s] = !split_form && plan.on && tn_tall_shape1(R[s], M[o], N[o]) && (bshift == nullptr || bshift[s] == 0) &&
                       (((uintptr_t)A[s] | (uintptr_t)B[s]) & 15) == 0;
-        seg_eff[s] = seg_tall[s] ? tall_eff_splits(R[s], M[o], plan, &seg_rps[s]) : batch_eff_splits(R[s], M[o], N[o], rt, &seg_rps[s]);
+        seg_eff[s] = split_form ? tns_eff_splits(R[s], rt_split, &seg_rps[s])
+                     : seg_tall[s] ? tall_eff_splits(R[s], M[o], plan, &seg_rps[s]) : batch_eff_splits(R[s], M[o], N[o], rt, &seg_rps[s]);
         out_splits[o] += seg_eff[s];
     }
     // workspace layout: per output [splits][M][N] then [splits][M]
@@ -774,6 +823,39 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     }
     int used[TN_MAXOUT];
     for (int o = 0; o < nout; ++o) used[o] = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (split_form) {
+        // longest workgroups first
+        int ord[TN_MAXSEG];
+        for (int s = 0; s < nseg; ++s) ord[s] = s;
+        std::stable_sort(ord, ord + nseg, [&](int a, int b) { return seg_rps[a] > seg_rps[b]; });
+        TnSplitSegs tq;
+        tq.n = nseg;
+        tq.wg_prefix[0] = 0;
+        for (int k = 0; k < nseg; ++k) {
+            const int s = ord[k], o = out[s];
+            int nb = 1;
+            const int tiles = tns_tiles(M[o], N[o], &nb);
+            tq.A[k] = A[s]; tq.B[k] = B[s];
+            tq.part[k] = part_base[o] + (int64_t)used[o] * M[o] * N[o];
+            tq.colpart[k] = (oq.colsum[o] != nullptr) ? col_base[o] + (int64_t)used[o] * M[o] : nullptr;
+            used[o] += seg_eff[s];
+            tq.R[k] = R[s]; tq.lda[k] = lda[s]; tq.ldb[k] = ldb[s]; tq.bshift[k] = bshift ? bshift[s] : 0;
+            tq.rows_per_split[k] = seg_rps[s]; tq.splits[k] = seg_eff[s]; tq.tiles[k] = tiles; tq.nblocks[k] = nb;
+            tq.M[k] = M[o]; tq.N[k] = N[o];
+            tq.wg_prefix[k + 1] = tq.wg_prefix[k] + tiles * 8 * ((seg_eff[s] + 7) / 8);
+        }
+        for (int k = nseg; k < MMDFN_TNS_MAXSEG; ++k) {
+            tq.A[k] = tq.B[k] = nullptr; tq.part[k] = tq.colpart[k] = nullptr;
+            tq.R[k] = tq.lda[k] = tq.ldb[k] = tq.bshift[k] = tq.rows_per_split[k] = tq.splits[k] = tq.tiles[k] = tq.nblocks[k] = 0;
+            tq.M[k] = tq.N[k] = 0;
+            tq.wg_prefix[k + 1] = tq.wg_prefix[nseg];
+        }
+        if (int e = mmdfn_launch_gemm_tn_split(tq, st)) return e;
+        hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[nout]), dim3(256), 0, st, oq);
+        MMDFN_CHECK_LAUNCH();
+        return 0;
+    }
     const bool use_wide = !tn_no_wide();
     // order: tall segments first, the 49-tile kind before the 14-tile kind (longest workgroups first; alternating the two kinds
     // measured 15 % slower), then the segments on the tiled bodies
@@ -813,7 +895,6 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
         sq.R[s] = sq.lda[s] = sq.ldb[s] = sq.bshift[s] = sq.rows_per_split[s] = sq.tiles[s] = sq.M[s] = sq.N[s] = 0;
         sq.wg_prefix[s + 1] = sq.wg_prefix[nseg];
     }
-    hipStream_t st = (hipStream_t)stream;
     if (ntall > 0) {
         void (*kern)(const TnSegs) = gemm_tn_tall_kernel<0>;
 #ifdef MMDFN_TUNING

@@ -87,3 +87,26 @@ int mmdfn_launch_tile_dot_split(const float* X, const float* Y, float* out_tiles
 int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, float* out_aux, float* deg,
                           const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                           int B, int M, int N, int K, int ldx, int ldy, int max_len, int epi, int accumulate, hipStream_t s);
+
+// bf16-piece form of the weight-gradient batch (gemm_tn_split.hip): the segment table of one launch.  A workgroup owns a
+// MMDFN_TNS_TM x MMDFN_TNS_TN output tile of segment p over the rows [split * rows_per_split, ...) of its split; tiles =
+// row tiles x nblocks (column blocks).  part / colpart: the slab stacks of gemm_tn.hip's batch ([split][M][N], [split][M]).
+// Block index -> (split, tile) inside a segment's range of 8 ceil(splits / 8) tiles blocks: XCD = block % 8 takes the splits
+// = its number (mod 8), all tiles of a split back to back -- the workgroups that read the same operand rows run on one XCD
+// at the same time and share them through its L2 (blocks of splits past the last one exit at once).
+#define MMDFN_TNS_BK 32
+#define MMDFN_TNS_TM 128
+#define MMDFN_TNS_TN 112
+constexpr int MMDFN_TNS_MAXSEG = 40;
+struct TnSplitSegs {
+    const float* A[MMDFN_TNS_MAXSEG];
+    const float* B[MMDFN_TNS_MAXSEG];
+    float* part[MMDFN_TNS_MAXSEG];
+    float* colpart[MMDFN_TNS_MAXSEG];
+    int R[MMDFN_TNS_MAXSEG], lda[MMDFN_TNS_MAXSEG], ldb[MMDFN_TNS_MAXSEG], bshift[MMDFN_TNS_MAXSEG];
+    int rows_per_split[MMDFN_TNS_MAXSEG], splits[MMDFN_TNS_MAXSEG], tiles[MMDFN_TNS_MAXSEG], nblocks[MMDFN_TNS_MAXSEG];
+    int M[MMDFN_TNS_MAXSEG], N[MMDFN_TNS_MAXSEG];
+    int wg_prefix[MMDFN_TNS_MAXSEG + 1];
+    int n;
+};
+int mmdfn_launch_gemm_tn_split(const TnSplitSegs& sq, hipStream_t s);
