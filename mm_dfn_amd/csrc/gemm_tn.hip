@@ -782,7 +782,9 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     // form's, which the launch checks of that form never enforced on the base pointers)
     bool split_form = tns_enabled();
     for (int s = 0; s < nseg && split_form; ++s)
-        if ((((uintptr_t)A[s] | (uintptr_t)B[s]) & 15) != 0) split_form = false;
+        if ((((uintptr_t)A[s] | (uintptr_t)B[s]) & 15) != 0 || (int64_t)R[s] * lda[s] >= (1ll << 30) ||
+            (int64_t)R[s] * ldb[s] >= (1ll << 30) || R[s] >= (1 << 24))
+            split_form = false;               // (its loads address rows by 32-bit byte offsets from the operand bases)
     const int rt_split = tns_rows_target(nseg, R, out, nout, M, N);
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];

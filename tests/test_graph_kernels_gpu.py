@@ -546,6 +546,75 @@ def test_weight_gradient_batch_tall_segments():
     assert torch.isfinite(o8[:99, :99]).all() and not torch.isfinite(o8[99]).any() and not torch.isfinite(o8[:, 99]).any()
 
 
+def _wgrad_reference(A, B, sh):
+    Ad, Bd = A.double().cpu(), B.double().cpu()
+    R = Ad.shape[0]
+    if abs(sh) >= R:
+        return torch.zeros(Ad.shape[1], Bd.shape[1], dtype=torch.float64)
+    return (Ad[:R - sh].t() @ Bd[sh:]) if sh >= 0 else (Ad[-sh:].t() @ Bd[:R + sh])
+
+
+# (rows, M, N, row shift, lda, ldb): what the bf16-piece form's tiles, chunks, splits and groups meet at their edges
+WGRAD_SPLIT_CASES = [
+    (1000, 100, 100, 0, 100, 100),      # one tile, 7 of 8 row tiles
+    (333, 300, 200, 45, 600, 200),      # positive shift larger than a chunk: clamped rows in the last chunks of B
+    (333, 300, 200, -7, 600, 200),      # negative shift: the first rows of B do not exist
+    (320, 300, 200, 45, 600, 200),      # the same with every chunk full
+    (97, 8, 4, 0, 8, 4),                # a sliver of one tile, one ragged chunk per split
+    (31, 20, 228, 0, 24, 232),          # fewer rows than a chunk, three column blocks, strided operands
+    (64, 128, 112, 5, 128, 112),        # exactly one tile, two chunks: one per group
+    (4097, 132, 116, 1, 132, 116),      # one row and one column block more than a tile, one row more than the chunks
+    (96, 100, 100, 64, 100, 100),       # shift of two chunks in a three-chunk segment
+    (40, 400, 100, -40, 400, 100),      # shift = -rows: nothing pairs up (zeros), four row tiles
+    (7040, 300, 100, 64, 600, 200),     # a party-GRU recurrent weight of cfg2
+]
+
+
+@pytest.mark.parametrize("R,M,N,sh,lda,ldb", WGRAD_SPLIT_CASES)
+def test_weight_gradient_batch_bf16_piece_form(R, M, N, sh, lda, ldb, kernel_variants):
+    """csrc/gemm_tn_split.hip (the batch's default form: operands cut into bf16 pieces, transposed through LDS planes, two
+    wave groups in opposite phases) at the edges of its tiling, against fp64 and against the exact-f32 forms of gemm_tn.hip
+    (MMDFN_TN_SPLIT=0 in the tuning build): weights and column sums at fp32 level, and a different kernel really ran."""
+    rs = np.random.RandomState(1000 + R + M)
+    t = lambda *shape: torch.from_numpy(rs.randn(*shape).astype(np.float32)).to(DEV)
+    A, B = t(R, lda)[:, lda - M:], t(R, ldb)[:, :N]
+    want, wcol = _wgrad_reference(A, B, sh), A.double().cpu().sum(0)
+    got = {}
+    for form in ("1", "0"):
+        kernel_variants.setenv("MMDFN_TN_SPLIT", form)
+        C, c1 = torch.full((M, N), float("nan"), device=DEV), torch.full((M,), float("nan"), device=DEV)
+        ops._launch_wgrad_batch([(dict(M=M, N=N), C, [c1], 0, [(A, B, sh)])])
+        got[form] = (C, c1)
+        scale = float(want.abs().max()) + 1e-30
+        assert float((C.double().cpu() - want).abs().max()) <= 2e-6 * scale + 1e-30, form
+        assert rel_err(c1, wcol) < 1e-5, form
+    if R * M * N > 100000 and abs(sh) < R:
+        assert float((got["1"][0] - got["0"][0]).abs().max()) > 0.0          # (two different kernels)
+
+
+def test_weight_gradient_batch_exact_f32_forms_stay_covered(kernel_variants):
+    """The tiled and tall exact-f32 forms of gemm_tn.hip (what a batch with a misaligned operand falls back to) through
+    the tuning switch: the two batch tests above, unchanged."""
+    kernel_variants.setenv("MMDFN_TN_SPLIT", "0")
+    test_weight_gradient_batch_kernel()
+    test_weight_gradient_batch_tall_segments()
+
+
+def test_weight_gradient_batch_misaligned_operand_falls_back():
+    """mmdfn_gemm_tn_batch with an operand that starts 4 bytes off a 16-byte boundary (ops never passes one: it copies such
+    views; a C-ABI caller may): the bf16-piece form needs aligned float4 rows, the batch falls back to the tiled form."""
+    rs = np.random.RandomState(5)
+    t = lambda *shape: torch.from_numpy(rs.randn(*shape).astype(np.float32)).to(DEV)
+    base = t(700 * 104 + 1)
+    A = base[1:].view(700, 104)[:, :100]
+    B = t(700, 100)
+    assert A.data_ptr() % 16 == 4
+    C, c1 = torch.empty(100, 100, device=DEV), torch.empty(100, device=DEV)
+    ops._launch_wgrad_batch([(dict(M=100, N=100), C, [c1], 0, [(A, B, 0)])])
+    assert rel_err(C, A.double().cpu().t() @ B.double().cpu()) < 1e-5
+    assert rel_err(c1, A.double().cpu().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("R,K,n1,n2", [(300, 200, 300, 300), (7040, 200, 300, 300), (129, 36, 4, 100), (2000, 100, 260, 52),
                                        (16640, 200, 300, 300)])      # (>= 16384 rows: the input gradient on the hand-written kernel)
 def test_two_block_projection(R, K, n1, n2):
