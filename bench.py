@@ -89,13 +89,16 @@ def profile_json(name):
         return None
 
 
+TRAFFIC_JSON = "r04_propagate_traffic.json"      # (this round's PMC passes)
+
+
 def measured_traffic(key, kernel):
     """HBM bytes per launch from the committed PMC passes of THIS round (tools/collect_traffic.py: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --only-roofline`, FETCH x2 on gfx950; the file records the
     commit it was collected at).  The counters cannot share a pass with the timing run, so they are not re-collected
     here; a figure is attached only if the kernel it was measured on still exists, by name, in the library this process
     loaded."""
-    d = profile_json("r03_propagate_traffic.json")
+    d = profile_json(TRAFFIC_JSON)
     if not d or key not in d:
         return None, None
     ent = d[key]
@@ -106,14 +109,14 @@ def measured_traffic(key, kernel):
     except OSError:
         present = False
     if not present:
-        return None, "profiles/r03_propagate_traffic.json names kernel %r, which is not in the current library: not attached" % ent["kernel"]
-    return ent["traffic_bytes"], "profiles/r03_propagate_traffic.json (commit %s, kernel %s)" % (d.get("commit", "?"), ent["kernel"])
+        return None, "profiles/%s names kernel %r, which is not in the current library: not attached" % (TRAFFIC_JSON, ent["kernel"])
+    return ent["traffic_bytes"], "profiles/%s (commit %s, kernel %s)" % (TRAFFIC_JSON, d.get("commit", "?"), ent["kernel"])
 
 
 def measured_traffic_bwd():
     """HBM bytes of the cfg5 backward leg = the sum over its three kernels (dH: propagate_split, dA: tile_dot_split +
     cross_dot) of the same committed PMC passes; attached only if all three kernels are still in the loaded library."""
-    d = profile_json("r03_propagate_traffic.json")
+    d = profile_json(TRAFFIC_JSON)
     if not d or "legs" not in d or "cfg5_b32" not in d:
         return None, None
     names = ("tile_dot_split_kernel", "cross_dot_kernel")
@@ -126,9 +129,9 @@ def measured_traffic_bwd():
     except OSError:
         return None, None
     if not all(n.encode() in blob for n in names + ("propagate_split_kernel",)):
-        return None, "profiles/r03_propagate_traffic.json names kernels that are not in the current library: not attached"
+        return None, "profiles/%s names kernels that are not in the current library: not attached" % TRAFFIC_JSON
     total = d["cfg5_b32"]["traffic_bytes"] + sum(max(l["traffic_bytes"] for l in legs[n]) for n in names)
-    return total, "profiles/r03_propagate_traffic.json (commit %s): propagate_split + tile_dot_split + cross_dot" % d.get("commit", "?")
+    return total, "profiles/%s (commit %s): propagate_split + tile_dot_split + cross_dot" % (TRAFFIC_JSON, d.get("commit", "?"))
 
 
 def time_propagate(make_set, nsets, iters, warm_replays=10, timed_replays=3):
