@@ -238,6 +238,13 @@ int mmdfn_linear_group(int n, const float* const* X, const float* const* W, cons
                        const float* const* bias, const float* const* bias2, float* const* Y, const int* R,
                        const int* K, const int* N, const int* ldx, const int* ldw, const int* ldy,
                        const int* kmajor, const int* accumulate, int act, void* stream);
+/* The same with an out-of-place addend: problem p computes Y_p = act(X_p W_p (+ b)) + Z_p for Z[p] != NULL (Z_p: R_p rows of
+ * N_p floats, row stride ldz[p]; read only -- an autograd node adds onto an incoming gradient without writing into a tensor
+ * it does not own), and behaves like mmdfn_linear_group for Z[p] == NULL (Z == NULL: for every problem). */
+int mmdfn_linear_group_addend(int n, const float* const* X, const float* const* W, const float* const* W2, const int* N1,
+                              const float* const* bias, const float* const* bias2, float* const* Y, const float* const* Z,
+                              const int* ldz, const int* R, const int* K, const int* N, const int* ldx, const int* ldw,
+                              const int* ldy, const int* kmajor, const int* accumulate, int act, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Secondary fusion modules (fusion.hip); their dense projections go through mmdfn_linear_group.

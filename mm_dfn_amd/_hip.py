@@ -38,6 +38,7 @@ SIGNATURES = {
     "mmdfn_linear2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear_group_supported": [_I, _I, _I],
     "mmdfn_linear_group": [_I] + [_P] * 15 + [_I, _P],
+    "mmdfn_linear_group_addend": [_I] + [_P] * 17 + [_I, _P],
     "mmdfn_softmax_scale_fwd": [_P, _P, _P, _P, _I, _I, _P],
     "mmdfn_softmax_scale_bwd": [_P, _P, _P, _P, _P, _I, _I, _P],
     "mmdfn_mfn_mem_fwd": [_P] * 6 + [_L, _P],

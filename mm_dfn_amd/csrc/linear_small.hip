@@ -37,6 +37,8 @@ struct SmallGroup {
     const float* b[SG_MAX];
     const float* b2[SG_MAX];
     float* Y[SG_MAX];
+    const float* Z[SG_MAX];      // accumulate: the addend (Y itself, or another buffer: out-of-place y = x W + z), row stride ldz
+    int ldz[SG_MAX];
     int R[SG_MAX], K[SG_MAX], N[SG_MAX], N1[SG_MAX], ldx[SG_MAX], ldw[SG_MAX], ldy[SG_MAX], kmajor[SG_MAX], accumulate[SG_MAX];
     int tile0[SG_MAX + 1];
     int ntn[SG_MAX];
@@ -182,13 +184,14 @@ __global__ __launch_bounds__(256) void linear_small_kernel(SmallGroup G) {
     for (int e = 0; e < 4; ++e)
         if (bias && col + e < N) o[e] += (col + e < N1) ? bias[col + e] : bias2[col + e - N1];
     if (G.accumulate[p]) {
-        if (vec) {
-            const float4 old = *reinterpret_cast<const float4*>(y);
+        const float* z = G.Z[p] + (int64_t)row * G.ldz[p] + col;
+        if (vec && ((G.ldz[p] & 3) == 0) && ((reinterpret_cast<uintptr_t>(G.Z[p]) & 15) == 0)) {
+            const float4 old = *reinterpret_cast<const float4*>(z);
             o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (col + e < N) o[e] += y[e];
+                if (col + e < N) o[e] += z[e];
         }
     }
     if (G.act == 1) {
@@ -461,13 +464,14 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(SmallGroup G) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += bv4[e];
         if (G.accumulate[p]) {
-            if (vec) {
-                const float4 old = *reinterpret_cast<const float4*>(y);
+            const float* z = G.Z[p] + (int64_t)row * G.ldz[p] + col;
+            if (vec && ((G.ldz[p] & 3) == 0) && ((reinterpret_cast<uintptr_t>(G.Z[p]) & 15) == 0)) {
+                const float4 old = *reinterpret_cast<const float4*>(z);
                 o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (col + e < N) o[e] += y[e];
+                    if (col + e < N) o[e] += z[e];
             }
         }
         if (G.act == 1) {
@@ -505,6 +509,15 @@ extern "C" int mmdfn_linear_group(int n, const float* const* X, const float* con
                                   const float* const* bias, const float* const* bias2, float* const* Y, const int* R,
                                   const int* K, const int* N, const int* ldx, const int* ldw, const int* ldy,
                                   const int* kmajor, const int* accumulate, int act, void* stream) {
+    return mmdfn_linear_group_addend(n, X, W, W2, N1, bias, bias2, Y, nullptr, nullptr, R, K, N, ldx, ldw, ldy, kmajor, accumulate,
+                                     act, stream);
+}
+
+extern "C" int mmdfn_linear_group_addend(int n, const float* const* X, const float* const* W, const float* const* W2,
+                                         const int* N1, const float* const* bias, const float* const* bias2, float* const* Y,
+                                         const float* const* Z, const int* ldz, const int* R, const int* K, const int* N,
+                                         const int* ldx, const int* ldw, const int* ldy, const int* kmajor, const int* accumulate,
+                                         int act, void* stream) {
     if (n <= 0 || n > SG_MAX) return -1;
     SmallGroup G;
     G.n = n;
@@ -542,7 +555,13 @@ extern "C" int mmdfn_linear_group(int n, const float* const* X, const float* con
         }
         G.X[p] = X[p]; G.W[p] = W[p]; G.W2[p] = W2[p]; G.b[p] = bias[p]; G.b2[p] = bias2[p]; G.Y[p] = Y[p];
         G.R[p] = R[p]; G.K[p] = K[p]; G.N[p] = N[p]; G.N1[p] = N1[p]; G.ldx[p] = ldx[p]; G.ldw[p] = ldw[p]; G.ldy[p] = ldy[p];
-        G.kmajor[p] = kmajor[p]; G.accumulate[p] = accumulate[p];
+        G.kmajor[p] = kmajor[p];
+        // problem p adds Z[p] (row stride ldz[p]) when one is given, its own output when `accumulate` asks for that
+        const bool ext = Z != nullptr && Z[p] != nullptr;
+        if (ext && ldz[p] < N[p]) return -1;
+        G.accumulate[p] = (ext || accumulate[p]) ? 1 : 0;
+        G.Z[p] = ext ? Z[p] : Y[p];
+        G.ldz[p] = ext ? ldz[p] : ldy[p];
         G.ntn[p] = (N[p] + tn - 1) / tn;
         G.tile0[p] = t0;
         t0 += ((R[p] + tm - 1) / tm) * G.ntn[p];

@@ -19,6 +19,11 @@ from torch.utils.data import DataLoader, Dataset, Sampler
 from torch.utils.data.sampler import SubsetRandomSampler
 
 
+def _odd_feature(t):
+    from . import ops
+    return ops.is_odd_feature_tensor(t)
+
+
 def _collate(data):
     """dataloader.py:31-34 without the pandas round trip: columns 0-3 time-major, 4-5 batch-major, 6 a list."""
     cols = list(zip(*data))
@@ -250,7 +255,7 @@ class DevicePrefetcher:
         with torch.cuda.stream(stream):
             dev = []
             for slot, t in enumerate(tensors):
-                if t.dim() == 3 and t.dtype == torch.float32 and t.shape[-1] % 4:
+                if _odd_feature(t):
                     # feature width not a multiple of 4 (1582-d audio, 342-d visual features): the pinned staging buffer
                     # is row-padded to the next multiple of 4 (pad columns zero), so the device copy is the operand the
                     # MFMA kernels fetch in 16-byte units (ops.py "row padding") -- no pad launch on the device

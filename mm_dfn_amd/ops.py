@@ -46,6 +46,13 @@ def pad4(n):
     return (int(n) + 3) & ~3
 
 
+def is_odd_feature_tensor(t):
+    """An (L, B, D) fp32 FEATURE tensor whose width is not a multiple of 4 (1582-d audio, 342-d visual): what the data
+    pipeline stages row-padded.  The speaker mask (L, B, P) has the same rank and dtype; its P <= 9 columns are not a
+    contraction width and it stays as it is (padding it made every step copy it back into a contiguous tensor)."""
+    return t.dim() == 3 and t.dtype == torch.float32 and t.shape[-1] % 4 != 0 and t.shape[-1] > 16
+
+
 def register_row_padded(base, region=None):
     """``base``: a contiguous (..., Kp) fp32 tensor whose columns past the logical width are zero and stay zero (nobody
     writes them).  Views of its leading columns are recognised as row-padded operands WHILE THE ``base`` OBJECT IS ALIVE
@@ -535,33 +542,27 @@ class _ProjectGather(torch.autograd.Function):
         dXs = [None] * Mn
         need = [m for m in range(Mn) if ctx.needs_input_grad[7 + m]]
         if need:
-            outs, seen = [], set()
+            # dX_m = dG_m [W1; W2] + (the gradient that reached X_m's passthrough alias), out of place: the incoming gradient is
+            # only READ (the kernel's addend), never written -- autograd may hand the same tensor to several nodes (ADVICE r03;
+            # an in-place accumulation needed a private copy of every view / duplicate: two 5 us copies per cfg2 step)
+            adds = []
             for m in need:
                 d = dpass[m] if m < len(dpass) else None
-                # the accumulation below writes INTO the incoming gradient of the passthrough alias: only a buffer that is
-                # private to this node may be used that way.  The same tensor reaching two aliases (X_a' + X_v' downstream:
-                # add's backward hands one tensor to both) would be written by two problems of the one grouped launch, so
-                # every duplicate -- and anything that is not a plain aligned buffer -- is copied first.
-                if d is not None and (not (d.is_contiguous() and d.data_ptr() % 16 == 0) or d.data_ptr() in seen
-                                      or d._base is not None):
-                    d = d.clone(memory_format=torch.contiguous_format)
-                if d is not None:
-                    seen.add(d.data_ptr())
-                outs.append(d)
+                adds.append(None if d is None else d.reshape(L * B, H))
             if wcat is not None:
                 probs = []
-                for m, d in zip(need, outs):
+                for m, d in zip(need, adds):
                     q = dict(x=dG[m], wk=wcat)
                     if d is not None:
-                        q.update(out=d.view(L * B, H), accumulate=True)      # in place on the alias' gradient buffer
+                        q.update(addend=d)
                     probs.append(q)
                 res = linear_group_raw(probs)
             else:
                 res = []
-                for m, d in zip(need, outs):
+                for m, d in zip(need, adds):
                     q = dict(x=dG[m][:, :n1], wk=w1)
                     if d is not None:
-                        q.update(out=d.view(L * B, H), accumulate=True)
+                        q.update(addend=d)
                     o = linear_group_raw([q])[0]
                     linear_group_raw([dict(x=dG[m][:, n1:], wk=w2, out=o, accumulate=True)])
                     res.append(o)
@@ -659,10 +660,11 @@ def linear_raw(x2d, weight, bias=None, act=0, out=None, accumulate=False):
 def linear_group_raw(problems, act=0):
     """One launch for up to 8 few-row projections (csrc/linear_small.hip).  Each problem is a dict: x (R, K) fp32 rows,
     either ``w`` (N, K) [+ ``w2`` (N2, K): second row block] with optional ``b`` / ``b2``, or ``wk`` (K, N) (n-contiguous:
-    y = x @ wk); optional ``out`` (+ ``accumulate``).  Returns the outputs."""
+    y = x @ wk); optional ``out`` (+ ``accumulate``: y += ...), optional ``addend`` (R, N): y = ... + addend, out of place
+    (the addend is only read).  Returns the outputs."""
     n = len(problems)
-    X, W, W2, B1, B2, Y = [], [], [], [], [], []
-    R, K, N, N1, ldx, ldw, ldy, km, acc = [], [], [], [], [], [], [], [], []
+    X, W, W2, B1, B2, Y, Z = [], [], [], [], [], [], []
+    R, K, N, N1, ldx, ldw, ldy, ldz, km, acc = [], [], [], [], [], [], [], [], [], []
     for q in problems:
         x = q["x"]
         if x.dtype != torch.float32 or x.dim() != 2:
@@ -691,9 +693,23 @@ def linear_group_raw(problems, act=0):
             out = torch.empty(x.shape[0], n_, dtype=torch.float32, device=x.device)
         X.append(x); Y.append(out); R.append(x.shape[0]); K.append(k_); N.append(n_); ldx.append(x.stride(0)); ldy.append(out.stride(0))
         acc.append(1 if q.get("accumulate") else 0)
+        z = q.get("addend")
+        if z is not None:
+            if z.dtype != torch.float32 or tuple(z.shape) != (x.shape[0], n_):
+                raise ValueError("linear_group_raw: addend must be an fp32 (R, N) matrix")
+            if z.stride(1) != 1:
+                z = z.contiguous()
+            _hip.require_cuda(z)
+        Z.append(z); ldz.append(z.stride(0) if z is not None else 0)
     _hip.require_cuda(*X, *W)
     _hip.require_f32(*X, *W)
     ia, pa = _hip.int_array, _hip.ptr_array
+    if any(z is not None for z in Z):
+        rc = _hip.lib().mmdfn_linear_group_addend(n, pa(X), pa(W), pa(W2), ia(N1), pa(B1), pa(B2), pa(Y), pa(Z), ia(ldz), ia(R),
+                                                  ia(K), ia(N), ia(ldx), ia(ldw), ia(ldy), ia(km), ia(acc), int(act),
+                                                  _hip.stream())
+        _hip.check(rc, "mmdfn_linear_group_addend")
+        return Y
     rc = _hip.lib().mmdfn_linear_group(n, pa(X), pa(W), pa(W2), ia(N1), pa(B1), pa(B2), pa(Y), ia(R), ia(K), ia(N), ia(ldx),
                                        ia(ldw), ia(ldy), ia(km), ia(acc), int(act), _hip.stream())
     _hip.check(rc, "mmdfn_linear_group")

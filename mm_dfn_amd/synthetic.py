@@ -59,10 +59,10 @@ def make_batch(seed, B, L, P, C, D_t, D_a, D_v, ragged=False, lengths=None, devi
         lab[b, n:] = 0
     def t(a):
         x = torch.from_numpy(a).to(device)
-        if x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and x.shape[-1] % 4:
+        from . import ops
+        if x.is_cuda and ops.is_odd_feature_tensor(x):
             # a feature width that is not a multiple of 4 (1582-d audio, 342-d visual): staged row-padded, as the data
             # pipeline does (ops.py "row padding"; same values, the modules see the (L, B, D) view)
-            from . import ops
             return ops.pad_rows(x)
         return x
 
@@ -114,10 +114,10 @@ def make_stream_batch(seed, B, L, P, C, D_streams, ragged=False, lengths=None, d
         lab[b, n:] = 0
     def t(a):
         x = torch.from_numpy(a).to(device)
-        if x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and x.shape[-1] % 4:
+        from . import ops
+        if x.is_cuda and ops.is_odd_feature_tensor(x):
             # a feature width that is not a multiple of 4 (1582-d audio, 342-d visual): staged row-padded, as the data
             # pipeline does (ops.py "row padding"; same values, the modules see the (L, B, D) view)
-            from . import ops
             return ops.pad_rows(x)
         return x
 

@@ -99,7 +99,7 @@ class StepGraphCache:
         if ent is None:
             self.misses += 1
             # (feature widths that are not multiples of 4 get row-padded static buffers: ops.py "row padding")
-            static = [ops.pad_rows(t) if (t.dim() == 3 and t.dtype == torch.float32 and t.shape[-1] % 4) else t.clone()
+            static = [ops.pad_rows(t) if ops.is_odd_feature_tensor(t) else t.clone()
                       for t in inputs]
             textf, visuf, acouf, qmask, umask, label = static
             # dialogue-major label flatten (run_train_erc.py:201) as a static gather: a boolean-mask select has a
