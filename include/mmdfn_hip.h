@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 10). */
+/* Library / device sanity: returns the ABI version (currently 11: 10 + mmdfn_linear_group_addend). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------

@@ -68,7 +68,7 @@ SIGNATURES = {
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class HipLibraryError(RuntimeError):
