@@ -959,3 +959,20 @@ def test_few_row_projection_group(shapes):
     assert rel_err(y2, x.double() @ wk.double()) < 2e-6
     # bit-reproducible (fixed summation order)
     assert torch.equal(y2, ops.linear_group_raw([dict(x=x, wk=wk)])[0])
+    # out-of-place addend (mmdfn_linear_group_addend): y = x @ wk + z with z only read -- an aligned contiguous addend, a strided
+    # view of a wider buffer, and one whose rows start 4 bytes off a 16-byte boundary (scalar epilogue reads), next to a problem
+    # without an addend in the same launch
+    z1 = t(R, N)
+    zwide = t(R, N + 8)
+    z2 = zwide[:, 4:4 + N]
+    z3 = t(R * N + 1)[1:].view(R, N)
+    keep = [z1.clone(), zwide.clone(), z3.clone()]
+    outs = ops.linear_group_raw([dict(x=x, wk=wk, addend=z1), dict(x=x, wk=wk, addend=z2), dict(x=x, wk=wk),
+                                 dict(x=x, wk=wk, addend=z3)])
+    prod = x.double() @ wk.double()
+    assert rel_err(outs[0], prod + z1.double()) < 2e-6
+    assert rel_err(outs[1], prod + z2.double()) < 2e-6
+    assert torch.equal(outs[2], y2)
+    assert rel_err(outs[3], prod + z3.double()) < 2e-6
+    assert torch.equal(z1, keep[0]) and torch.equal(zwide, keep[1]) and torch.equal(z3, keep[2])      # (never written)
+    assert all(o.data_ptr() not in (z1.data_ptr(), z2.data_ptr(), z3.data_ptr()) for o in outs)

@@ -255,3 +255,16 @@ def test_backward_with_cached_unit_seed_matches_plain_backward():
     w.grad = None
     train.backward((w * w).sum())            # second call: the cached seed
     assert torch.equal(w.grad, g0)
+
+
+def test_only_feature_tensors_are_row_padded():
+    """Row padding (ops.py) is for contraction operands: an (L, B, D) feature tensor with D % 4 != 0.  The speaker mask
+    (L, B, P) has the same rank and dtype and stays as it is -- padding it made every step copy it back."""
+    from mm_dfn_amd import ops
+    assert ops.is_odd_feature_tensor(torch.zeros(5, 3, 342))
+    assert ops.is_odd_feature_tensor(torch.zeros(5, 3, 1582))
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 100))
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 2))           # qmask, two speakers
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 9))           # qmask, MELD
+    assert not ops.is_odd_feature_tensor(torch.zeros(3, 5))              # umask
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 342, dtype=torch.int64))
