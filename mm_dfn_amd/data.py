@@ -285,6 +285,8 @@ class DevicePrefetcher:
         stream = torch.cuda.Stream(device=self.device)
         queue = []
         it = iter(self.loader)
+        if self.graph_cache is not None:
+            self.graph_cache.forget_queued()       # (announcements of a pass that was abandoned mid-way)
         try:
             while len(queue) < self.depth:
                 queue.append(self._stage(next(it), stream))
@@ -293,9 +295,16 @@ class DevicePrefetcher:
         while queue:
             dev, rest, ev, lengths, ring_slot = queue.pop(0)
             torch.cuda.current_stream(self.device).wait_event(ev)
-            if not self.recycle:
-                for t in dev:
-                    t.record_stream(torch.cuda.current_stream(self.device))
+            cur = torch.cuda.current_stream(self.device)
+            for t in dev:
+                base = getattr(t, "_mmdfn_padbase", None)
+                if ring_slot is not None and base is not None:
+                    # row-padded features are fresh allocations made on the COPY stream (not ring buffers): the consumer's
+                    # stream must be recorded, or the allocator may hand the block to a later copy while kernels queued on
+                    # the consumer's stream still read it
+                    base.record_stream(cur)
+                elif not self.recycle:
+                    t.record_stream(cur)
             try:
                 queue.append(self._stage(next(it), stream))
             except StopIteration:

@@ -72,6 +72,7 @@ class StepGraphCache:
         self.model, self.loss_f = model, loss_f
         self.max_entries, self.warmup = max_entries, warmup
         self.entries = OrderedDict()
+        self.queued = {}           # signature -> batches a staging loader has announced (claim_static) and not stepped yet
         self.hits = self.misses = self.recaptures = 0
 
     @staticmethod
@@ -84,11 +85,25 @@ class StepGraphCache:
         already promised to a staged batch that has not been stepped).  The caller copies the batch INTO them (after
         waiting for ``entry["done"]``, the event behind the entry's last replay) and hands exactly these tensors to
         ``step``, which then has nothing to copy."""
-        ent = self.entries.get(self.signature(shapes, lengths, train_flag, test_label))
-        if ent is None or ent.get("reserved"):
+        key = self.signature(shapes, lengths, train_flag, test_label)
+        # every announced batch counts, claimed or not: the static buffers are handed out only when NO earlier batch of this
+        # signature is still waiting to be stepped -- such a batch (staged elsewhere) is copied into the same buffers by its
+        # step, on the compute stream, unordered with a later batch's direct copy on the loader's stream (with repeated
+        # signatures inside the prefetch window the later batch's data would be overwritten, or replayed under the wrong
+        # batch's name)
+        ahead = self.queued.get(key, 0)
+        self.queued[key] = ahead + 1
+        ent = self.entries.get(key)
+        if ent is None or ahead or ent.get("reserved"):
             return None
         ent["reserved"] = True
         return ent
+
+    def forget_queued(self):
+        """Drop the announcements of batches that will never be stepped (a pass abandoned mid-way)."""
+        self.queued.clear()
+        for ent in self.entries.values():
+            ent["reserved"] = False
 
     def step(self, inputs, lengths, train_flag, test_label=False):
         """inputs = (textf, visuf, acouf, qmask, umask, label) on the device.  Returns (loss, log_prob, flat_labels):
@@ -96,6 +111,15 @@ class StepGraphCache:
         from .graphs import CapturedStep
         key = self.signature([t.shape for t in inputs], lengths, train_flag, test_label)
         ent = self.entries.get(key)
+        if self.queued.get(key, 0) > 0:
+            self.queued[key] -= 1
+            if not self.queued[key]:
+                del self.queued[key]
+        if ent is not None and ent.get("reserved") and any(d is not s_ for d, s_ in zip(ent["static"], inputs)):
+            # the static buffers are promised to (and being filled for) another staged batch: copying this one over them
+            # would race with that copy
+            raise RuntimeError("StepGraphCache.step: this signature's static inputs are reserved for a later staged batch; "
+                               "step batches in the order they were announced with claim_static")
         if ent is None:
             self.misses += 1
             # (feature widths that are not multiples of 4 get row-padded static buffers: ops.py "row padding")

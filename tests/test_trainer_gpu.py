@@ -142,6 +142,29 @@ def test_prefetcher_stages_straight_into_captured_static_buffers(tmp_path):
         assert abs(got[2] - want[2]) < 1e-3
 
 
+def test_prefetcher_with_consecutive_identical_signatures(tmp_path):
+    """several batches of ONE signature inside the prefetch window (uniform-length data, batch_size 1,
+    repeated length tuples).  The static buffers of a captured step are handed to the loader only while no earlier batch of
+    that signature is still waiting to be stepped; every batch must be replayed with ITS OWN data (different features and
+    labels per batch, so a batch replayed under another one's name changes predictions and loss)."""
+    p = D.write_synthetic_pickle(str(tmp_path / "u.pkl"), n_train=2, n_test=12, max_len=9, min_len=9, seed=5)
+    names = ['hap', 'sad', 'neu', 'ang', 'exc', 'fru']
+    _, _, te = D.get_IEMOCAP_loaders(p, batch_size=2, valid_rate=0.0)
+    batches = [list(b) for b in te]                  # six batches, every dialogue 9 utterances long: one signature
+    assert len(batches) == 6
+    m = _model(23)
+    loss_f = FocalLoss(gamma=0.5)
+    want = T.train_or_eval_graph_model(m, loss_f, batches, cuda_flag=True, target_names=names)
+    for depth in (2, 3):
+        cache = T.StepGraphCache(m, loss_f)
+        for _ in range(3):                           # pass 1 captures, passes 2-3 replay with claims in flight
+            got = T.train_or_eval_graph_model(m, loss_f, D.DevicePrefetcher(batches, depth=depth), target_names=names,
+                                              graph_cache=cache)
+            assert np.array_equal(got[5], want[5]) and np.array_equal(got[4], want[4])
+            assert np.allclose(got[7][1], want[7][1], atol=1e-4)          # per-batch losses, in order
+        assert cache.misses == 1 and not cache.queued
+
+
 def test_dropout_stream_is_not_rewound_by_captured_steps():
     """building a captured step must consume no random numbers and replays must move torch's generator along,
     so that two signatures captured and stepped back to back (every step of a first epoch is a cache miss) draw their keep
