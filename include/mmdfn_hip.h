@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 11: 10 + mmdfn_linear_group_addend). */
+/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -124,6 +124,34 @@ int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const float* const* y
                       const float* const* gates, const float* const* w_hh,
                       float* const* dgi, float* const* dgh,
                       const int* rows, const int* T, int H, void* stream);
+
+/* Valid-length ("segmented") form of the same recurrence for the speaker-party batch (model.py:1076-1087: per dialogue b and
+ * speaker p the reference fills rows [:k_bp] of a zero (L, H) buffer, runs the party GRU over all L steps and scatters rows
+ * [:k_bp] back).  Exact work removal, see csrc/gru.hip "Valid-length truncation".  Per group g (host arrays, one entry per group):
+ *   rank[g]  : the gather's (T, BP) int32 rank array (>= 0 where speaker p talks) or NULL (every row runs all T steps);
+ *              rows[g] must be a multiple of BP[g] (one (B, P) block per gathered modality), P[g] <= 16, P[g] * T[g] <= 2048
+ *   tdir[g]  : -1, or the direction that stops at / starts from the valid length: its P sequences per (modality, dialogue)
+ *              run back to back in one workgroup.  Rows with k = 0 are skipped in BOTH directions.
+ *   ytab[g]  : NULL, or (tdir[g] must be 1) the (T, 1, 2H) outputs of the all-padding sequence (gi = b_ih at every step, run
+ *              through mmdfn_gru_seq_fwd as a one-row group): a truncated reverse row starts at t = k - 1 from ytab[k] and
+ *              its outputs at t >= k are copies of ytab[t]; with NULL a truncated row starts from 0 and y[t >= k] = 0.
+ * Positions never visited hold ytab copies / zeros in y and are NOT written in gates.
+ * Backward: dgi / dgh are zero at the positions never visited; with dhinit[g] (rows, H) and kout[g] (rows) int32 given
+ * (tdir[g] == 1) the gradient wrt every truncated row's start state and its step count are written, and
+ * mmdfn_gru_tab_reduce sums what reaches the all-padding sequence:
+ *   dyt[t][dir half] = sum_{rows: k <= t} dy[t][row] + sum_{rows: k == t >= 1} dhinit[row]   (the other half zero),
+ * the dy of that one-row group's own mmdfn_gru_seq_bwd. */
+int mmdfn_gru_seq_fwd_seg(int ngroups, const float* const* gi, const float* const* w_hh,
+                          const float* const* b_hh, float* const* y, float* const* gates,
+                          const int* rows, const int* T, int H, const int32_t* const* rank, const int* P,
+                          const int* BP, const int* tdir, const float* const* ytab, void* stream);
+int mmdfn_gru_seq_bwd_seg(int ngroups, const float* const* dy, const float* const* y,
+                          const float* const* gates, const float* const* w_hh,
+                          float* const* dgi, float* const* dgh, const int* rows, const int* T, int H,
+                          const int32_t* const* rank, const int* P, const int* BP, const int* tdir,
+                          float* const* dhinit, int32_t* const* kout, void* stream);
+int mmdfn_gru_tab_reduce(const float* dy, const int32_t* kout, const float* dhinit, float* dyt, int rows, int T,
+                         int H, int dir, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K8  LSTM-cell gate math of the "reasoning" / dynamic-fusion module (replaces the pointwise part

@@ -24,6 +24,9 @@ SIGNATURES = {
     "mmdfn_adj_build_bwd": [_P] * 16 + [_P, _P, _P] + [_I] * 5 + [_F, _P],
     "mmdfn_gru_seq_fwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "mmdfn_gru_seq_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "mmdfn_gru_seq_fwd_seg": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "mmdfn_gru_seq_bwd_seg": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_gru_tab_reduce": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_lstm_pointwise_fwd": [_P, _P, _P, _P, _L, _I, _P],
     "mmdfn_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
     "mmdfn_gcnii_combine_fwd": [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P],
@@ -68,7 +71,7 @@ SIGNATURES = {
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class HipLibraryError(RuntimeError):

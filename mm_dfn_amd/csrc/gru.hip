@@ -26,6 +26,89 @@ constexpr int GH = 100;          // hidden size (the reference hard-codes D_e = 
 constexpr int NT = 256;
 constexpr int MAXG = 4;
 
+// Valid-length truncation of the speaker-party sequences (exact; model.py:1076-1087 fills rows [:k_bp] of a zero (L, H)
+// buffer per (dialogue b, speaker p), runs the party GRU over all L steps and scatters rows [:k_bp] back).  Rows [k_bp, L)
+// of every party sequence carry the same input (zeros -> gi = b_ih), so
+//   * a direction whose OUTPUTS at the padding positions nobody reads and whose padding lies BEHIND the data in its
+//     processing order (layer 2, forward direction) stops after k_bp steps;
+//   * a direction that meets the padding FIRST (layer 1, reverse direction: t = L-1 .. 0) starts at t = k_bp - 1 from the
+//     state the all-padding ("silent") sequence has reached at position k_bp -- one extra sequence per launch, y_tab --
+//     and its outputs at the padding positions are copies of that sequence's outputs;
+//   * a speaker who never talks in a dialogue (k_bp = 0) needs nothing at all.
+// The P party sequences of one (modality, dialogue) then make Sum_p k_bp = L_b <= L steps in total, so a truncated
+// direction runs them back to back in ONE workgroup ("merged chain": P segments, state re-initialised at each
+// segment start) instead of in P workgroups of L steps each.  k_bp is read from the gather's rank array (max + 1).
+constexpr int SCHED_MAX = 2048;    // flattened steps of one chain (host checks P * T <= SCHED_MAX)
+constexpr int MAXSEG = 16;         // segments (speakers) per merged chain
+
+struct SegInfo {
+    const int32_t* rank[MAXG];     // (T, BP) int32: rank[t][b*P + p] >= 0 iff speaker p talks at t (its position among p's
+                                   // utterances), or nullptr: every row of the group runs all T steps in both directions
+    int P[MAXG];                   // speakers; row r of the group is party (r % BP), rows r..r+P-1 (r % P == 0) share a dialogue
+    int BP[MAXG];
+    int tdir[MAXG];                // direction that runs as merged, truncated chains (-1: none)
+    int nslot;                     // launch order of the (group, direction) slots: full-length slots first
+    int slot_g[2 * MAXG];
+    int slot_d[2 * MAXG];
+    int slot_start[2 * MAXG + 1];
+};
+
+struct Chain {
+    int gidx, dir, row0, nseg, S;
+    bool trunc, has_rank;
+};
+
+// decode blockIdx.x -> chain, count the steps of its segments and lay out the flattened schedule in LDS:
+//   sched[s] = t | segment << 12 | (first step of its segment) << 16,   s = 0 .. S-1 in FORWARD processing order
+// seg_k[p] = steps of segment p (a full-length chain: T, or 0 for a silent party row).  Ends with a barrier.
+template <int NTH>
+__device__ __forceinline__ Chain seg_setup(const SegInfo& Sg, const int* Tg, uint32_t* sched, int* seg_k) {
+    Chain c;
+    const int tid = threadIdx.x;
+    int sl = 0;
+    while (sl + 1 < Sg.nslot && (int)blockIdx.x >= Sg.slot_start[sl + 1]) ++sl;
+    c.gidx = Sg.slot_g[sl];
+    c.dir = Sg.slot_d[sl];
+    const int ci = (int)blockIdx.x - Sg.slot_start[sl];
+    const int32_t* __restrict__ rk = Sg.rank[c.gidx];
+    const int P = Sg.P[c.gidx], BP = Sg.BP[c.gidx], T = Tg[c.gidx];
+    c.has_rank = rk != nullptr;
+    c.trunc = c.has_rank && Sg.tdir[c.gidx] == c.dir;
+    c.row0 = c.trunc ? ci * P : ci;
+    c.nseg = c.trunc ? P : 1;
+    if (tid < MAXSEG) seg_k[tid] = 0;
+    __syncthreads();
+    if (c.has_rank) {
+        for (int idx = tid; idx < c.nseg * T; idx += NTH) {
+            const int p = idx / T;
+            const int t = idx - p * T;
+            const int v = rk[(int64_t)t * BP + (c.row0 + p) % BP];
+            if (v >= 0) atomicMax(&seg_k[p], v + 1);
+        }
+        __syncthreads();
+        if (!c.trunc && tid == 0) seg_k[0] = seg_k[0] > 0 ? T : 0;
+    } else if (tid == 0) {
+        seg_k[0] = T;
+    }
+    __syncthreads();
+    int S = 0;
+    for (int p = 0; p < c.nseg; ++p) S += seg_k[p];
+    c.S = S;
+    for (int idx = tid; idx < c.nseg * T; idx += NTH) {
+        const int p = idx / T;
+        const int j = idx - p * T;
+        const int k = seg_k[p];
+        if (j < k) {
+            int off = 0;
+            for (int q = 0; q < p; ++q) off += seg_k[q];
+            const int t = c.dir ? k - 1 - j : j;
+            sched[off + j] = (uint32_t)t | ((uint32_t)p << 12) | ((j == 0 ? 1u : 0u) << 16);
+        }
+    }
+    __syncthreads();
+    return c;
+}
+
 struct FwdGroups {
     int n;
     const float* gi[MAXG];
@@ -37,6 +120,8 @@ struct FwdGroups {
     int T[MAXG];
     int slice0[MAXG + 1];
     int abl;                       // tuning build only (MMDFN_GRU_ABL): timing ablations of the forward step, wrong results
+    SegInfo seg;                   // segmented (valid-length) launches only
+    const float* ytab[MAXG];       // (T, 1, 2H) outputs of the all-padding sequence, or nullptr (zero start / zero fill)
 };
 
 struct BwdGroups {
@@ -50,6 +135,9 @@ struct BwdGroups {
     int rows[MAXG];
     int T[MAXG];
     int slice0[MAXG + 1];
+    SegInfo seg;                   // segmented (valid-length) launches only
+    float* dhinit[MAXG];           // (rows, H): gradient wrt the start state of every truncated row (nullptr: not wanted)
+    int32_t* kout[MAXG];           // (rows): steps run per truncated row (with dhinit)
 };
 
 // Gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): the
@@ -361,20 +449,39 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
 // =====================================================================================================
 // ABL (tuning build, timing only): 1 no matvec, 2 no transcendental gate math, 4 no result writes, 8 no h exchange wait
 // (the LDS write of h stays, the barrier goes), 16 no gate-operand reads
-template <int SCALAR_FMA, int ABL>
+// SEG = 1: segmented launch (see SegInfo): 1-D grid of chains, the time loop runs over the chain's flattened schedule
+// (S steps, each naming its row and t), the state is re-initialised at segment starts (one extra barrier there), and the
+// positions a truncated / silent row does not visit are filled afterwards (copies of the all-padding sequence, or zeros).
+template <int SCALAR_FMA, int ABL, int SEG>
 __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     constexpr int TB = 4;                          // steps per block
     constexpr int NLD = (TB * 3 * GH / 4 + 63) / 64;   // float4 loads per I/O lane and block (5)
     __shared__ __attribute__((aligned(16))) float hs[2][GH + 4];
     __shared__ __attribute__((aligned(16))) float in_s[2][TB][3 * GH];
     __shared__ __attribute__((aligned(16))) float out_s[2][TB][GH][8];     // y r z n | W_hn h + b_hn, 3 pad
+    __shared__ uint32_t sched[SEG ? SCHED_MAX : 1];
+    __shared__ int seg_k[MAXSEG];
+    __shared__ __attribute__((aligned(16))) float seg_init[SEG ? MAXSEG : 1][GH];
 
     int gidx = 0;
-    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-    const int dir = blockIdx.y;
+    int dir_ = 0, row_ = 0, T_ = 0;
+    Chain ch{};
+    if constexpr (SEG) {
+        ch = seg_setup<320>(G.seg, G.T, sched, seg_k);
+        gidx = ch.gidx;
+        dir_ = ch.dir;
+        row_ = ch.row0;
+        T_ = ch.S;                                 // the time loop runs over the flattened schedule
+    } else {
+        while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
+        dir_ = blockIdx.y;
+        row_ = (int)blockIdx.x - G.slice0[gidx];
+        T_ = G.T[gidx];
+    }
+    const int dir = dir_;
     const int rows = G.rows[gidx];
-    const int T = G.T[gidx];
-    const int row = (int)blockIdx.x - G.slice0[gidx];
+    const int T = T_;
+    const int row = row_;
     const float* __restrict__ gi = G.gi[gidx];
     const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
     const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
@@ -382,6 +489,30 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     float* __restrict__ gates = G.gates[gidx];
     const int tid = threadIdx.x;
     const int nblocks = (T + TB - 1) / TB;
+    if constexpr (SEG) {
+        // start state of every segment: the all-padding sequence's state at position k (reverse direction: it has consumed
+        // positions T-1 .. k), zero otherwise
+        const float* __restrict__ yt = ch.trunc ? G.ytab[gidx] : nullptr;
+        const int Tfull = G.T[gidx];
+        for (int idx = tid; idx < ch.nseg * GH; idx += 320) {
+            const int p = idx / GH;
+            const int uq = idx - p * GH;
+            const int k = seg_k[p];
+            seg_init[p][uq] = (yt != nullptr && k > 0 && k < Tfull) ? yt[(int64_t)k * (2 * GH) + dir * GH + uq] : 0.f;
+        }
+        __syncthreads();
+    }
+    // (row, t) of flattened step sidx
+    auto step_row = [&](int sidx, int& t) {
+        if constexpr (SEG) {
+            const uint32_t e = sched[sidx];
+            t = (int)(e & 0xFFFu);
+            return row + (int)((e >> 12) & 0xFu);
+        } else {
+            t = dir ? T - 1 - sidx : sidx;
+            return row;
+        }
+    };
 
     if (tid >= NT) {
         // ---------------- the I/O wave ----------------
@@ -396,8 +527,9 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
                 const int sidx = b * TB + sl;
                 gq[e] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (sl < TB && sidx < T) {
-                    const int t = dir ? T - 1 - sidx : sidx;
-                    gq[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH + 4 * c4);
+                    int t;
+                    const int rw = step_row(sidx, t);
+                    gq[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + rw) * (6 * GH) + dir * 3 * GH + 4 * c4);
                 }
             }
         };
@@ -411,8 +543,9 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
         auto flush_step = [&](int b, int sl) {     // results of step (b, sl): lanes = consecutive units (coalesced rows)
             const int sidx = b * TB + sl;
             if (sidx >= T) return;
-            const int t = dir ? T - 1 - sidx : sidx;
-            const int64_t o = (int64_t)t * rows + row;
+            int t;
+            const int rw = step_row(sidx, t);
+            const int64_t o = (int64_t)t * rows + rw;
             float* yp = y + o * (2 * GH) + dir * GH;
             float* gp = gates + (o * 2 + dir) * (4 * GH);
 #pragma unroll
@@ -438,6 +571,9 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
         for (int b = 0; b < nblocks; ++b) {
             if (b + 1 < nblocks) load_block(b + 1);
             for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
+                if constexpr (SEG) {
+                    if (step > 0 && ((sched[step] >> 16) & 1u)) __syncthreads();     // a segment starts: the state is re-initialised
+                }
                 if (fl < b * TB) {                 // one finished step of an earlier block per step (its block is complete)
                     flush_step(fl / TB, fl % TB);
                     ++fl;
@@ -479,7 +615,15 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     pin_loaded(bhn);
     const bool mine = active && half == 0;
     float hprev = 0.f;
-    for (int i = tid; i < 2 * (GH + 4); i += NT) (&hs[0][0])[i] = 0.f;
+    uint32_t e_cur = 0;
+    if constexpr (SEG) {
+        e_cur = T > 0 ? sched[0] : 0u;
+        const int p0 = (e_cur >> 12) & 0xFu;
+        for (int i = tid; i < 2 * (GH + 4); i += NT) (&hs[0][0])[i] = (T > 0 && i < GH) ? seg_init[p0][i] : 0.f;
+        hprev = T > 0 ? seg_init[p0][uu] : 0.f;
+    } else {
+        for (int i = tid; i < 2 * (GH + 4); i += NT) (&hs[0][0])[i] = 0.f;
+    }
     __syncthreads();                               // (A)
 
     __shared__ __attribute__((aligned(16))) float scratch[NT][8];      // write target of lanes that own no unit
@@ -491,6 +635,15 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     for (int b = 0; b < nblocks; ++b) {
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int cur = step & 1;
+            if constexpr (SEG) {
+                // a new segment: the state (LDS copy and register) becomes the segment's start state; e_cur was fetched during
+                // the previous step, so the branch condition is not an LDS round trip on the chain
+                if (step > 0 && __builtin_amdgcn_readfirstlane((e_cur >> 16) & 1u)) {
+                    hprev = seg_init[(e_cur >> 12) & 0xFu][uu];
+                    if (mine) hs[cur][u] = hprev;
+                    __syncthreads();
+                }
+            }
             // LDS operations of a step in ISSUE order (a wave's LDS operations execute in order, so anything queued in front of
             // the h loads delays the first FMA by its whole service time): six h loads, then the matvec with its reloads, and
             // only behind the LAST h load the three gate operands of this step and the two result writes of the previous
@@ -581,7 +734,27 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16" : : "v"(pend_addr), "v"(pend4), "v"(pend1) : "memory");
                 pend_addr = scratch_addr;          // (the next step's deferred write then lands in the scratch slot)
             }
+            if constexpr (SEG) e_cur = step + 1 < T ? sched[step + 1] : 0u;
             if (!(ABL & 8)) __syncthreads();
+        }
+    }
+    if constexpr (SEG) {
+        // positions this chain's rows did not visit: the all-padding sequence's outputs (a truncated direction that starts from
+        // them) or zeros (never read as values; they are operands of dense products whose other factor is an exact zero there)
+        if (ch.has_rank) {
+            const float* __restrict__ yt = ch.trunc ? G.ytab[gidx] : nullptr;
+            const int Tfull = G.T[gidx];
+            const int per = Tfull * (GH / 4);
+            for (int idx = tid; idx < ch.nseg * per; idx += NT) {
+                const int p = idx / per;
+                const int rem = idx - p * per;
+                const int t = rem / (GH / 4);
+                const int c4 = rem - t * (GH / 4);
+                if (t < seg_k[p]) continue;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yt != nullptr) v = *reinterpret_cast<const float4*>(yt + (int64_t)t * (2 * GH) + dir * GH + 4 * c4);
+                *reinterpret_cast<float4*>(y + ((int64_t)t * rows + row + p) * (2 * GH) + dir * GH + 4 * c4) = v;
+            }
         }
     }
 }
@@ -773,7 +946,11 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 
 // NW waves per workgroup (8: two per SIMD, half the instructions per wave and a second wave to issue from while the
 // first waits on a dependent result); GRP operands are fetched per group of FMAs
-template <int NW, int GRP>
+// SEG = 1: segmented launch (see SegInfo).  The flattened schedule is walked backwards; where a segment ends in that order the
+// recurrent gradient is cut (and, for a direction that started from the all-padding sequence's state, the gradient wrt that
+// start state is written to dhinit: one more matvec + exchange per segment); the (t, row) positions a truncated / silent row
+// never visited get zero dgi / dgh afterwards (they are operands of the weight-gradient contractions and column sums).
+template <int NW, int GRP, int SEG>
 __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G) {
     constexpr int NTK = 64 * NW;
     constexpr int JPW = (3 * GH + NW - 1) / NW;     // gate rows per wave (75 / 38)
@@ -784,14 +961,41 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     constexpr int NIN = (TB * IN4 + NTK - 1) / NTK;
     __shared__ __attribute__((aligned(16))) float in_s[2][TB][6 * GH];
     __shared__ __attribute__((aligned(16))) float out_s[TB][6 * GH];
-    __shared__ __attribute__((aligned(16))) float part[2][NW][PU];
+    __shared__ __attribute__((aligned(16))) float part[SEG ? 3 : 2][NW][PU];
+    __shared__ uint32_t sched[SEG ? SCHED_MAX : 1];
+    __shared__ int seg_k[MAXSEG];
 
     int gidx = 0;
-    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-    const int dir = blockIdx.y;
+    int dir_ = 0, row_ = 0, T_ = 0;
+    Chain ch{};
+    if constexpr (SEG) {
+        ch = seg_setup<NTK>(G.seg, G.T, sched, seg_k);
+        gidx = ch.gidx;
+        dir_ = ch.dir;
+        row_ = ch.row0;
+        T_ = ch.S;                                 // the time loop runs over the flattened schedule, backwards
+    } else {
+        while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
+        dir_ = blockIdx.y;
+        row_ = (int)blockIdx.x - G.slice0[gidx];
+        T_ = G.T[gidx];
+    }
+    const int dir = dir_;
     const int rows = G.rows[gidx];
-    const int T = G.T[gidx];
-    const int row = (int)blockIdx.x - G.slice0[gidx];
+    const int T = T_;
+    const int row = row_;
+    const int Tfull = G.T[gidx];
+    // (row, t) of backward step sidx
+    auto step_row = [&](int sidx, int& t) {
+        if constexpr (SEG) {
+            const uint32_t e = sched[T - 1 - sidx];
+            t = (int)(e & 0xFFFu);
+            return row + (int)((e >> 12) & 0xFu);
+        } else {
+            t = dir ? sidx : T - 1 - sidx;
+            return row;
+        }
+    };
     const float* __restrict__ dy = G.dy[gidx];
     const float* __restrict__ y = G.y[gidx];
     const float* __restrict__ gates = G.gates[gidx];
@@ -839,16 +1043,19 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
             const int sidx = b * TB + sl;
             stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sl < TB && sidx < T) {
-                const int t = dir ? sidx : T - 1 - sidx;
-                const int64_t o = (int64_t)t * rows + row;
+                int t;
+                const int rw = step_row(sidx, t);
+                const int64_t o = (int64_t)t * rows + rw;
                 if (c4 < GH / 4) {
                     stage[e] = *reinterpret_cast<const float4*>(dy + o * (2 * GH) + dir * GH + 4 * c4);
                 } else if (c4 < 5 * GH / 4) {
                     stage[e] = *reinterpret_cast<const float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4));
                 } else {
-                    const int tp = dir ? t + 1 : t - 1;   // the step that produced h_prev in the forward pass
-                    if (tp >= 0 && tp < T)
-                        stage[e] = *reinterpret_cast<const float4*>(y + ((int64_t)tp * rows + row) * (2 * GH) + dir * GH +
+                    // the step that produced h_prev in the forward pass (a truncated reverse row: position k holds the copy of
+                    // the all-padding sequence's output it started from; a truncated forward row starts from 0 at t = 0)
+                    const int tp = dir ? t + 1 : t - 1;
+                    if (tp >= 0 && tp < Tfull)
+                        stage[e] = *reinterpret_cast<const float4*>(y + ((int64_t)tp * rows + rw) * (2 * GH) + dir * GH +
                                                                     4 * (c4 - 5 * GH / 4));
                 }
             }
@@ -867,9 +1074,10 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
             const int c4 = idx - sl * OUT4;
             const int sidx = b * TB + sl;
             if (sidx >= T) continue;
-            const int t = dir ? sidx : T - 1 - sidx;
+            int t;
+            const int rw = step_row(sidx, t);
             const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][4 * c4]);
-            const int64_t o = ((int64_t)t * rows + row) * (6 * GH) + dir * 3 * GH;
+            const int64_t o = ((int64_t)t * rows + rw) * (6 * GH) + dir * 3 * GH;
             if (c4 < 3 * GH / 4)
                 *reinterpret_cast<float4*>(dgi + o + 4 * c4) = v;
             else
@@ -882,11 +1090,55 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     if (nblocks > 1) load_block(1);
     __syncthreads();
 
+    // the segment of row prow is complete: its gradient wrt the start state is carry + W_hh^T dgh(last step) -- the
+    // recurrent term the next step would have used -- written out when wanted; then the recurrence is cut
+    float* __restrict__ dhinit = SEG ? G.dhinit[gidx] : nullptr;
+    auto seg_end = [&](int prow) {
+        if (dhinit != nullptr && ch.trunc) {
+            f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < JPW; ++jj) {
+                const float dj = lane_bcast(dv[jj / 64], jj % 64);
+                const f32x2 dd = {dj, dj};
+                if (jj & 1) acc1 = __builtin_elementwise_fma(w[jj], dd, acc1);
+                else acc0 = __builtin_elementwise_fma(w[jj], dd, acc0);
+            }
+            constexpr int PX = SEG ? 2 : 0;
+            part[PX][wv][lane] = acc0[0] + acc1[0];
+            part[PX][wv][lane + 64] = acc0[1] + acc1[1];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NGR; ++q) {
+                float pr[NW];
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) pr[w2] = part[PX][w2][uu[q]];
+#pragma unroll
+                for (int sp = 1; sp < NW; sp *= 2)
+#pragma unroll
+                    for (int w2 = 0; w2 + sp < NW; w2 += 2 * sp) pr[w2] += pr[w2 + sp];
+                if (has[q] && gg[q] == 0) dhinit[(int64_t)prow * GH + uu[q]] = carry[q] + pr[0];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NGR; ++q) {
+            dv[q] = 0.f;
+            carry[q] = 0.f;
+        }
+    };
+
     int step = 0;
     for (int b = 0; b < nblocks; ++b) {
         const int buf = b & 1;
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int pb = step & 1;
+            if constexpr (SEG) {
+                // sched[T - step] is the forward-order successor of this step: if it opened a segment, the segment finished
+                // with the previous backward step
+                if (step > 0) {
+                    const uint32_t en = sched[T - step];
+                    if ((en >> 16) & 1u) seg_end(row + (int)((en >> 12) & 0xFu));
+                }
+            }
             // dh_prev partials of units (lane, lane + 64) over this wave's gate rows; dgh[j0 + jj] sits in lane jj % 64 of
             // THIS wave (register dv[jj / 64])
             // the step's staged operands of this lane's gate rows, read under the matvec instead of behind the barrier
@@ -954,12 +1206,107 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
         if (b + 2 < nblocks) load_block(b + 2);
         __syncthreads();
     }
+    if constexpr (SEG) {
+        if (T > 0) seg_end(row + (int)((sched[0] >> 12) & 0xFu));      // the segment the forward pass ran first
+        if (ch.has_rank) {
+            int32_t* __restrict__ kout = G.kout[gidx];
+            if (ch.trunc && dhinit != nullptr) {
+                for (int idx = tid; idx < ch.nseg * GH; idx += NTK) {
+                    const int p = idx / GH;
+                    if (seg_k[p] == 0) dhinit[(int64_t)(row + p) * GH + (idx - p * GH)] = 0.f;
+                }
+            }
+            if (ch.trunc && kout != nullptr && tid < ch.nseg) kout[row + tid] = seg_k[tid];
+            // zero gradients at the positions this chain's rows never visited
+            const int per = Tfull * (3 * GH / 4);
+            for (int idx = tid; idx < ch.nseg * per; idx += NTK) {
+                const int p = idx / per;
+                const int rem = idx - p * per;
+                const int t = rem / (3 * GH / 4);
+                const int c4 = rem - t * (3 * GH / 4);
+                if (t < seg_k[p]) continue;
+                const int64_t o = ((int64_t)t * rows + row + p) * (6 * GH) + dir * 3 * GH + 4 * c4;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(dgi + o) = z;
+                __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(dgh + o));
+            }
+        }
+    }
 }
 
 // one sequence per workgroup, backward pass: the wave-partitioned kernel (8 waves) unless the tuning build asks for the
 // lane-pair one (MMDFN_GRU_KPART_BWD=0) for A/B runs.  Measured at cfg2 (profiles/r02_gru_kernels.md): lane-pair 110 us,
 // partitioned over 4 waves 126, over 8 waves 84, over 16 waves ~125.  The forward pass keeps the lane-pair kernel (80 us;
 // its wave-partitioned forms 102-104 us, a lane-quad form on 8 waves 80 us).
+// Gradient that reaches the all-padding sequence (the extra row behind y_tab) from the rows that were truncated against it:
+//   dyt[t][dir half] = sum over rows with k_row <= t of dy[t][row]     (their output at t is a copy of y_tab[t])
+//                    + sum over rows with k_row == t >= 1 of dhinit[row] (they started from y_tab[t]),   the other half = 0.
+// One workgroup per t, fixed summation order (bit-reproducible).
+__global__ __launch_bounds__(256) void gru_tab_reduce_kernel(const float* __restrict__ dy, const int32_t* __restrict__ kout,
+                                                             const float* __restrict__ dhinit, float* __restrict__ dyt,
+                                                             int rows, int T, int dir) {
+    constexpr int C4 = GH / 4;        // 25 float4 columns, 32 lanes per row group
+    __shared__ float4 red[8][32];
+    const int t = blockIdx.x;
+    const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4) {
+        for (int r = rg; r < rows; r += 8) {
+            const int k = kout[r];
+            if (k <= t) {
+                const float4 v = *reinterpret_cast<const float4*>(dy + ((int64_t)t * rows + r) * (2 * GH) + dir * GH + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            if (k == t && k >= 1) {
+                const float4 v = *reinterpret_cast<const float4*>(dhinit + (int64_t)r * GH + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+    }
+    red[rg][c4] = acc;
+    __syncthreads();
+    if (rg == 0 && c4 < C4) {
+        float4 a = red[0][c4];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) {
+            const float4 v = red[g][c4];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dyt + (int64_t)t * (2 * GH) + dir * GH + 4 * c4) = a;
+        *reinterpret_cast<float4*>(dyt + (int64_t)t * (2 * GH) + (1 - dir) * GH + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// chain enumeration of a segmented launch: full-length (group, direction) slots first, merged truncated slots last (the
+// hardware hands out workgroups in index order: longest first)
+int seg_slots(SegInfo& S, int ngroups, const int* rows, const int* T, const int32_t* const* rank, const int* P, const int* BP,
+              const int* tdir) {
+    for (int g = 0; g < ngroups; ++g) {
+        S.rank[g] = rank ? rank[g] : nullptr;
+        S.P[g] = 1; S.BP[g] = 1; S.tdir[g] = -1;
+        if (S.rank[g] != nullptr) {
+            if (P[g] <= 0 || P[g] > MAXSEG || BP[g] <= 0 || BP[g] % P[g] || rows[g] % BP[g] || T[g] >= 4096 ||
+                (int64_t)P[g] * T[g] > SCHED_MAX || tdir[g] < -1 || tdir[g] > 1) return -1;
+            S.P[g] = P[g]; S.BP[g] = BP[g]; S.tdir[g] = tdir[g];
+        } else if (T[g] > SCHED_MAX) {
+            return -1;
+        }
+    }
+    int ns = 0, start = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int g = 0; g < ngroups; ++g)
+            for (int d = 0; d < 2; ++d) {
+                const bool trunc = S.rank[g] != nullptr && S.tdir[g] == d;
+                if ((int)trunc != pass) continue;
+                S.slot_g[ns] = g; S.slot_d[ns] = d; S.slot_start[ns] = start;
+                start += trunc ? rows[g] / S.P[g] : rows[g];
+                ++ns;
+            }
+    S.nslot = ns;
+    S.slot_start[ns] = start;
+    return start;
+}
+
 bool kpart_any_size() {
 #ifdef MMDFN_TUNING
     const char* e = getenv("MMDFN_GRU_KPART_BWD");
@@ -1033,12 +1380,12 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     if (const char* e = getenv("MMDFN_GRU_SCALAR_FMA")) scalar_fma = e[0] == '1';
 #endif
 #ifdef MMDFN_TUNING
-#define GRU_IO_ABL(A) if (io_wave && G.abl == A) { hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, A>), grid, dim3(320), 0, s, G); MMDFN_CHECK_LAUNCH(); return 0; }
+#define GRU_IO_ABL(A) if (io_wave && G.abl == A) { hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, A, 0>), grid, dim3(320), 0, s, G); MMDFN_CHECK_LAUNCH(); return 0; }
     GRU_IO_ABL(1) GRU_IO_ABL(2) GRU_IO_ABL(4) GRU_IO_ABL(8) GRU_IO_ABL(16) GRU_IO_ABL(3) GRU_IO_ABL(11) GRU_IO_ABL(31) GRU_IO_ABL(23)
 #undef GRU_IO_ABL
 #endif
-    if (io_wave && scalar_fma) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<1, 0>), grid, dim3(320), 0, s, G);
-    else if (io_wave) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0>), grid, dim3(320), 0, s, G);
+    if (io_wave && scalar_fma) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<1, 0, 0>), grid, dim3(320), 0, s, G);
+    else if (io_wave) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0, 0>), grid, dim3(320), 0, s, G);
     else if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_fwd_kernel<4>, grid, block, 0, s, G);
@@ -1066,10 +1413,67 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     hipStream_t s = (hipStream_t)stream;
     // (the 8-wave kernel runs one workgroup per CU: it wins while all sequences fit in one round; beyond that the lane-pair
     // kernel, two workgroups per CU, keeps the batch in one round -- cfg4: 320 workgroups, 1.75 vs 1.69 ms per step)
-    if (R == 1 && (2 * sl <= 256 || kpart_any_size()) && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4>), grid, dim3(512), 0, s, G);
+    if (R == 1 && (2 * sl <= 256 || kpart_any_size()) && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 0>), grid, dim3(512), 0, s, G);
     else if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, grid, block, 0, s, G);
     else hipLaunchKernelGGL(gru_seq_bwd_kernel<4>, grid, block, 0, s, G);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_gru_seq_fwd_seg(int ngroups, const float* const* gi, const float* const* w_hh,
+                                     const float* const* b_hh, float* const* y, float* const* gates, const int* rows,
+                                     const int* T, int H, const int32_t* const* rank, const int* P, const int* BP,
+                                     const int* tdir, const float* const* ytab, void* stream) {
+    if (ngroups <= 0 || ngroups > MAXG || H != GH) return -1;
+    FwdGroups G;
+    G.n = ngroups;
+    G.abl = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        if (rows[g] <= 0 || T[g] <= 0) return -1;
+        G.gi[g] = gi[g]; G.y[g] = y[g]; G.gates[g] = gates[g];
+        G.w_hh[2 * g] = w_hh[2 * g]; G.w_hh[2 * g + 1] = w_hh[2 * g + 1];
+        G.b_hh[2 * g] = b_hh[2 * g]; G.b_hh[2 * g + 1] = b_hh[2 * g + 1];
+        G.rows[g] = rows[g]; G.T[g] = T[g]; G.slice0[g] = 0;
+        G.ytab[g] = ytab ? ytab[g] : nullptr;
+        if (G.ytab[g] != nullptr && (rank == nullptr || rank[g] == nullptr || tdir[g] != 1)) return -1;   // a start table serves the reverse direction
+    }
+    const int nchains = seg_slots(G.seg, ngroups, rows, T, rank, P, BP, tdir);
+    if (nchains <= 0) return -1;
+    hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0, 1>), dim3(nchains), dim3(320), 0, (hipStream_t)stream, G);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_gru_seq_bwd_seg(int ngroups, const float* const* dy, const float* const* y,
+                                     const float* const* gates, const float* const* w_hh, float* const* dgi,
+                                     float* const* dgh, const int* rows, const int* T, int H,
+                                     const int32_t* const* rank, const int* P, const int* BP, const int* tdir,
+                                     float* const* dhinit, int32_t* const* kout, void* stream) {
+    if (ngroups <= 0 || ngroups > MAXG || H != GH) return -1;
+    BwdGroups G;
+    G.n = ngroups;
+    for (int g = 0; g < ngroups; ++g) {
+        if (rows[g] <= 0 || T[g] <= 0) return -1;
+        G.dy[g] = dy[g]; G.y[g] = y[g]; G.gates[g] = gates[g]; G.dgi[g] = dgi[g];
+        G.w_hh[2 * g] = w_hh[2 * g]; G.w_hh[2 * g + 1] = w_hh[2 * g + 1];
+        G.dgh[g] = dgh[g]; G.rows[g] = rows[g]; G.T[g] = T[g]; G.slice0[g] = 0;
+        G.dhinit[g] = dhinit ? dhinit[g] : nullptr;
+        G.kout[g] = kout ? kout[g] : nullptr;
+        if ((G.dhinit[g] != nullptr) != (G.kout[g] != nullptr)) return -1;
+        if (G.dhinit[g] != nullptr && (rank == nullptr || rank[g] == nullptr || tdir[g] != 1)) return -1;
+    }
+    const int nchains = seg_slots(G.seg, ngroups, rows, T, rank, P, BP, tdir);
+    if (nchains <= 0) return -1;
+    hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 1>), dim3(nchains), dim3(512), 0, (hipStream_t)stream, G);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mmdfn_gru_tab_reduce(const float* dy, const int32_t* kout, const float* dhinit, float* dyt, int rows, int T,
+                                    int H, int dir, void* stream) {
+    if (H != GH || rows <= 0 || T <= 0 || dir < 0 || dir > 1) return -1;
+    hipLaunchKernelGGL(gru_tab_reduce_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, dy, kout, dhinit, dyt, rows, T, dir);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

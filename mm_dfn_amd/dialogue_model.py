@@ -163,6 +163,14 @@ class DialogueGNNModel(nn.Module):
         (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209).
         The context GRU and the batched party GRU are independent and share every recurrence launch;
         the party gather / scatter / pad-strip are the fused K3/K4 kernels (csrc/encoder_glue.hip)."""
+        # valid-length launches of the party encoder (gru.py TRUNCATE): their all-padding sequence depends on the weights only
+        # and starts NOW, on a side stream, under the projections and the gather
+        table = None
+        n_act = sum(1 for w in self.speaker_weights if w != 0.0)
+        L_, B_, P_ = U.shape[0], U.shape[1], qmask.shape[2]
+        if (self.use_crn_speaker and n_act and P_ <= 16 and P_ * L_ <= 2048
+                and fused_gru.wants_truncation(B_ + n_act * B_ * P_)):
+            table = fused_gru.start_party_table(self.rnn_parties, L_)
         Xa, Xv, Xl = ops.linear_group([U_a, U_v, U], [self.linear_a.weight, self.linear_v.weight, self.linear_l.weight],
                                       [self.linear_a.bias, self.linear_v.bias, self.linear_l.bias])
         L, B, H = Xa.shape
@@ -187,7 +195,7 @@ class DialogueGNNModel(nn.Module):
                 passed = iter(passed)
                 Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
                 ctx, E = fused_gru.bigru2([Xl_, None], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
-                                          gi0=[None, gi_p])
+                                          gi0=[None, gi_p], party=None if table is None else (1, rank, table))
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
             if act:
                 # the gathered modalities come back as identities (passthrough): the combine stage below reads those, so
@@ -195,7 +203,8 @@ class DialogueGNNModel(nn.Module):
                 S, rank, *passed = ops.party_gather(act, qmask, passthrough=True)
                 passed = iter(passed)
                 Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
-                ctx, E = self._run_grus([Xl_, S], [self.lstm_l, self.rnn_parties])
+                ctx, E = fused_gru.bigru2([Xl_, S], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
+                                          party=None if table is None else (1, rank, table))
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
         ctx = self._run_grus([Xl], [self.lstm_l])[0]
         rank = torch.full((L, B, qmask.shape[2]), -1, dtype=torch.int32, device=Xa.device)

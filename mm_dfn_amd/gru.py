@@ -13,13 +13,45 @@ from . import _hip, ops
 H = 100
 
 
+# Valid-length truncation of the speaker-party batch (csrc/gru.hip, "Valid-length truncation"; include/mmdfn_hip.h,
+# mmdfn_gru_seq_fwd_seg): "auto" uses the segmented launches when the plain form would need more workgroups than the chip
+# has CUs (every sequence-direction is one persistent workgroup; with a CU per chain the launch lasts as long as its longest
+# chain whatever the others do, so truncation buys nothing below that), True / False force it (tests, A/B runs).
+TRUNCATE = "auto"
+CUS = 256
+
+
+def wants_truncation(n_rows_total):
+    if TRUNCATE == "auto":
+        return 2 * n_rows_total > CUS
+    return bool(TRUNCATE)
+
+
+class _Seg:
+    """Per-launch description of the party group for the segmented kernels: ``group`` index, the gather's ``rank`` array
+    (L, B, P) int32, the truncated direction, whether the all-padding sequence's outputs are an input (layer 1)."""
+
+    def __init__(self, group, rank, tdir):
+        self.group, self.rank, self.tdir = group, rank, tdir
+        self.P = rank.shape[2]
+        self.BP = rank.shape[1] * rank.shape[2]
+
+    def arrays(self, n):
+        ranks = [self.rank if g == self.group else None for g in range(n)]
+        P = [self.P if g == self.group else 1 for g in range(n)]
+        BP = [self.BP if g == self.group else 1 for g in range(n)]
+        tdir = [self.tdir if g == self.group else -1 for g in range(n)]
+        return _hip.ptr_array(ranks), _hip.int_array(P), _hip.int_array(BP), _hip.int_array(tdir)
+
+
 class _GruRecurrence(torch.autograd.Function):
-    """args = per group (gi, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev), flattened -> (y_0, y_1, ...).  The recurrent
-    weights are the module's own parameters (no stack / cat per step): the kernels take one pointer per direction
-    and the gradients come back per parameter."""
+    """args = (seg, ytab, then per group (gi, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev), flattened) -> (y_0, y_1, ...).  The
+    recurrent weights are the module's own parameters (no stack / cat per step): the kernels take one pointer per direction
+    and the gradients come back per parameter.  ``seg`` (a _Seg or None) selects the segmented launch; ``ytab`` (T, 1, 2H) or
+    None: the all-padding sequence's outputs the truncated reverse direction starts from (its gradient is returned)."""
 
     @staticmethod
-    def forward(ctx, *args):
+    def forward(ctx, seg, ytab, *args):
         n = len(args) // 5
         gis = [args[5 * g].contiguous() for g in range(n)]
         whh = [args[5 * g + 1 + d].contiguous() for g in range(n) for d in range(2)]
@@ -33,11 +65,27 @@ class _GruRecurrence(torch.autograd.Function):
             gates.append(torch.empty(T, R, 2, 4, H, dtype=torch.float32, device=gi.device))
             rows.append(R)
             Ts.append(T)
-        rc = _hip.lib().mmdfn_gru_seq_fwd(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
-                                          _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
-                                          _hip.int_array(Ts), H, _hip.stream())
-        _hip.check(rc, "mmdfn_gru_seq_fwd")
+        if seg is None:
+            rc = _hip.lib().mmdfn_gru_seq_fwd(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
+                                              _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
+                                              _hip.int_array(Ts), H, _hip.stream())
+            _hip.check(rc, "mmdfn_gru_seq_fwd")
+        else:
+            if ytab is not None:
+                ytab = ytab.contiguous()
+                _hip.require_f32(ytab)
+                if tuple(ytab.shape) != (Ts[seg.group], 1, 2 * H):
+                    raise ValueError("ytab must be (T, 1, 2H)")
+            ytabs = [ytab if g == seg.group else None for g in range(n)]
+            rk, P, BP, tdir = seg.arrays(n)
+            rc = _hip.lib().mmdfn_gru_seq_fwd_seg(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
+                                                  _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
+                                                  _hip.int_array(Ts), H, rk, P, BP, tdir, _hip.ptr_array(ytabs), _hip.stream())
+            _hip.check(rc, "mmdfn_gru_seq_fwd_seg")
         ctx.n = n
+        ctx.seg = seg
+        ctx.has_tab = ytab is not None
+        ctx.on_side = _SIDE["active"]
         ctx.refs = [args[5 * g + 1 + k] for g in range(n) for k in range(4)]   # the parameter objects (leaf test)
         ctx.save_for_backward(*ys, *gates, *whh)
         return tuple(ys)
@@ -45,6 +93,7 @@ class _GruRecurrence(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dys):
         n = ctx.n
+        seg = ctx.seg
         saved = ctx.saved_tensors
         ys, gates, whh = saved[:n], saved[n:2 * n], saved[2 * n:]
         dys = [dy.contiguous() if dy is not None else torch.zeros_like(y) for dy, y in zip(dys, ys)]
@@ -52,10 +101,31 @@ class _GruRecurrence(torch.autograd.Function):
         dgh = [torch.empty_like(t) for t in dgi]
         rows = [y.shape[1] for y in ys]
         Ts = [y.shape[0] for y in ys]
-        rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
-                                          _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
-                                          _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
-        _hip.check(rc, "mmdfn_gru_seq_bwd")
+        dyt = None
+        if seg is None:
+            rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
+                                              _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
+                                              _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
+            _hip.check(rc, "mmdfn_gru_seq_bwd")
+        else:
+            g0 = seg.group
+            dhinit = kout = None
+            if ctx.has_tab:
+                dhinit = torch.empty(rows[g0], H, dtype=torch.float32, device=ys[g0].device)
+                kout = torch.empty(rows[g0], dtype=torch.int32, device=ys[g0].device)
+            rk, P, BP, tdir = seg.arrays(n)
+            rc = _hip.lib().mmdfn_gru_seq_bwd_seg(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
+                                                  _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
+                                                  _hip.int_array(rows), _hip.int_array(Ts), H, rk, P, BP, tdir,
+                                                  _hip.ptr_array([dhinit if g == g0 else None for g in range(n)]),
+                                                  _hip.ptr_array([kout if g == g0 else None for g in range(n)]), _hip.stream())
+            _hip.check(rc, "mmdfn_gru_seq_bwd_seg")
+            if ctx.has_tab and ctx.needs_input_grad[1]:
+                # what reaches the all-padding sequence from the rows truncated against it (its own backward follows)
+                dyt = torch.empty(Ts[g0], 1, 2 * H, dtype=torch.float32, device=ys[g0].device)
+                rc = _hip.lib().mmdfn_gru_tab_reduce(_hip.ptr(dys[g0]), _hip.ptr(kout), _hip.ptr(dhinit), _hip.ptr(dyt),
+                                                     rows[g0], Ts[g0], H, seg.tdir, _hip.stream())
+                _hip.check(rc, "mmdfn_gru_tab_reduce")
         # recurrent-weight gradients of every group and direction join the step's weight-gradient batch:
         #   dW_hh = sum_t dgh_t (x) h_{t-1}   forward: h_{t-1} = y[t-1] (row shift -R), reverse: y[t+1] (+R)
         #   db_hh = sum_t dgh_t                = the column sums of the same operand
@@ -77,7 +147,66 @@ class _GruRecurrence(torch.autograd.Function):
                     ops.gemm_tn_grouped([dict(A=A, B=B, C=dw, colsum=db, shift=shift)])
                     res.append((dw, db))
             out += [dgi[g], res[0][0], res[1][0], res[0][1], res[1][1]]
-        return tuple(out)
+        if ctx.on_side:
+            # this node ran on the side stream (the all-padding sequence): the weight-gradient batch, issued on the stream
+            # that runs backward, waits for what was queued here
+            ops.note_side_work()
+        return (None, dyt) + tuple(out)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The all-padding ("silent") party sequence: input zeros -> gi = b_ih at every step.  Its reverse-direction states are what
+# every party sequence's reverse pass goes through before it reaches its own data (model.py:1076-1087 pads BEHIND the data),
+# so layer 1 computes them ONCE per step: one extra one-row group on the unchanged kernels, launched on a side stream at the
+# start of the encoders (it depends on the weights only: a single workgroup, T dependent steps, hidden behind the projections
+# and the gather) and joined where the first recurrence launch needs it.  Its backward (the same kernels again, fed by
+# mmdfn_gru_tab_reduce) runs on the side stream as well, next to the rest of the encoder backward.
+# ---------------------------------------------------------------------------------------------------
+_SIDE = {"stream": None, "active": False}
+
+
+class _SideStream:
+    def __enter__(self):
+        if _SIDE["stream"] is None:
+            _SIDE["stream"] = torch.cuda.Stream()
+        self.side = _SIDE["stream"]
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        _SIDE["active"] = True
+        return self.side
+
+    def __exit__(self, *exc):
+        _SIDE["active"] = False
+        return self.ctx.__exit__(*exc)
+
+
+class PartyTable:
+    """Handle of the all-padding sequence of one forward pass: ``y`` (T, 1, 2H) and the event behind its launch."""
+
+    def __init__(self, y, event):
+        self.y, self.event = y, event
+
+    def join(self):
+        """Called on the consumer's stream right before the launch that reads ``y``."""
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.event)
+        self.y.record_stream(cur)
+        return self.y
+
+
+def start_party_table(gru, T):
+    """Launch the all-padding sequence of ``gru``'s first layer (T steps) on the side stream; returns a PartyTable."""
+    _, b_ih, hh = _layer_params(gru, 0)
+    # aliases made on the caller's stream: the bias gradients that come back from the side stream are then handed to
+    # autograd nodes of the caller's stream (autograd orders the two streams where a gradient crosses)
+    bf, br = b_ih[0].view_as(b_ih[0]), b_ih[1].view_as(b_ih[1])
+    with _SideStream() as side:
+        gi = torch.cat([bf, br]).expand(T, 1, 6 * H).contiguous()
+        y = _GruRecurrence.apply(None, None, gi, *hh)[0]
+        ev = torch.cuda.Event()
+        ev.record(side)
+    return PartyTable(y, ev)
 
 
 def _layer_params(gru, layer):
@@ -131,11 +260,13 @@ def pair_gru_weights(module):
     return n
 
 
-def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
+def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
     """xs[g]: (T, rows_g, 200) -> ys[g]: (T, rows_g, 200); grus[g]: the nn.GRU holding group g's weights.
     gi0[g] (optional): the first layer's gate pre-activations X W_ih^T + b_ih (T, rows_g, 600) computed by the caller
     (the party encoder projects the L*B utterances once and gathers the result instead of projecting the L*P*B
-    party rows); xs[g] is then ignored."""
+    party rows); xs[g] is then ignored.
+    party = (group index, rank (L, B, P) int32, PartyTable): run that group with the valid-length launches (layer 1: reverse
+    direction truncated against the all-padding sequence; layer 2: forward direction truncated; silent rows skipped)."""
     for gru in grus:
         if gru.hidden_size != H or gru.num_layers != 2 or not gru.bidirectional or gru.batch_first:
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
@@ -172,7 +303,12 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None):
         args = []
         for gi, p in zip(gis, prm):
             args += [gi] + p[2]
-        cur = list(_GruRecurrence.apply(*args))
+        if party is None:
+            cur = list(_GruRecurrence.apply(None, None, *args))
+        elif layer == 0:
+            cur = list(_GruRecurrence.apply(_Seg(party[0], party[1], 1), party[2].join(), *args))
+        else:
+            cur = list(_GruRecurrence.apply(_Seg(party[0], party[1], 0), None, *args))
         if layer == 0 and training and dropout > 0:
             # nn.GRU's dropout between the layers: 0 / 1 keep flags from the step's flag pool (no generator launch of its
             # own) applied to every group's output by ONE launch each way

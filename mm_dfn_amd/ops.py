@@ -972,10 +972,31 @@ def flush_queued_wgrads_early():
     _flush_outs(outs, _WGQ["side"])
 
 
+_SIDE_EVENTS = []
+
+
+def note_side_work():
+    """A backward node that ran on another stream (gru.start_party_table's sequence) has queued weight-gradient segments
+    or produced their operands there: the flush, on the stream that runs backward, waits for the event recorded here."""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    _SIDE_EVENTS.append(ev)
+    if _WGQ["scope"] > 0 and not _WGQ["armed"]:
+        _WGQ["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_queued_wgrads)
+
+
+def _wait_side_events():
+    cur = torch.cuda.current_stream()
+    while _SIDE_EVENTS:
+        cur.wait_event(_SIDE_EVENTS.pop())
+
+
 def flush_queued_wgrads():
     """Issue every queued weight-gradient contraction (one launch pair per <= 40 segments) into the .grad fields."""
     outs = list(_WGQ["outs"].values())
     _WGQ["outs"], _WGQ["armed"] = {}, False
+    _wait_side_events()
     _join_side()             # first: a parameter may collect contributions from both batches (the later one accumulates)
     if outs:
         _flush_outs(outs, None)

@@ -327,3 +327,92 @@ def test_keep_flag_generator_statistics_seeding_and_graph_replay():
         seen.append(out.clone())
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
     assert all(abs(float(x.mean()) - 0.5) < 0.05 for x in seen)
+
+
+def _party_case(L, lengths, P, seed, silent=None, solo=None):
+    """Speaker masks of a ragged batch: one-hot per utterance, zero beyond each dialogue's length; ``silent`` = (b, p): that
+    speaker never talks in dialogue b; ``solo`` = b: one speaker holds the whole dialogue (k_bp = L_b)."""
+    rs = np.random.RandomState(seed)
+    B = len(lengths)
+    q = np.zeros((L, B, P), np.float32)
+    for b, n in enumerate(lengths):
+        spk = rs.randint(0, P, size=n)
+        if silent is not None and silent[0] == b:
+            spk = np.where(spk == silent[1], (silent[1] + 1) % P, spk)
+        if solo is not None and solo == b:
+            spk[:] = P - 1
+        q[np.arange(n), b, spk] = 1.0
+    return torch.from_numpy(q)
+
+
+def _run_party(mode, L, lengths, P, seed, qmask, dropout=0.0, batch=True, n_mod=2):
+    """ctx + party encoders through bigru2 with / without the valid-length launches; loss reads only what the model reads:
+    the scattered rows [:k_bp] of the party output and the context rows of real utterances."""
+    from mm_dfn_amd import ops
+    from mm_dfn_amd import train as T
+    rs = np.random.RandomState(seed)
+    B = len(lengths)
+    torch.manual_seed(seed)
+    g_ctx, g_par = make_gru(seed + 1).to(DEV), make_gru(seed + 2).to(DEV)
+    Xs = [torch.from_numpy(rs.randn(L, B, 200).astype(np.float32)).to(DEV).requires_grad_(True) for _ in range(n_mod)]
+    Xc = torch.from_numpy(rs.randn(L, B, 200).astype(np.float32)).to(DEV).requires_grad_(True)
+    q = qmask.to(DEV)
+    prev = fused.TRUNCATE
+    fused.TRUNCATE = mode
+    try:
+        table = fused.start_party_table(g_par, L) if mode else None
+        S, rank = ops.party_gather(Xs, q)
+        with ops.flag_pool(("t", seed)):
+            ctx, E = fused.bigru2([Xc, S], [g_ctx, g_par], dropout, True, party=None if table is None else (1, rank, table))
+        # weights: zero where the model never looks (t >= k of a party row)
+        k = (rank.max(0).values + 1).to(torch.int64)                     # (B, P)
+        kk = k.reshape(1, B * P).repeat(1, n_mod)                        # rows (m, b, p)
+        live = (torch.arange(L, device=DEV).unsqueeze(1) < kk).unsqueeze(-1).to(torch.float32)
+        wE = torch.from_numpy(np.random.RandomState(seed + 9).randn(*E.shape).astype(np.float32)).to(DEV) * live
+        wc = torch.from_numpy(np.random.RandomState(seed + 8).randn(*ctx.shape).astype(np.float32)).to(DEV)
+        loss = (E * wE).sum() + (ctx * wc).sum()
+        if batch:
+            T.backward(loss)
+        else:
+            loss.backward()
+    finally:
+        fused.TRUNCATE = prev
+    torch.cuda.synchronize()
+    grads = {("ctx." if g is g_ctx else "par.") + n: p.grad.clone() for g in (g_ctx, g_par) for n, p in g.named_parameters()}
+    return dict(E=E.detach() * live, ctx=ctx.detach(), dX=[x.grad.clone() for x in Xs], dXc=Xc.grad.clone(), grads=grads)
+
+
+@pytest.mark.parametrize("batch", [True, False])
+@pytest.mark.parametrize("L,lengths,P,kw", [
+    (15, [15, 9, 1], 3, {}),                       # the goldens' (L, B, P) sets
+    (33, [33, 20, 7, 3], 9, {}),
+    (110, [110, 64], 2, {}),
+    (24, [24, 24, 11, 5, 17], 4, dict(silent=(1, 2), solo=0)),       # a silent speaker; one speaker holding a whole dialogue (k = L)
+    (12, [12] * 40, 2, {}),                        # more chains than CUs in the plain form
+])
+def test_valid_length_launches_match_full_length(L, lengths, P, kw, batch):
+    """Layer 1 reverse truncated against the all-padding sequence, layer 2 forward truncated, silent rows skipped, the P
+    sequences of a (modality, dialogue) back to back in one workgroup: the scattered rows and the context are BIT-equal to
+    the full-length launches, every gradient agrees to summation-order noise (the padding steps' contributions to the
+    recurrent weights and biases arrive through the one all-padding sequence instead of once per row)."""
+    q = _party_case(L, lengths, P, 7 + L, **kw)
+    full = _run_party(False, L, lengths, P, 11, q, batch=batch)
+    seg = _run_party(True, L, lengths, P, 11, q, batch=batch)
+    assert torch.equal(seg["ctx"], full["ctx"])
+    assert torch.equal(seg["E"], full["E"])
+    assert float(full["E"].abs().max()) > 0
+    for a, b in zip(seg["dX"] + [seg["dXc"]], full["dX"] + [full["dXc"]]):
+        assert rel_err(a, b) < 2e-5
+    for k in full["grads"]:
+        assert rel_err(seg["grads"][k], full["grads"][k]) < 5e-5, k
+
+
+def test_valid_length_launches_with_interlayer_dropout():
+    """nn.GRU's dropout between the layers is applied to every row, visited or not: same flags, same result."""
+    L, lengths, P = 21, [21, 13, 8], 3
+    q = _party_case(L, lengths, P, 3)
+    full = _run_party(False, L, lengths, P, 5, q, dropout=0.5)
+    seg = _run_party(True, L, lengths, P, 5, q, dropout=0.5)
+    assert torch.equal(seg["E"], full["E"]) and torch.equal(seg["ctx"], full["ctx"])
+    for k in full["grads"]:
+        assert rel_err(seg["grads"][k], full["grads"][k]) < 5e-5, k

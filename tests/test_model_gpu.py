@@ -56,6 +56,39 @@ def test_end_to_end_against_reference_golden(name):
         assert np.abs(grads[k].cpu().numpy() - want).max() / np.abs(want).max() < 2e-4, k
 
 
+@pytest.mark.parametrize("name", sorted(E2E))
+def test_end_to_end_golden_with_valid_length_party_launches(name):
+    """The same reference goldens with the party encoder on the valid-length launches (gru.TRUNCATE forced on: at these batch
+    sizes "auto" keeps the full-length form): log-probabilities, loss and every gradient digest, through the queued
+    weight-gradient batch (the all-padding sequence's segments are queued from the side stream)."""
+    from mm_dfn_amd import gru as fused
+    cfg, seed, lengths = E2E[name]
+    g = load("e2e_%s.npz" % name)
+    b = synthetic.make_batch(seed + 1, lengths=lengths, **cfg)
+    prev, fused.TRUNCATE = fused.TRUNCATE, True
+    try:
+        m = hip_model(cfg, seed).eval()
+        with torch.no_grad():
+            logp = run(m, b)
+        assert np.abs(logp.cpu().numpy() - g["log_prob"]).max() < 1e-4
+        m.train()
+        logp = run(m, b)
+        label = train.flatten_labels(b["label"].to(DEV), b["lengths"])
+        loss = FocalLoss(gamma=0.5)(logp, label)
+        assert abs(loss.item() - float(g["loss"])) < 1e-5
+        train.backward(loss)
+    finally:
+        fused.TRUNCATE = prev
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    for k in [str(x) for x in g["live_params"]]:
+        want = g["gd/" + k]
+        assert grads[k] is not None, k
+        assert abs(_digest(grads[k])[1] - want[1]) / (want[1] + 1e-12) < 2e-4, k
+    for k in [x[2:] for x in g.files if x.startswith("g/")]:
+        want = g["g/" + k]
+        assert np.abs(grads[k].cpu().numpy() - want).max() / np.abs(want).max() < 2e-4, k
+
+
 def test_gcnii_module_against_golden():
     g = load("gcnii.npz")
     for ci in range(3):
