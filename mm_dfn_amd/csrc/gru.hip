@@ -58,24 +58,68 @@ struct Chain {
     bool trunc, has_rank;
 };
 
-// decode blockIdx.x -> chain, count the steps of its segments and lay out the flattened schedule in LDS:
-//   sched[s] = t | segment << 12 | (first step of its segment) << 16,   s = 0 .. S-1 in FORWARD processing order
-// seg_k[p] = steps of segment p (a full-length chain: T, or 0 for a silent party row).  Ends with a barrier.
-template <int NTH>
-__device__ __forceinline__ Chain seg_setup(const SegInfo& Sg, const int* Tg, uint32_t* sched, int* seg_k) {
+// blockIdx.x -> chain (arithmetic only: the weight loads that depend on the group / direction can start before the counting)
+__device__ __forceinline__ Chain seg_decode(const SegInfo& Sg) {
     Chain c;
-    const int tid = threadIdx.x;
     int sl = 0;
     while (sl + 1 < Sg.nslot && (int)blockIdx.x >= Sg.slot_start[sl + 1]) ++sl;
     c.gidx = Sg.slot_g[sl];
     c.dir = Sg.slot_d[sl];
     const int ci = (int)blockIdx.x - Sg.slot_start[sl];
-    const int32_t* __restrict__ rk = Sg.rank[c.gidx];
-    const int P = Sg.P[c.gidx], BP = Sg.BP[c.gidx], T = Tg[c.gidx];
-    c.has_rank = rk != nullptr;
+    c.has_rank = Sg.rank[c.gidx] != nullptr;
     c.trunc = c.has_rank && Sg.tdir[c.gidx] == c.dir;
-    c.row0 = c.trunc ? ci * P : ci;
-    c.nseg = c.trunc ? P : 1;
+    c.row0 = c.trunc ? ci * Sg.P[c.gidx] : ci;
+    c.nseg = c.trunc ? Sg.P[c.gidx] : 1;
+    c.S = 0;
+    return c;
+}
+
+// count the steps of the chain's segments and lay out the flattened schedule in LDS:
+//   sched[s] = t | segment << 12 | (first step of its segment) << 16,   s = 0 .. S-1 in FORWARD processing order
+// seg_k[p] = steps of segment p (a full-length chain: T, or 0 for a silent party row).  Ends with a barrier.
+// Uniform (scalar-register) walk over the segments that have steps: which segment a flattened step belongs to and where the
+// next one starts.  The per-step checks of the time loops are integer compares on these (an LDS lookup per step, or a
+// readfirstlane of one, costs the 5-wave forward kernel 10 us per 110 steps: tools/ablate_gru_seg.py).
+struct SegCursor {
+    int p, off, k;      // current segment, its first flattened step, its step count (k = 0: no segment left)
+    int next;           // first flattened step of the next segment with steps (INT_MAX: none)
+};
+
+__device__ __forceinline__ int seg_next_with_steps(const int* seg_k, int nseg, int p) {
+    ++p;
+    while (p < nseg && seg_k[p] == 0) ++p;
+    return p;
+}
+
+__device__ __forceinline__ SegCursor seg_cursor_begin(const int* seg_k, int nseg) {
+    SegCursor c;
+    c.p = seg_next_with_steps(seg_k, nseg, -1);
+    c.off = 0;
+    c.k = c.p < nseg ? seg_k[c.p] : 0;
+    const int q = seg_next_with_steps(seg_k, nseg, c.p);
+    c.next = q < nseg ? c.off + c.k : 0x7fffffff;
+    c.p = __builtin_amdgcn_readfirstlane(c.p);
+    c.k = __builtin_amdgcn_readfirstlane(c.k);
+    c.next = __builtin_amdgcn_readfirstlane(c.next);
+    return c;
+}
+
+__device__ __forceinline__ void seg_cursor_advance(SegCursor& c, const int* seg_k, int nseg) {
+    c.off += c.k;
+    c.p = seg_next_with_steps(seg_k, nseg, c.p);
+    c.k = c.p < nseg ? seg_k[c.p] : 0;
+    const int q = seg_next_with_steps(seg_k, nseg, c.p);
+    c.next = q < nseg ? c.off + c.k : 0x7fffffff;
+    c.p = __builtin_amdgcn_readfirstlane(c.p);
+    c.k = __builtin_amdgcn_readfirstlane(c.k);
+    c.next = __builtin_amdgcn_readfirstlane(c.next);
+}
+
+template <int NTH>
+__device__ __forceinline__ void seg_schedule(const SegInfo& Sg, const int* Tg, Chain& c, uint32_t* sched, int* seg_k) {
+    const int tid = threadIdx.x;
+    const int32_t* __restrict__ rk = Sg.rank[c.gidx];
+    const int BP = Sg.BP[c.gidx], T = Tg[c.gidx];
     if (tid < MAXSEG) seg_k[tid] = 0;
     __syncthreads();
     if (c.has_rank) {
@@ -106,6 +150,12 @@ __device__ __forceinline__ Chain seg_setup(const SegInfo& Sg, const int* Tg, uin
         }
     }
     __syncthreads();
+}
+
+template <int NTH>
+__device__ __forceinline__ Chain seg_setup(const SegInfo& Sg, const int* Tg, uint32_t* sched, int* seg_k) {
+    Chain c = seg_decode(Sg);
+    seg_schedule<NTH>(Sg, Tg, c, sched, seg_k);
     return c;
 }
 
@@ -182,8 +232,10 @@ constexpr int KW = 52;                  // weights held per gate per lane (secon
 // collected in LDS and written out with coalesced 16-byte stores that nobody waits for.  Inside a block the
 // recurrence touches LDS only.
 
-template <int R>
+// SEG = 1 (R = 1 only): segmented launch, see SegInfo and gru_seq_fwd_io_kernel.
+template <int R, int SEG>
 __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
+    static_assert(!SEG || R == 1, "segmented launches run one row per workgroup");
     constexpr int TB = 8 / R;
     constexpr int IN4 = 3 * GH / 4;                 // float4 per (step, row) of staged input  (gi: r, z, n)
     constexpr int OUT4 = 5 * GH / 4;                // float4 per (step, row) of staged output (y, r, z, n, ghn)
@@ -191,19 +243,13 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     __shared__ __attribute__((aligned(16))) float hs[2][R][GH + 4];
     __shared__ __attribute__((aligned(16))) float in_s[2][TB][R][3 * GH];
     __shared__ __attribute__((aligned(16))) float out_s[TB][R][5 * GH];
+    __shared__ uint32_t sched[SEG ? SCHED_MAX : 1];
+    __shared__ int seg_k[MAXSEG];
+    __shared__ __attribute__((aligned(16))) float seg_init[SEG ? MAXSEG : 1][GH];
 
     int gidx = 0;
-    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-    const int dir = blockIdx.y;
-    const int rows = G.rows[gidx];
-    const int T = G.T[gidx];
-    const int row0 = ((int)blockIdx.x - G.slice0[gidx]) * R;
-    const float* __restrict__ gi = G.gi[gidx];
-    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
-    const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
-    float* __restrict__ y = G.y[gidx];
-    float* __restrict__ gates = G.gates[gidx];
-
+    int dir_ = 0, row_ = 0, T_ = 0;
+    Chain ch{};
     const int tid = threadIdx.x;
     const int u = tid >> 1;
     const int half = tid & 1;
@@ -211,6 +257,75 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     const int uu = active ? u : GH - 1;
     const int kbase = half ? KH0 : 0;
     const int klen = half ? GH - KH0 : KH0;
+    // weights as packed pairs: v_pk_fma_f32 retires two FMAs per issue slot (a single wave per SIMD issues
+    // one VALU instruction every ~4 cycles, so halving the instruction count halves the matvec time)
+    f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
+    auto load_weights = [&](const float* __restrict__ wsrc) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const bool ok = k < klen;
+            const int kk = kbase + (ok ? k : 0);
+            wr[k >> 1][k & 1] = ok ? wsrc[(int64_t)(0 * GH + uu) * GH + kk] : 0.f;
+            wz[k >> 1][k & 1] = ok ? wsrc[(int64_t)(1 * GH + uu) * GH + kk] : 0.f;
+            wn[k >> 1][k & 1] = ok ? wsrc[(int64_t)(2 * GH + uu) * GH + kk] : 0.f;
+        }
+    };
+    if constexpr (SEG) {
+        ch = seg_decode(G.seg);
+        gidx = ch.gidx;
+        dir_ = ch.dir;
+        row_ = ch.row0;
+        load_weights(G.w_hh[2 * gidx + dir_]);     // in flight while the steps are counted
+        seg_schedule<NT>(G.seg, G.T, ch, sched, seg_k);
+        T_ = ch.S;                                 // the time loop runs over the flattened schedule
+    } else {
+        while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
+        dir_ = blockIdx.y;
+        row_ = ((int)blockIdx.x - G.slice0[gidx]) * R;
+        T_ = G.T[gidx];
+    }
+    const int dir = dir_;
+    const int rows = G.rows[gidx];
+    const int T = T_;
+    const int row0 = row_;
+    // (row, t) of flattened step sidx (SEG), or of step sidx of row r
+    auto step_row = [&](int sidx, int r, int& t) {
+        if constexpr (SEG) {
+            const uint32_t e = sched[sidx];
+            t = (int)(e & 0xFFFu);
+            return row0 + (int)((e >> 12) & 0xFu);
+        } else {
+            t = dir ? T - 1 - sidx : sidx;
+            return row0 + r;
+        }
+    };
+    const float* __restrict__ gi = G.gi[gidx];
+    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
+    const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
+    float* __restrict__ y = G.y[gidx];
+    float* __restrict__ gates = G.gates[gidx];
+
+    // SEG: positions this chain's rows do not visit get the all-padding sequence's outputs, or zeros (see gru_seq_fwd_io_kernel)
+    auto fill_unvisited = [&]() {
+        if (!ch.has_rank) return;
+        const float* __restrict__ yt = ch.trunc ? G.ytab[gidx] : nullptr;
+        const int Tfull = G.T[gidx];
+        const int per = Tfull * (GH / 4);
+        for (int idx = tid; idx < ch.nseg * per; idx += NT) {
+            const int p = idx / per;
+            const int rem = idx - p * per;
+            const int t = rem / (GH / 4);
+            const int c4 = rem - t * (GH / 4);
+            if (t < seg_k[p]) continue;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yt != nullptr) v = *reinterpret_cast<const float4*>(yt + (int64_t)t * (2 * GH) + dir * GH + 4 * c4);
+            *reinterpret_cast<float4*>(y + ((int64_t)t * rows + row0 + p) * (2 * GH) + dir * GH + 4 * c4) = v;
+        }
+    };
+    if constexpr (SEG) {
+        fill_unvisited();              // (up front: the stores drain under the prologue)
+        if (T == 0) return;            // a silent row / a dialogue without a party utterance: nothing to run
+    }
 #ifdef MMDFN_TUNING
     const int abl = G.abl;         // 1 no matvec, 2 no transcendental gate math, 4 no block traffic (stash / flush / prefetch),
                                    // 8 no deferred result writes, 16 no per-step barrier
@@ -218,17 +333,7 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
     constexpr int abl = 0;
 #endif
 
-    // weights as packed pairs: v_pk_fma_f32 retires two FMAs per issue slot (a single wave per SIMD issues
-    // one VALU instruction every ~4 cycles, so halving the instruction count halves the matvec time)
-    f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
-#pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        const bool ok = k < klen;
-        const int kk = kbase + (ok ? k : 0);
-        wr[k >> 1][k & 1] = ok ? w_hh[(int64_t)(0 * GH + uu) * GH + kk] : 0.f;
-        wz[k >> 1][k & 1] = ok ? w_hh[(int64_t)(1 * GH + uu) * GH + kk] : 0.f;
-        wn[k >> 1][k & 1] = ok ? w_hh[(int64_t)(2 * GH + uu) * GH + kk] : 0.f;
-    }
+    if constexpr (!SEG) load_weights(w_hh);
 #pragma unroll
     for (int k = 0; k < KW / 2; ++k) {
         pin_loaded(wr[k]);
@@ -261,8 +366,9 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             const int sidx = b * TB + sl;
             stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sl < TB && sidx < T && row0 + r < rows) {
-                const int t = dir ? T - 1 - sidx : sidx;
-                stage[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + row0 + r) * (6 * GH) + dir * 3 * GH + 4 * c4);
+                int t;
+                const int rw = step_row(sidx, r, t);
+                stage[e] = *reinterpret_cast<const float4*>(gi + ((int64_t)t * rows + rw) * (6 * GH) + dir * 3 * GH + 4 * c4);
             }
         }
     };
@@ -281,9 +387,10 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             const int c4 = rem - r * OUT4;
             const int sidx = b * TB + sl;
             if (sidx >= T || row0 + r >= rows) continue;
-            const int t = dir ? T - 1 - sidx : sidx;
+            int t;
+            const int rw = step_row(sidx, r, t);
             const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][r][4 * c4]);
-            const int64_t o = ((int64_t)t * rows + row0 + r);
+            const int64_t o = ((int64_t)t * rows + rw);
             if (c4 < GH / 4)
                 *reinterpret_cast<float4*>(y + o * (2 * GH) + dir * GH + 4 * c4) = v;
             else
@@ -291,7 +398,25 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
         }
     };
 
-    for (int i = tid; i < 2 * R * (GH + 4); i += NT) (&hs[0][0][0])[i] = 0.f;
+    uint32_t e_cur = 0;
+    if constexpr (SEG) {
+        // start state of every segment: the all-padding sequence's state at position k (reverse direction), zero otherwise
+        const float* __restrict__ yt = ch.trunc ? G.ytab[gidx] : nullptr;
+        const int Tfull = G.T[gidx];
+        for (int idx = tid; idx < ch.nseg * GH; idx += NT) {
+            const int p = idx / GH;
+            const int uq = idx - p * GH;
+            const int kq = seg_k[p];
+            seg_init[p][uq] = (yt != nullptr && kq > 0 && kq < Tfull) ? yt[(int64_t)kq * (2 * GH) + dir * GH + uq] : 0.f;
+        }
+        __syncthreads();
+        e_cur = T > 0 ? sched[0] : 0u;
+        const int p0 = (e_cur >> 12) & 0xFu;
+        for (int i = tid; i < 2 * R * (GH + 4); i += NT) (&hs[0][0][0])[i] = (T > 0 && i < GH) ? seg_init[p0][i] : 0.f;
+        hprev[0] = T > 0 ? seg_init[p0][uu] : 0.f;
+    } else {
+        for (int i = tid; i < 2 * R * (GH + 4); i += NT) (&hs[0][0][0])[i] = 0.f;
+    }
     load_block(0);
     stash_block(0);
     if (nblocks > 1) load_block(1);
@@ -324,6 +449,15 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
         const int buf = b & 1;
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int cur = step & 1;
+            if constexpr (SEG) {
+                // a new segment: the state (LDS copy and register) becomes the segment's start state (e_cur was fetched during
+                // the previous step)
+                if (step > 0 && __builtin_amdgcn_readfirstlane((e_cur >> 16) & 1u)) {
+                    hprev[0] = seg_init[(e_cur >> 12) & 0xFu][uu];
+                    if (mine[0]) hs[cur][0][u] = hprev[0];
+                    __syncthreads();
+                }
+            }
             if (have_pend && !(abl & 8)) write_pending();
             float g0[R], g1[R], g2[R];
 #pragma unroll
@@ -418,6 +552,7 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
             }
             have_pend = true;
             pend_sl = sl;
+            if constexpr (SEG) e_cur = step + 1 < T ? sched[step + 1] : 0u;
             if (!(abl & 16)) __syncthreads();
         }
         if (have_pend) write_pending();
@@ -466,11 +601,33 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     int gidx = 0;
     int dir_ = 0, row_ = 0, T_ = 0;
     Chain ch{};
+    // lane pair (2u, 2u+1) = hidden unit u x half of the contraction (the recurrence waves; the I/O wave's lanes map to unit GH-1)
+    const int tid = threadIdx.x;
+    const int u = tid >> 1;
+    const int half = tid & 1;
+    const bool active = u < GH;
+    const int uu = active ? u : GH - 1;
+    const int kbase = half ? KH0 : 0;
+    const int klen = half ? GH - KH0 : KH0;
+    f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
+    auto load_weights = [&](const float* __restrict__ wsrc) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const bool ok = k < klen;
+            const int kk = kbase + (ok ? k : 0);
+            wr[k >> 1][k & 1] = ok ? wsrc[(int64_t)(0 * GH + uu) * GH + kk] : 0.f;
+            wz[k >> 1][k & 1] = ok ? wsrc[(int64_t)(1 * GH + uu) * GH + kk] : 0.f;
+            wn[k >> 1][k & 1] = ok ? wsrc[(int64_t)(2 * GH + uu) * GH + kk] : 0.f;
+        }
+    };
     if constexpr (SEG) {
-        ch = seg_setup<320>(G.seg, G.T, sched, seg_k);
+        ch = seg_decode(G.seg);
         gidx = ch.gidx;
         dir_ = ch.dir;
         row_ = ch.row0;
+        // the weight loads (they need the group and the direction only) are in flight while the steps are counted
+        if (tid < NT) load_weights(G.w_hh[2 * gidx + dir_]);
+        seg_schedule<320>(G.seg, G.T, ch, sched, seg_k);
         T_ = ch.S;                                 // the time loop runs over the flattened schedule
     } else {
         while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
@@ -487,7 +644,6 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     const float* __restrict__ b_hh = G.b_hh[2 * gidx + dir];
     float* __restrict__ y = G.y[gidx];
     float* __restrict__ gates = G.gates[gidx];
-    const int tid = threadIdx.x;
     const int nblocks = (T + TB - 1) / TB;
     if constexpr (SEG) {
         // start state of every segment: the all-padding sequence's state at position k (reverse direction: it has consumed
@@ -501,6 +657,30 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
             seg_init[p][uq] = (yt != nullptr && k > 0 && k < Tfull) ? yt[(int64_t)k * (2 * GH) + dir * GH + uq] : 0.f;
         }
         __syncthreads();
+    }
+    // SEG: positions this chain's rows do not visit get the all-padding sequence's outputs (a truncated direction that starts
+    // from them) or zeros (never read as values; they are operands of dense products whose other factor is an exact zero there)
+    auto fill_unvisited = [&](int first, int nthreads) {
+        if (!ch.has_rank) return;
+        const float* __restrict__ yt = ch.trunc ? G.ytab[gidx] : nullptr;
+        const int Tfull = G.T[gidx];
+        const int per = Tfull * (GH / 4);
+        for (int idx = first; idx < ch.nseg * per; idx += nthreads) {
+            const int p = idx / per;
+            const int rem = idx - p * per;
+            const int t = rem / (GH / 4);
+            const int c4 = rem - t * (GH / 4);
+            if (t < seg_k[p]) continue;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (yt != nullptr) v = *reinterpret_cast<const float4*>(yt + (int64_t)t * (2 * GH) + dir * GH + 4 * c4);
+            *reinterpret_cast<float4*>(y + ((int64_t)t * rows + row + p) * (2 * GH) + dir * GH + 4 * c4) = v;
+        }
+    };
+    if constexpr (SEG) {
+        if (T == 0) {                  // a silent row / a dialogue without a party utterance: nothing to run, no weights needed
+            fill_unvisited(tid, 320);
+            return;
+        }
     }
     // (row, t) of flattened step sidx
     auto step_row = [&](int sidx, int& t) {
@@ -540,11 +720,23 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
                 if (idx < TB * 3 * GH / 4) *reinterpret_cast<float4*>(&in_s[buf][0][0] + 4 * idx) = gq[e];
             }
         };
+        // SEG: the (row, t) of the step to drain comes from a scalar segment cursor (an LDS lookup in front of every drain makes
+        // this wave late for the per-step barrier)
+        SegCursor cf{};
+        if constexpr (SEG) cf = seg_cursor_begin(seg_k, ch.nseg);
         auto flush_step = [&](int b, int sl) {     // results of step (b, sl): lanes = consecutive units (coalesced rows)
             const int sidx = b * TB + sl;
             if (sidx >= T) return;
             int t;
-            const int rw = step_row(sidx, t);
+            int rw;
+            if constexpr (SEG) {
+                if (sidx >= cf.next) seg_cursor_advance(cf, seg_k, ch.nseg);      // (steps are drained in order)
+                const int j = sidx - cf.off;
+                t = dir ? cf.k - 1 - j : j;
+                rw = row + cf.p;
+            } else {
+                rw = step_row(sidx, t);
+            }
             const int64_t o = (int64_t)t * rows + rw;
             float* yp = y + o * (2 * GH) + dir * GH;
             float* gp = gates + (o * 2 + dir) * (4 * GH);
@@ -568,11 +760,16 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
         __syncthreads();                           // (A) block 0 operands in LDS, h_0 = 0 written by the recurrence waves
         int step = 0;
         int fl = 0;                                // next step whose results are still to be drained
+        SegCursor cs{};                            // SEG: where the next segment starts (the recurrence waves' extra barrier)
+        if constexpr (SEG) cs = seg_cursor_begin(seg_k, ch.nseg);
         for (int b = 0; b < nblocks; ++b) {
             if (b + 1 < nblocks) load_block(b + 1);
             for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
                 if constexpr (SEG) {
-                    if (step > 0 && ((sched[step] >> 16) & 1u)) __syncthreads();     // a segment starts: the state is re-initialised
+                    if (!(ABL & 32) && step == cs.next) {      // a segment starts: the state is re-initialised
+                        seg_cursor_advance(cs, seg_k, ch.nseg);
+                        __syncthreads();
+                    }
                 }
                 if (fl < b * TB) {                 // one finished step of an earlier block per step (its block is complete)
                     flush_step(fl / TB, fl % TB);
@@ -588,21 +785,7 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     }
 
     // ---------------- the four recurrence waves (lane pair (2u, 2u+1) = hidden unit u x half of the contraction) ----------------
-    const int u = tid >> 1;
-    const int half = tid & 1;
-    const bool active = u < GH;
-    const int uu = active ? u : GH - 1;
-    const int kbase = half ? KH0 : 0;
-    const int klen = half ? GH - KH0 : KH0;
-    f32x2 wr[KW / 2], wz[KW / 2], wn[KW / 2];
-#pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        const bool ok = k < klen;
-        const int kk = kbase + (ok ? k : 0);
-        wr[k >> 1][k & 1] = ok ? w_hh[(int64_t)(0 * GH + uu) * GH + kk] : 0.f;
-        wz[k >> 1][k & 1] = ok ? w_hh[(int64_t)(1 * GH + uu) * GH + kk] : 0.f;
-        wn[k >> 1][k & 1] = ok ? w_hh[(int64_t)(2 * GH + uu) * GH + kk] : 0.f;
-    }
+    if constexpr (!SEG) load_weights(w_hh);
 #pragma unroll
     for (int k = 0; k < KW / 2; ++k) {
         pin_loaded(wr[k]);
@@ -615,12 +798,13 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
     pin_loaded(bhn);
     const bool mine = active && half == 0;
     float hprev = 0.f;
-    uint32_t e_cur = 0;
+    SegCursor cs{};
     if constexpr (SEG) {
-        e_cur = T > 0 ? sched[0] : 0u;
-        const int p0 = (e_cur >> 12) & 0xFu;
+        cs = seg_cursor_begin(seg_k, ch.nseg);
+        const int p0 = cs.p < ch.nseg ? cs.p : 0;
         for (int i = tid; i < 2 * (GH + 4); i += NT) (&hs[0][0])[i] = (T > 0 && i < GH) ? seg_init[p0][i] : 0.f;
         hprev = T > 0 ? seg_init[p0][uu] : 0.f;
+        fill_unvisited(tid, NT);       // stores nobody waits for (these waves touch no global memory in the time loop)
     } else {
         for (int i = tid; i < 2 * (GH + 4); i += NT) (&hs[0][0])[i] = 0.f;
     }
@@ -636,10 +820,10 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int cur = step & 1;
             if constexpr (SEG) {
-                // a new segment: the state (LDS copy and register) becomes the segment's start state; e_cur was fetched during
-                // the previous step, so the branch condition is not an LDS round trip on the chain
-                if (step > 0 && __builtin_amdgcn_readfirstlane((e_cur >> 16) & 1u)) {
-                    hprev = seg_init[(e_cur >> 12) & 0xFu][uu];
+                // a new segment: the state (LDS copy and register) becomes the segment's start state; the test is a scalar compare
+                if (!(ABL & 32) && step == cs.next) {
+                    seg_cursor_advance(cs, seg_k, ch.nseg);
+                    hprev = seg_init[cs.p][uu];
                     if (mine) hs[cur][u] = hprev;
                     __syncthreads();
                 }
@@ -734,27 +918,7 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %0, %2 offset:16" : : "v"(pend_addr), "v"(pend4), "v"(pend1) : "memory");
                 pend_addr = scratch_addr;          // (the next step's deferred write then lands in the scratch slot)
             }
-            if constexpr (SEG) e_cur = step + 1 < T ? sched[step + 1] : 0u;
             if (!(ABL & 8)) __syncthreads();
-        }
-    }
-    if constexpr (SEG) {
-        // positions this chain's rows did not visit: the all-padding sequence's outputs (a truncated direction that starts from
-        // them) or zeros (never read as values; they are operands of dense products whose other factor is an exact zero there)
-        if (ch.has_rank) {
-            const float* __restrict__ yt = ch.trunc ? G.ytab[gidx] : nullptr;
-            const int Tfull = G.T[gidx];
-            const int per = Tfull * (GH / 4);
-            for (int idx = tid; idx < ch.nseg * per; idx += NT) {
-                const int p = idx / per;
-                const int rem = idx - p * per;
-                const int t = rem / (GH / 4);
-                const int c4 = rem - t * (GH / 4);
-                if (t < seg_k[p]) continue;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (yt != nullptr) v = *reinterpret_cast<const float4*>(yt + (int64_t)t * (2 * GH) + dir * GH + 4 * c4);
-                *reinterpret_cast<float4*>(y + ((int64_t)t * rows + row + p) * (2 * GH) + dir * GH + 4 * c4) = v;
-            }
         }
     }
 }
@@ -764,8 +928,12 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
 constexpr int JH0 = 152;
 constexpr int JW = 152;
 
-template <int R>
+// SEG = 1 (R = 1 only): segmented launch, see SegInfo and gru_seq_bwd_kpart_kernel.  The recurrent term of a step is formed
+// from the previous step's dgh anyway: where a segment ended it IS the gradient wrt that segment's start state (written to
+// dhinit when wanted) and the step itself starts from zero.
+template <int R, int SEG>
 __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
+    static_assert(!SEG || R == 1, "segmented launches run one row per workgroup");
     constexpr int TB = 8 / R;
     constexpr int IN4 = 6 * GH / 4;     // staged per (step,row): dy (GH) | r z n ghn (4 GH) | h_prev (GH)
     constexpr int OUT4 = 6 * GH / 4;    // dgi (3 GH) | dgh (3 GH)
@@ -773,20 +941,12 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     __shared__ __attribute__((aligned(16))) float dghs[2][R][3 * GH + 4];
     __shared__ __attribute__((aligned(16))) float in_s[2][TB][R][6 * GH];
     __shared__ __attribute__((aligned(16))) float out_s[TB][R][6 * GH];
+    __shared__ uint32_t sched[SEG ? SCHED_MAX : 1];
+    __shared__ int seg_k[MAXSEG];
 
     int gidx = 0;
-    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-    const int dir = blockIdx.y;
-    const int rows = G.rows[gidx];
-    const int T = G.T[gidx];
-    const int row0 = ((int)blockIdx.x - G.slice0[gidx]) * R;
-    const float* __restrict__ dy = G.dy[gidx];
-    const float* __restrict__ y = G.y[gidx];
-    const float* __restrict__ gates = G.gates[gidx];
-    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
-    float* __restrict__ dgi = G.dgi[gidx];
-    float* __restrict__ dgh = G.dgh[gidx];
-
+    int dir_ = 0, row_ = 0, T_ = 0;
+    Chain ch{};
     const int tid = threadIdx.x;
     const int u = tid >> 1;
     const int half = tid & 1;
@@ -795,8 +955,77 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     const int jbase = half ? JH0 : 0;
     const int jlen = half ? 3 * GH - JH0 : JH0;
     f32x2 w[JW / 2];
+    auto load_weights = [&](const float* __restrict__ wsrc) {
 #pragma unroll
-    for (int j = 0; j < JW; ++j) w[j >> 1][j & 1] = (j < jlen) ? w_hh[(int64_t)(jbase + (j < jlen ? j : 0)) * GH + uu] : 0.f;
+        for (int j = 0; j < JW; ++j) w[j >> 1][j & 1] = (j < jlen) ? wsrc[(int64_t)(jbase + (j < jlen ? j : 0)) * GH + uu] : 0.f;
+    };
+    if constexpr (SEG) {
+        ch = seg_decode(G.seg);
+        gidx = ch.gidx;
+        dir_ = ch.dir;
+        row_ = ch.row0;
+        load_weights(G.w_hh[2 * gidx + dir_]);     // in flight while the steps are counted
+        seg_schedule<NT>(G.seg, G.T, ch, sched, seg_k);
+        T_ = ch.S;                                 // the time loop runs over the flattened schedule, backwards
+    } else {
+        while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
+        dir_ = blockIdx.y;
+        row_ = ((int)blockIdx.x - G.slice0[gidx]) * R;
+        T_ = G.T[gidx];
+    }
+    const int dir = dir_;
+    const int rows = G.rows[gidx];
+    const int T = T_;
+    const int row0 = row_;
+    const int Tfull = G.T[gidx];
+    float* __restrict__ dhinit = SEG ? G.dhinit[gidx] : nullptr;
+    // (row, t) of backward step sidx
+    auto step_row = [&](int sidx, int r, int& t) {
+        if constexpr (SEG) {
+            const uint32_t e = sched[T - 1 - sidx];
+            t = (int)(e & 0xFFFu);
+            return row0 + (int)((e >> 12) & 0xFu);
+        } else {
+            t = dir ? sidx : T - 1 - sidx;
+            return row0 + r;
+        }
+    };
+    const float* __restrict__ dy = G.dy[gidx];
+    const float* __restrict__ y = G.y[gidx];
+    const float* __restrict__ gates = G.gates[gidx];
+    const float* __restrict__ w_hh = G.w_hh[2 * gidx + dir];
+    float* __restrict__ dgi = G.dgi[gidx];
+    float* __restrict__ dgh = G.dgh[gidx];
+
+    // SEG: step counts / zero start-state gradients of rows without steps, zero dgi / dgh at the positions never visited
+    auto finish_unvisited = [&]() {
+        if (!ch.has_rank) return;
+        int32_t* __restrict__ kout = G.kout[gidx];
+        if (ch.trunc && dhinit != nullptr) {
+            for (int idx = tid; idx < ch.nseg * GH; idx += NT) {
+                const int p = idx / GH;
+                if (seg_k[p] == 0) dhinit[(int64_t)(row0 + p) * GH + (idx - p * GH)] = 0.f;
+            }
+        }
+        if (ch.trunc && kout != nullptr && tid < ch.nseg) kout[row0 + tid] = seg_k[tid];
+        const int per = Tfull * (3 * GH / 4);
+        for (int idx = tid; idx < ch.nseg * per; idx += NT) {
+            const int p = idx / per;
+            const int rem = idx - p * per;
+            const int t = rem / (3 * GH / 4);
+            const int c4 = rem - t * (3 * GH / 4);
+            if (t < seg_k[p]) continue;
+            const int64_t o = ((int64_t)t * rows + row0 + p) * (6 * GH) + dir * 3 * GH + 4 * c4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(dgi + o) = z;
+            __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(dgh + o));
+        }
+    };
+    if constexpr (SEG) {
+        finish_unvisited();            // (up front: the stores drain under the prologue and the first steps instead of at the end)
+        if (T == 0) return;            // nothing to run
+    }
+    if constexpr (!SEG) load_weights(w_hh);
 #pragma unroll
     for (int j = 0; j < JW / 2; ++j) pin_loaded(w[j]);
 
@@ -822,16 +1051,17 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
             const int sidx = b * TB + sl;
             stage[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sl < TB && sidx < T && row0 + r < rows) {
-                const int t = dir ? sidx : T - 1 - sidx;
-                const int64_t o = ((int64_t)t * rows + row0 + r);
+                int t;
+                const int rw = step_row(sidx, r, t);
+                const int64_t o = ((int64_t)t * rows + rw);
                 if (c4 < GH / 4) {
                     stage[e] = *reinterpret_cast<const float4*>(dy + o * (2 * GH) + dir * GH + 4 * c4);
                 } else if (c4 < 5 * GH / 4) {
                     stage[e] = *reinterpret_cast<const float4*>(gates + (o * 2 + dir) * (4 * GH) + 4 * (c4 - GH / 4));
                 } else {
                     const int tp = dir ? t + 1 : t - 1;   // the step that produced h_prev in the forward pass
-                    if (tp >= 0 && tp < T)
-                        stage[e] = *reinterpret_cast<const float4*>(y + ((int64_t)tp * rows + row0 + r) * (2 * GH) + dir * GH +
+                    if (tp >= 0 && tp < Tfull)
+                        stage[e] = *reinterpret_cast<const float4*>(y + ((int64_t)tp * rows + rw) * (2 * GH) + dir * GH +
                                                                     4 * (c4 - 5 * GH / 4));
                 }
             }
@@ -852,9 +1082,10 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
             const int c4 = rem - r * OUT4;
             const int sidx = b * TB + sl;
             if (sidx >= T || row0 + r >= rows) continue;
-            const int t = dir ? sidx : T - 1 - sidx;
+            int t;
+            const int rw = step_row(sidx, r, t);
             const float4 v = *reinterpret_cast<const float4*>(&out_s[sl][r][4 * c4]);
-            const int64_t o = ((int64_t)t * rows + row0 + r) * (6 * GH) + dir * 3 * GH;
+            const int64_t o = ((int64_t)t * rows + rw) * (6 * GH) + dir * 3 * GH;
             if (c4 < 3 * GH / 4)
                 *reinterpret_cast<float4*>(dgi + o + 4 * c4) = v;
             else
@@ -869,10 +1100,19 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
     __syncthreads();
 
     int step = 0;
+    uint32_t e_succ = 0;
     for (int b = 0; b < nblocks; ++b) {
         const int buf = b & 1;
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int cur = step & 1;
+            // SEG: sched[T - step] is this step's forward-order successor; if it opened a segment, that segment ended with the
+            // previous backward step
+            bool bnd = false;
+            int prow = 0;
+            if constexpr (SEG) {
+                bnd = step > 0 && ((e_succ >> 16) & 1u);       // (e_succ = sched[T - step], fetched during the previous step)
+                prow = row0 + (int)((e_succ >> 12) & 0xFu);
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 // recurrent contribution from the step processed just before (its dgh sits in dghs[cur^1])
@@ -889,6 +1129,14 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
                 }
                 float rec = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
                 rec += pair_swap(rec);
+                float dh0 = 0.f;
+                if constexpr (SEG) {
+                    // branch-free in the step's body (a branch here splits the block the operand reads are scheduled in); the
+                    // rare store of the finished segment's start-state gradient follows at the end of the step
+                    dh0 = carry[r] + rec;
+                    rec = bnd ? 0.f : rec;
+                    carry[r] = bnd ? 0.f : carry[r];
+                }
                 if (mine[r]) {
                     const float* ip = &in_s[buf][sl][r][u];
                     const float dh = ip[0] + carry[r] + rec;
@@ -911,13 +1159,37 @@ __global__ __launch_bounds__(NT) void gru_seq_bwd_kernel(BwdGroups G) {
                     dghs[cur][r][GH + u] = dzpre;
                     dghs[cur][r][2 * GH + u] = dghn;
                 }
+                if constexpr (SEG) {
+                    if (bnd && mine[r] && dhinit != nullptr && ch.trunc) dhinit[(int64_t)prow * GH + u] = dh0;
+                }
             }
+            if constexpr (SEG) e_succ = sched[T - 1 - step];
             __syncthreads();
         }
         if (b + 1 < nblocks) stash_block(buf ^ 1);
         flush_block(b);
         if (b + 2 < nblocks) load_block(b + 2);
         __syncthreads();
+    }
+    if constexpr (SEG) {
+        if (T > 0 && dhinit != nullptr && ch.trunc) {
+            // the segment the forward pass ran first: its start-state gradient is the recurrent term one more step would use
+            const int cur = T & 1;
+            f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
+            const float4* dv = reinterpret_cast<const float4*>(&dghs[cur ^ 1][0][jbase]);
+#pragma unroll
+            for (int j8 = 0; j8 < JW / 8; ++j8) {
+                const float4 d4 = dv[2 * j8], e4 = dv[2 * j8 + 1];
+                const f32x2 da = {d4.x, d4.y}, db = {d4.z, d4.w}, dc = {e4.x, e4.y}, dd = {e4.z, e4.w};
+                a0 = __builtin_elementwise_fma(w[4 * j8 + 0], da, a0);
+                a1 = __builtin_elementwise_fma(w[4 * j8 + 1], db, a1);
+                a2 = __builtin_elementwise_fma(w[4 * j8 + 2], dc, a2);
+                a3 = __builtin_elementwise_fma(w[4 * j8 + 3], dd, a3);
+            }
+            float rec = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+            rec += pair_swap(rec);
+            if (mine[0]) dhinit[(int64_t)(row0 + (int)((sched[0] >> 12) & 0xFu)) * GH + u] = carry[0] + rec;
+        }
     }
 }
 
@@ -968,11 +1240,27 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     int gidx = 0;
     int dir_ = 0, row_ = 0, T_ = 0;
     Chain ch{};
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j0 = JPW * wv;
+    // W_hh[j0 + jj][u] for the lane's two units u = lane, lane + 64 (< 100 for lane < 36); rows past 3H-1 carry zeros
+    const bool has1 = lane + 64 < GH;
+    f32x2 w[JPW];
+    auto load_weights = [&](const float* __restrict__ wsrc) {
+#pragma unroll
+        for (int jj = 0; jj < JPW; ++jj) {
+            const bool jok = j0 + jj < 3 * GH;
+            const int jc = jok ? j0 + jj : 3 * GH - 1;
+            w[jj][0] = jok ? wsrc[(int64_t)jc * GH + lane] : 0.f;
+            w[jj][1] = (jok && has1) ? wsrc[(int64_t)jc * GH + lane + 64] : 0.f;
+        }
+    };
     if constexpr (SEG) {
-        ch = seg_setup<NTK>(G.seg, G.T, sched, seg_k);
+        ch = seg_decode(G.seg);
         gidx = ch.gidx;
         dir_ = ch.dir;
         row_ = ch.row0;
+        load_weights(G.w_hh[2 * gidx + dir_]);     // in flight while the steps are counted
+        seg_schedule<NTK>(G.seg, G.T, ch, sched, seg_k);
         T_ = ch.S;                                 // the time loop runs over the flattened schedule, backwards
     } else {
         while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
@@ -1003,18 +1291,36 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     float* __restrict__ dgi = G.dgi[gidx];
     float* __restrict__ dgh = G.dgh[gidx];
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int j0 = JPW * wv;
-    // W_hh[j0 + jj][u] for the lane's two units u = lane, lane + 64 (< 100 for lane < 36); rows past 3H-1 carry zeros
-    const bool has1 = lane + 64 < GH;
-    f32x2 w[JPW];
-#pragma unroll
-    for (int jj = 0; jj < JPW; ++jj) {
-        const bool jok = j0 + jj < 3 * GH;
-        const int jc = jok ? j0 + jj : 3 * GH - 1;
-        w[jj][0] = jok ? w_hh[(int64_t)jc * GH + lane] : 0.f;
-        w[jj][1] = (jok && has1) ? w_hh[(int64_t)jc * GH + lane + 64] : 0.f;
+    float* __restrict__ dhinit = SEG ? G.dhinit[gidx] : nullptr;
+    // SEG: step counts / zero start-state gradients of rows without steps, zero dgi / dgh at the positions never visited
+    auto finish_unvisited = [&]() {
+        if (!ch.has_rank) return;
+        int32_t* __restrict__ kout = G.kout[gidx];
+        if (ch.trunc && dhinit != nullptr) {
+            for (int idx = tid; idx < ch.nseg * GH; idx += NTK) {
+                const int p = idx / GH;
+                if (seg_k[p] == 0) dhinit[(int64_t)(row + p) * GH + (idx - p * GH)] = 0.f;
+            }
+        }
+        if (ch.trunc && kout != nullptr && tid < ch.nseg) kout[row + tid] = seg_k[tid];
+        const int per = Tfull * (3 * GH / 4);
+        for (int idx = tid; idx < ch.nseg * per; idx += NTK) {
+            const int p = idx / per;
+            const int rem = idx - p * per;
+            const int t = rem / (3 * GH / 4);
+            const int c4 = rem - t * (3 * GH / 4);
+            if (t < seg_k[p]) continue;
+            const int64_t o = ((int64_t)t * rows + row + p) * (6 * GH) + dir * 3 * GH + 4 * c4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(dgi + o) = z;
+            __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(dgh + o));
+        }
+    };
+    if constexpr (SEG) {
+        finish_unvisited();            // (up front: the stores drain under the prologue and the first steps instead of at the end)
+        if (T == 0) return;            // nothing to run
     }
+    if constexpr (!SEG) load_weights(w_hh);
 #pragma unroll
     for (int jj = 0; jj < JPW; ++jj) pin_loaded(w[jj]);
     // gate stage: lane l handles gate row j0 + l (and j0 + 64 + l when a wave owns more than 64 rows)
@@ -1092,7 +1398,6 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
 
     // the segment of row prow is complete: its gradient wrt the start state is carry + W_hh^T dgh(last step) -- the
     // recurrent term the next step would have used -- written out when wanted; then the recurrence is cut
-    float* __restrict__ dhinit = SEG ? G.dhinit[gidx] : nullptr;
     auto seg_end = [&](int prow) {
         if (dhinit != nullptr && ch.trunc) {
             f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
@@ -1127,16 +1432,29 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     };
 
     int step = 0;
+    int seg_p = 0, bnd = 0x7fffffff;        // SEG: the segment being walked (last first) and the backward step at which it ends
+    if constexpr (SEG) {
+        int q = ch.nseg - 1;
+        while (q >= 0 && seg_k[q] == 0) --q;
+        int q2 = q - 1;
+        while (q2 >= 0 && seg_k[q2] == 0) --q2;
+        seg_p = __builtin_amdgcn_readfirstlane(q < 0 ? 0 : q);
+        bnd = __builtin_amdgcn_readfirstlane(q2 >= 0 ? seg_k[q] : 0x7fffffff);
+    }
     for (int b = 0; b < nblocks; ++b) {
         const int buf = b & 1;
         for (int sl = 0; sl < TB && step < T; ++sl, ++step) {
             const int pb = step & 1;
             if constexpr (SEG) {
-                // sched[T - step] is the forward-order successor of this step: if it opened a segment, the segment finished
-                // with the previous backward step
-                if (step > 0) {
-                    const uint32_t en = sched[T - step];
-                    if ((en >> 16) & 1u) seg_end(row + (int)((en >> 12) & 0xFu));
+                // the segments are walked last to first; seg_p's steps end where bnd says (scalar compare, see SegCursor)
+                if (step == bnd) {
+                    seg_end(row + seg_p);
+                    int q = seg_p - 1;
+                    while (q >= 0 && seg_k[q] == 0) --q;
+                    seg_p = __builtin_amdgcn_readfirstlane(q);
+                    int q2 = q - 1;
+                    while (q2 >= 0 && seg_k[q2] == 0) --q2;
+                    bnd = __builtin_amdgcn_readfirstlane(q2 >= 0 ? bnd + seg_k[q] : 0x7fffffff);
                 }
             }
             // dh_prev partials of units (lane, lane + 64) over this wave's gate rows; dgh[j0 + jj] sits in lane jj % 64 of
@@ -1207,30 +1525,7 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
         __syncthreads();
     }
     if constexpr (SEG) {
-        if (T > 0) seg_end(row + (int)((sched[0] >> 12) & 0xFu));      // the segment the forward pass ran first
-        if (ch.has_rank) {
-            int32_t* __restrict__ kout = G.kout[gidx];
-            if (ch.trunc && dhinit != nullptr) {
-                for (int idx = tid; idx < ch.nseg * GH; idx += NTK) {
-                    const int p = idx / GH;
-                    if (seg_k[p] == 0) dhinit[(int64_t)(row + p) * GH + (idx - p * GH)] = 0.f;
-                }
-            }
-            if (ch.trunc && kout != nullptr && tid < ch.nseg) kout[row + tid] = seg_k[tid];
-            // zero gradients at the positions this chain's rows never visited
-            const int per = Tfull * (3 * GH / 4);
-            for (int idx = tid; idx < ch.nseg * per; idx += NTK) {
-                const int p = idx / per;
-                const int rem = idx - p * per;
-                const int t = rem / (3 * GH / 4);
-                const int c4 = rem - t * (3 * GH / 4);
-                if (t < seg_k[p]) continue;
-                const int64_t o = ((int64_t)t * rows + row + p) * (6 * GH) + dir * 3 * GH + 4 * c4;
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(dgi + o) = z;
-                __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(dgh + o));
-            }
-        }
+        if (T > 0) seg_end(row + seg_p);       // the segment the forward pass ran first
     }
 }
 
@@ -1242,25 +1537,35 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
 //   dyt[t][dir half] = sum over rows with k_row <= t of dy[t][row]     (their output at t is a copy of y_tab[t])
 //                    + sum over rows with k_row == t >= 1 of dhinit[row] (they started from y_tab[t]),   the other half = 0.
 // One workgroup per t, fixed summation order (bit-reproducible).
-__global__ __launch_bounds__(256) void gru_tab_reduce_kernel(const float* __restrict__ dy, const int32_t* __restrict__ kout,
-                                                             const float* __restrict__ dhinit, float* __restrict__ dyt,
-                                                             int rows, int T, int dir) {
-    constexpr int C4 = GH / 4;        // 25 float4 columns, 32 lanes per row group
-    __shared__ float4 red[8][32];
+__global__ __launch_bounds__(1024) void gru_tab_reduce_kernel(const float* __restrict__ dy, const int32_t* __restrict__ kout,
+                                                              const float* __restrict__ dhinit, float* __restrict__ dyt,
+                                                              int rows, int T, int dir) {
+    constexpr int C4 = GH / 4;        // 25 float4 columns on 32 lanes, 32 row groups
+    constexpr int RG = 32;
+    __shared__ float4 red[RG][32];
     const int t = blockIdx.x;
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int cc = c4 < C4 ? c4 : C4 - 1;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c4 < C4) {
-        for (int r = rg; r < rows; r += 8) {
-            const int k = kout[r];
-            if (k <= t) {
-                const float4 v = *reinterpret_cast<const float4*>(dy + ((int64_t)t * rows + r) * (2 * GH) + dir * GH + 4 * c4);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-            if (k == t && k >= 1) {
-                const float4 v = *reinterpret_cast<const float4*>(dhinit + (int64_t)r * GH + 4 * c4);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
+    // eight rows per trip, every load issued before the first use (the row count per thread is what bounds this kernel)
+    for (int r0 = rg; r0 < rows; r0 += 8 * RG) {
+        float4 v[8], h[8];
+        float m[8], mh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = r0 + e * RG;
+            const int rc = r < rows ? r : rows - 1;
+            const int k = kout[rc];
+            m[e] = (r < rows && k <= t) ? 1.f : 0.f;
+            mh[e] = (r < rows && k == t && k >= 1) ? 1.f : 0.f;
+            v[e] = *reinterpret_cast<const float4*>(dy + ((int64_t)t * rows + rc) * (2 * GH) + dir * GH + 4 * cc);
+            h[e] = *reinterpret_cast<const float4*>(dhinit + (int64_t)rc * GH + 4 * cc);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // (select, not multiply: a row the sum excludes may hold anything)
+            if (m[e] != 0.f) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
+            if (mh[e] != 0.f) { acc.x += h[e].x; acc.y += h[e].y; acc.z += h[e].z; acc.w += h[e].w; }
         }
     }
     red[rg][c4] = acc;
@@ -1268,7 +1573,7 @@ __global__ __launch_bounds__(256) void gru_tab_reduce_kernel(const float* __rest
     if (rg == 0 && c4 < C4) {
         float4 a = red[0][c4];
 #pragma unroll
-        for (int g = 1; g < 8; ++g) {
+        for (int g = 1; g < RG; ++g) {
             const float4 v = red[g][c4];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
@@ -1386,9 +1691,9 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
 #endif
     if (io_wave && scalar_fma) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<1, 0, 0>), grid, dim3(320), 0, s, G);
     else if (io_wave) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0, 0>), grid, dim3(320), 0, s, G);
-    else if (R == 1) hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, block, 0, s, G);
-    else if (R == 2) hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, grid, block, 0, s, G);
-    else hipLaunchKernelGGL(gru_seq_fwd_kernel<4>, grid, block, 0, s, G);
+    else if (R == 1) hipLaunchKernelGGL((gru_seq_fwd_kernel<1, 0>), grid, block, 0, s, G);
+    else if (R == 2) hipLaunchKernelGGL((gru_seq_fwd_kernel<2, 0>), grid, block, 0, s, G);
+    else hipLaunchKernelGGL((gru_seq_fwd_kernel<4, 0>), grid, block, 0, s, G);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -1414,9 +1719,9 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     // (the 8-wave kernel runs one workgroup per CU: it wins while all sequences fit in one round; beyond that the lane-pair
     // kernel, two workgroups per CU, keeps the batch in one round -- cfg4: 320 workgroups, 1.75 vs 1.69 ms per step)
     if (R == 1 && (2 * sl <= 256 || kpart_any_size()) && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 0>), grid, dim3(512), 0, s, G);
-    else if (R == 1) hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, grid, block, 0, s, G);
-    else if (R == 2) hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, grid, block, 0, s, G);
-    else hipLaunchKernelGGL(gru_seq_bwd_kernel<4>, grid, block, 0, s, G);
+    else if (R == 1) hipLaunchKernelGGL((gru_seq_bwd_kernel<1, 0>), grid, block, 0, s, G);
+    else if (R == 2) hipLaunchKernelGGL((gru_seq_bwd_kernel<2, 0>), grid, block, 0, s, G);
+    else hipLaunchKernelGGL((gru_seq_bwd_kernel<4, 0>), grid, block, 0, s, G);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -1440,7 +1745,21 @@ extern "C" int mmdfn_gru_seq_fwd_seg(int ngroups, const float* const* gi, const 
     }
     const int nchains = seg_slots(G.seg, ngroups, rows, T, rank, P, BP, tdir);
     if (nchains <= 0) return -1;
-    hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0, 1>), dim3(nchains), dim3(320), 0, (hipStream_t)stream, G);
+    // one chain per CU: the 5-wave kernel (one workgroup per CU); more chains: the 4-wave kernel, two workgroups per CU
+    bool io_wave = nchains <= 256;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_IO")) io_wave = e[0] != '0';      // A/B aid
+#endif
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_ABL")) {         // timing ablations of the segmented bookkeeping (wrong results)
+        const int a = atoi(e);
+#define GRU_SEG_ABL(A) if (io_wave && a == A) { hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, A, 1>), dim3(nchains), dim3(320), 0, (hipStream_t)stream, G); MMDFN_CHECK_LAUNCH(); return 0; }
+        GRU_SEG_ABL(32)
+#undef GRU_SEG_ABL
+    }
+#endif
+    if (io_wave) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0, 1>), dim3(nchains), dim3(320), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL((gru_seq_fwd_kernel<1, 1>), dim3(nchains), dim3(NT), 0, (hipStream_t)stream, G);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -1465,7 +1784,12 @@ extern "C" int mmdfn_gru_seq_bwd_seg(int ngroups, const float* const* dy, const 
     }
     const int nchains = seg_slots(G.seg, ngroups, rows, T, rank, P, BP, tdir);
     if (nchains <= 0) return -1;
-    hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 1>), dim3(nchains), dim3(512), 0, (hipStream_t)stream, G);
+    bool kpart = nchains <= 256;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_KPART_BWD")) kpart = e[0] != '0';      // A/B aid
+#endif
+    if (kpart) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 1>), dim3(nchains), dim3(512), 0, (hipStream_t)stream, G);
+    else hipLaunchKernelGGL((gru_seq_bwd_kernel<1, 1>), dim3(nchains), dim3(NT), 0, (hipStream_t)stream, G);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
@@ -1473,7 +1797,7 @@ extern "C" int mmdfn_gru_seq_bwd_seg(int ngroups, const float* const* dy, const 
 extern "C" int mmdfn_gru_tab_reduce(const float* dy, const int32_t* kout, const float* dhinit, float* dyt, int rows, int T,
                                     int H, int dir, void* stream) {
     if (H != GH || rows <= 0 || T <= 0 || dir < 0 || dir > 1) return -1;
-    hipLaunchKernelGGL(gru_tab_reduce_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, dy, kout, dhinit, dyt, rows, T, dir);
+    hipLaunchKernelGGL(gru_tab_reduce_kernel, dim3(T), dim3(1024), 0, (hipStream_t)stream, dy, kout, dhinit, dyt, rows, T, dir);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

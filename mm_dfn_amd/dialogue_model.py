@@ -168,11 +168,18 @@ class DialogueGNNModel(nn.Module):
         table = None
         n_act = sum(1 for w in self.speaker_weights if w != 0.0)
         L_, B_, P_ = U.shape[0], U.shape[1], qmask.shape[2]
-        if (self.use_crn_speaker and n_act and P_ <= 16 and P_ * L_ <= 2048
-                and fused_gru.wants_truncation(B_ + n_act * B_ * P_)):
-            table = fused_gru.start_party_table(self.rnn_parties, L_)
+        truncate = (self.use_crn_speaker and n_act and P_ <= 16 and P_ * L_ <= 2048
+                    and fused_gru.wants_truncation(B_ + n_act * B_ * P_))
+        use_table = truncate and fused_gru.USE_TABLE
+        if use_table:
+            fork = torch.cuda.Event()
+            fork.record()
         Xa, Xv, Xl = ops.linear_group([U_a, U_v, U], [self.linear_a.weight, self.linear_v.weight, self.linear_l.weight],
                                       [self.linear_a.bias, self.linear_v.bias, self.linear_l.bias])
+        if use_table:
+            # (launched behind the projections in program order, so the main stream's first kernel is not held up by the
+            # side branch's launches; ordered behind the point BEFORE them)
+            table = fused_gru.start_party_table(self.rnn_parties, L_, after=fork)
         L, B, H = Xa.shape
         idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
         if self.use_crn_speaker:
@@ -195,7 +202,7 @@ class DialogueGNNModel(nn.Module):
                 passed = iter(passed)
                 Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
                 ctx, E = fused_gru.bigru2([Xl_, None], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
-                                          gi0=[None, gi_p], party=None if table is None else (1, rank, table))
+                                          gi0=[None, gi_p], party=(1, rank, table) if truncate else None)
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
             if act:
                 # the gathered modalities come back as identities (passthrough): the combine stage below reads those, so
@@ -204,7 +211,7 @@ class DialogueGNNModel(nn.Module):
                 passed = iter(passed)
                 Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
                 ctx, E = fused_gru.bigru2([Xl_, S], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
-                                          party=None if table is None else (1, rank, table))
+                                          party=(1, rank, table) if truncate else None)
                 return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
         ctx = self._run_grus([Xl], [self.lstm_l])[0]
         rank = torch.full((L, B, qmask.shape[2]), -1, dtype=torch.int32, device=Xa.device)

@@ -17,8 +17,18 @@ H = 100
 # mmdfn_gru_seq_fwd_seg): "auto" uses the segmented launches when the plain form would need more workgroups than the chip
 # has CUs (every sequence-direction is one persistent workgroup; with a CU per chain the launch lasts as long as its longest
 # chain whatever the others do, so truncation buys nothing below that), True / False force it (tests, A/B runs).
-TRUNCATE = "auto"
+TRUNCATE = {"0": False, "1": True}.get(__import__("os").environ.get("MMDFN_GRU_TRUNCATE", "auto"), "auto")
 CUS = 256
+# Layer 1's reverse direction can be truncated as well, against the all-padding sequence (start_party_table: one more
+# workgroup chain per step on a side stream).  Inside a captured step every fork / join of the side branch costs ~10 us of
+# the main chain (measured, profiles/r05_gru_valid_length.md), which is what the shorter layer-1 launch saves at the
+# BASELINE batch sizes: off unless asked for (MMDFN_GRU_TABLE=1, or gru.USE_TABLE = True).
+USE_TABLE = __import__("os").environ.get("MMDFN_GRU_TABLE", "0") == "1"
+# Without the table layer 1 can still run on the segmented kernels just to skip the silent rows (k = 0), at the price of their
+# bookkeeping on every other row: with a quarter of the rows silent (synthetic cfg3) that is a loss (1.252 vs 1.225 ms per step),
+# so layer 1 stays on the plain launch by default; corpora whose dialogues involve few of many speakers (MELD: 2-3 of 9)
+# are the case for MMDFN_GRU_L1_SEG=1.
+L1_SKIPS_SILENT = __import__("os").environ.get("MMDFN_GRU_L1_SEG", "0") == "1"
 
 
 def wants_truncation(n_rows_total):
@@ -85,7 +95,6 @@ class _GruRecurrence(torch.autograd.Function):
         ctx.n = n
         ctx.seg = seg
         ctx.has_tab = ytab is not None
-        ctx.on_side = _SIDE["active"]
         ctx.refs = [args[5 * g + 1 + k] for g in range(n) for k in range(4)]   # the parameter objects (leaf test)
         ctx.save_for_backward(*ys, *gates, *whh)
         return tuple(ys)
@@ -147,10 +156,6 @@ class _GruRecurrence(torch.autograd.Function):
                     ops.gemm_tn_grouped([dict(A=A, B=B, C=dw, colsum=db, shift=shift)])
                     res.append((dw, db))
             out += [dgi[g], res[0][0], res[1][0], res[0][1], res[1][1]]
-        if ctx.on_side:
-            # this node ran on the side stream (the all-padding sequence): the weight-gradient batch, issued on the stream
-            # that runs backward, waits for what was queued here
-            ops.note_side_work()
         return (None, dyt) + tuple(out)
 
 
@@ -166,11 +171,20 @@ _SIDE = {"stream": None, "active": False}
 
 
 class _SideStream:
+    """Fork: the side stream continues from ``after`` (an event recorded on the caller's stream; default: from everything
+    the caller's stream has been given so far)."""
+
+    def __init__(self, after=None):
+        self.after = after
+
     def __enter__(self):
         if _SIDE["stream"] is None:
             _SIDE["stream"] = torch.cuda.Stream()
         self.side = _SIDE["stream"]
-        self.side.wait_stream(torch.cuda.current_stream())
+        if self.after is not None:
+            self.side.wait_event(self.after)
+        else:
+            self.side.wait_stream(torch.cuda.current_stream())
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         _SIDE["active"] = True
@@ -179,6 +193,57 @@ class _SideStream:
     def __exit__(self, *exc):
         _SIDE["active"] = False
         return self.ctx.__exit__(*exc)
+
+
+class _GruTable(torch.autograd.Function):
+    """(T, b_ih_fwd, b_ih_rev, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev) -> y_tab (T, 1, 2H): the all-padding sequence of the
+    layer these parameters belong to, on the plain one-row kernels.  Runs on whatever stream is current (start_party_table:
+    the side stream; autograd then runs the backward there too).  Only the reverse direction's states are ever read, so
+    only its parameters receive gradients -- W_hh_rev, b_hh_rev and b_ih_rev -- and they do not travel through autograd:
+    they are small in-line contractions here, handed to ops.add_grad_addends, which adds them to ``.grad`` at the end of the
+    backward pass (the step's weight-gradient batch does not wait for this one-workgroup chain)."""
+
+    @staticmethod
+    def forward(ctx, T, params, bif, bir, wf, wr, bf, br):
+        _hip.require_cuda(bif, bir, wf, wr, bf, br)
+        bcat = _stacked_view(bif, bir) if not torch.cuda.is_current_stream_capturing() or _adjacent(bif, bir) else None
+        src = bcat if bcat is not None else torch.cat([bif.detach(), bir.detach()])
+        gi = src.expand(T, 1, 6 * H).contiguous()
+        whh = [wf.detach().contiguous(), wr.detach().contiguous()]
+        bhh = [bf.detach().contiguous(), br.detach().contiguous()]
+        y = torch.empty(T, 1, 2 * H, dtype=torch.float32, device=gi.device)
+        gates = torch.empty(T, 1, 2, 4, H, dtype=torch.float32, device=gi.device)
+        rc = _hip.lib().mmdfn_gru_seq_fwd(1, _hip.ptr_array([gi]), _hip.ptr_array(whh), _hip.ptr_array(bhh),
+                                          _hip.ptr_array([y]), _hip.ptr_array([gates]), _hip.int_array([1]),
+                                          _hip.int_array([T]), H, _hip.stream())
+        _hip.check(rc, "mmdfn_gru_seq_fwd")
+        ctx.T = T
+        ctx.params = params            # (b_ih_rev, w_hh_rev, b_hh_rev): the parameter objects themselves
+        ctx.save_for_backward(y, gates, *whh)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, gates, wf, wr = ctx.saved_tensors
+        T = ctx.T
+        dy = dy.contiguous()
+        dgi = torch.empty(T, 1, 6 * H, dtype=torch.float32, device=y.device)
+        dgh = torch.empty_like(dgi)
+        rc = _hip.lib().mmdfn_gru_seq_bwd(1, _hip.ptr_array([dy]), _hip.ptr_array([y]), _hip.ptr_array([gates]),
+                                          _hip.ptr_array([wf, wr]), _hip.ptr_array([dgi]), _hip.ptr_array([dgh]),
+                                          _hip.int_array([1]), _hip.int_array([T]), H, _hip.stream())
+        _hip.check(rc, "mmdfn_gru_seq_bwd")
+        bir, w, b = ctx.params
+        d2, g2, y2 = dgh.view(T, 6 * H)[:, 3 * H:], dgi.view(T, 6 * H)[:, 3 * H:], y.view(T, 2 * H)[:, H:]
+        dw = torch.empty(3 * H, H, dtype=torch.float32, device=y.device)
+        scratch = torch.empty_like(dw)
+        dbh = torch.empty(3 * H, dtype=torch.float32, device=y.device)
+        dbi = torch.empty_like(dbh)
+        # dW_hh = sum_t dgh_t (x) y[t+1] (reverse direction: h_{t-1} of step t is the output at t+1), db_hh / db_ih = the column
+        # sums of dgh / dgi (the second problem's product is scratch: only its column sum is wanted)
+        ops.gemm_tn_grouped([dict(A=d2, B=y2, C=dw, colsum=dbh, shift=1), dict(A=g2, B=y2, C=scratch, colsum=dbi, shift=1)])
+        ops.add_grad_addends([(w, dw), (b, dbh), (bir, dbi)])
+        return (None,) * 8
 
 
 class PartyTable:
@@ -195,15 +260,20 @@ class PartyTable:
         return self.y
 
 
-def start_party_table(gru, T):
-    """Launch the all-padding sequence of ``gru``'s first layer (T steps) on the side stream; returns a PartyTable."""
+def start_party_table(gru, T, after=None):
+    """Launch the all-padding sequence of ``gru``'s first layer (T steps) on the side stream, which continues from ``after``
+    (an event on the caller's stream; default: from the work given to it so far); returns a PartyTable."""
     _, b_ih, hh = _layer_params(gru, 0)
-    # aliases made on the caller's stream: the bias gradients that come back from the side stream are then handed to
-    # autograd nodes of the caller's stream (autograd orders the two streams where a gradient crosses)
-    bf, br = b_ih[0].view_as(b_ih[0]), b_ih[1].view_as(b_ih[1])
-    with _SideStream() as side:
-        gi = torch.cat([bf, br]).expand(T, 1, 6 * H).contiguous()
-        y = _GruRecurrence.apply(None, None, gi, *hh)[0]
+    for prm in (b_ih[1], hh[1], hh[3]):
+        if prm.requires_grad and not prm.is_leaf:
+            raise NotImplementedError("the valid-length party launches write the all-padding sequence's gradients into .grad: "
+                                      "leaf parameters only")
+    # the node's tensor inputs are aliases made on the CALLER's stream: autograd creates a parameter's gradient accumulator
+    # where the parameter is first used and runs it on the stream that was current there -- made under the side stream, the
+    # accumulators of these six parameters would run on it, and the end of every backward pass would wait for the side stream
+    alias = [prm.view_as(prm) for prm in (b_ih[0], b_ih[1], *hh)]
+    with _SideStream(after) as side:
+        y = _GruTable.apply(T, (b_ih[1], hh[1], hh[3]), *alias)
         ev = torch.cuda.Event()
         ev.record(side)
     return PartyTable(y, ev)
@@ -265,8 +335,9 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
     gi0[g] (optional): the first layer's gate pre-activations X W_ih^T + b_ih (T, rows_g, 600) computed by the caller
     (the party encoder projects the L*B utterances once and gathers the result instead of projecting the L*P*B
     party rows); xs[g] is then ignored.
-    party = (group index, rank (L, B, P) int32, PartyTable): run that group with the valid-length launches (layer 1: reverse
-    direction truncated against the all-padding sequence; layer 2: forward direction truncated; silent rows skipped)."""
+    party = (group index, rank (L, B, P) int32, PartyTable or None): run that group with the valid-length launches (layer 1:
+    reverse direction truncated against the all-padding sequence when one is given; layer 2: forward direction truncated;
+    silent rows skipped)."""
     for gru in grus:
         if gru.hidden_size != H or gru.num_layers != 2 or not gru.bidirectional or gru.batch_first:
             raise NotImplementedError("fused GRU path supports nn.GRU(*, 100, num_layers=2, bidirectional=True)")
@@ -305,6 +376,11 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
             args += [gi] + p[2]
         if party is None:
             cur = list(_GruRecurrence.apply(None, None, *args))
+        elif layer == 0 and party[2] is None and not L1_SKIPS_SILENT:
+            cur = list(_GruRecurrence.apply(None, None, *args))
+        elif layer == 0 and party[2] is None:
+            # no all-padding sequence at hand: layer 1 runs both directions at full length, silent rows are skipped
+            cur = list(_GruRecurrence.apply(_Seg(party[0], party[1], -1), None, *args))
         elif layer == 0:
             cur = list(_GruRecurrence.apply(_Seg(party[0], party[1], 1), party[2].join(), *args))
         else:

@@ -972,31 +972,50 @@ def flush_queued_wgrads_early():
     _flush_outs(outs, _WGQ["side"])
 
 
-_SIDE_EVENTS = []
+_GRAD_ADDENDS = []      # (parameter, tensor, event recorded on the producing stream)
 
 
-def note_side_work():
-    """A backward node that ran on another stream (gru.start_party_table's sequence) has queued weight-gradient segments
-    or produced their operands there: the flush, on the stream that runs backward, waits for the event recorded here."""
+def add_grad_addends(pairs):
+    """``p.grad += t`` for every (p, t) at the END of the running backward pass, on the stream that runs it, behind an
+    event recorded now on the CURRENT stream (the producer: gru._GruTable's backward on the side stream).  For small
+    gradient pieces computed off the main stream that neither autograd nor the weight-gradient batch should wait for."""
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
-    _SIDE_EVENTS.append(ev)
-    if _WGQ["scope"] > 0 and not _WGQ["armed"]:
-        _WGQ["armed"] = True
-        torch.autograd.Variable._execution_engine.queue_callback(flush_queued_wgrads)
+    first = not _GRAD_ADDENDS
+    for prm, t in pairs:
+        if prm.requires_grad:
+            _GRAD_ADDENDS.append((prm, t, ev))
+    if first and _GRAD_ADDENDS:
+        torch.autograd.Variable._execution_engine.queue_callback(apply_grad_addends)
 
 
-def _wait_side_events():
+def apply_grad_addends():
+    if not _GRAD_ADDENDS:
+        return
+    items = list(_GRAD_ADDENDS)
+    del _GRAD_ADDENDS[:]
     cur = torch.cuda.current_stream()
-    while _SIDE_EVENTS:
-        cur.wait_event(_SIDE_EVENTS.pop())
+    seen = set()
+    for _, t, ev in items:
+        if id(ev) not in seen:
+            seen.add(id(ev))
+            cur.wait_event(ev)
+        t.record_stream(cur)
+    dst, src = [], []
+    for prm, t, _ in items:
+        if prm.grad is None:
+            prm.grad = t if tuple(t.shape) == tuple(prm.shape) else t.view(prm.shape).clone()
+        else:
+            dst.append(prm.grad)
+            src.append(t.view(prm.grad.shape))
+    if dst:
+        torch._foreach_add_(dst, src)
 
 
 def flush_queued_wgrads():
     """Issue every queued weight-gradient contraction (one launch pair per <= 40 segments) into the .grad fields."""
     outs = list(_WGQ["outs"].values())
     _WGQ["outs"], _WGQ["armed"] = {}, False
-    _wait_side_events()
     _join_side()             # first: a parameter may collect contributions from both batches (the later one accumulates)
     if outs:
         _flush_outs(outs, None)

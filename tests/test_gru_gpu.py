@@ -345,7 +345,7 @@ def _party_case(L, lengths, P, seed, silent=None, solo=None):
     return torch.from_numpy(q)
 
 
-def _run_party(mode, L, lengths, P, seed, qmask, dropout=0.0, batch=True, n_mod=2):
+def _run_party(mode, L, lengths, P, seed, qmask, dropout=0.0, batch=True, n_mod=2, table=True, l1seg=True):
     """ctx + party encoders through bigru2 with / without the valid-length launches; loss reads only what the model reads:
     the scattered rows [:k_bp] of the party output and the context rows of real utterances."""
     from mm_dfn_amd import ops
@@ -357,13 +357,13 @@ def _run_party(mode, L, lengths, P, seed, qmask, dropout=0.0, batch=True, n_mod=
     Xs = [torch.from_numpy(rs.randn(L, B, 200).astype(np.float32)).to(DEV).requires_grad_(True) for _ in range(n_mod)]
     Xc = torch.from_numpy(rs.randn(L, B, 200).astype(np.float32)).to(DEV).requires_grad_(True)
     q = qmask.to(DEV)
-    prev = fused.TRUNCATE
-    fused.TRUNCATE = mode
+    prev, prev_l1 = fused.TRUNCATE, fused.L1_SKIPS_SILENT
+    fused.TRUNCATE, fused.L1_SKIPS_SILENT = mode, l1seg
     try:
-        table = fused.start_party_table(g_par, L) if mode else None
+        tab = fused.start_party_table(g_par, L) if (mode and table) else None
         S, rank = ops.party_gather(Xs, q)
-        with ops.flag_pool(("t", seed)):
-            ctx, E = fused.bigru2([Xc, S], [g_ctx, g_par], dropout, True, party=None if table is None else (1, rank, table))
+        with ops.flag_pool(("t", seed, bool(mode))):
+            ctx, E = fused.bigru2([Xc, S], [g_ctx, g_par], dropout, True, party=(1, rank, tab) if mode else None)
         # weights: zero where the model never looks (t >= k of a party row)
         k = (rank.max(0).values + 1).to(torch.int64)                     # (B, P)
         kk = k.reshape(1, B * P).repeat(1, n_mod)                        # rows (m, b, p)
@@ -376,12 +376,13 @@ def _run_party(mode, L, lengths, P, seed, qmask, dropout=0.0, batch=True, n_mod=
         else:
             loss.backward()
     finally:
-        fused.TRUNCATE = prev
+        fused.TRUNCATE, fused.L1_SKIPS_SILENT = prev, prev_l1
     torch.cuda.synchronize()
     grads = {("ctx." if g is g_ctx else "par.") + n: p.grad.clone() for g in (g_ctx, g_par) for n, p in g.named_parameters()}
     return dict(E=E.detach() * live, ctx=ctx.detach(), dX=[x.grad.clone() for x in Xs], dXc=Xc.grad.clone(), grads=grads)
 
 
+@pytest.mark.parametrize("table", ["table", "l1seg", "l1plain"])
 @pytest.mark.parametrize("batch", [True, False])
 @pytest.mark.parametrize("L,lengths,P,kw", [
     (15, [15, 9, 1], 3, {}),                       # the goldens' (L, B, P) sets
@@ -390,14 +391,14 @@ def _run_party(mode, L, lengths, P, seed, qmask, dropout=0.0, batch=True, n_mod=
     (24, [24, 24, 11, 5, 17], 4, dict(silent=(1, 2), solo=0)),       # a silent speaker; one speaker holding a whole dialogue (k = L)
     (12, [12] * 40, 2, {}),                        # more chains than CUs in the plain form
 ])
-def test_valid_length_launches_match_full_length(L, lengths, P, kw, batch):
+def test_valid_length_launches_match_full_length(L, lengths, P, kw, batch, table):
     """Layer 1 reverse truncated against the all-padding sequence, layer 2 forward truncated, silent rows skipped, the P
     sequences of a (modality, dialogue) back to back in one workgroup: the scattered rows and the context are BIT-equal to
     the full-length launches, every gradient agrees to summation-order noise (the padding steps' contributions to the
     recurrent weights and biases arrive through the one all-padding sequence instead of once per row)."""
     q = _party_case(L, lengths, P, 7 + L, **kw)
     full = _run_party(False, L, lengths, P, 11, q, batch=batch)
-    seg = _run_party(True, L, lengths, P, 11, q, batch=batch)
+    seg = _run_party(True, L, lengths, P, 11, q, batch=batch, table=table == "table", l1seg=table != "l1plain")
     assert torch.equal(seg["ctx"], full["ctx"])
     assert torch.equal(seg["E"], full["E"])
     assert float(full["E"].abs().max()) > 0
@@ -414,5 +415,28 @@ def test_valid_length_launches_with_interlayer_dropout():
     full = _run_party(False, L, lengths, P, 5, q, dropout=0.5)
     seg = _run_party(True, L, lengths, P, 5, q, dropout=0.5)
     assert torch.equal(seg["E"], full["E"]) and torch.equal(seg["ctx"], full["ctx"])
+    for k in full["grads"]:
+        assert rel_err(seg["grads"][k], full["grads"][k]) < 5e-5, k
+
+
+@pytest.mark.parametrize("L,lengths,P,kw", [
+    (15, [15, 9, 1], 3, {}),
+    (33, [33, 20, 7, 3], 9, {}),
+    (24, [24, 24, 11, 5, 17], 4, dict(silent=(1, 2), solo=0)),
+])
+@pytest.mark.parametrize("io,kpart", [("0", "0"), ("1", "1")])
+def test_valid_length_launches_on_both_kernel_families(L, lengths, P, kw, io, kpart, kernel_variants):
+    """The segmented launch picks the 5-wave / wave-partitioned kernels up to one chain per CU and the 4-wave lane-pair
+    kernels beyond; both families are forced here on the same small cases."""
+    kernel_variants.setenv("MMDFN_GRU_IO", io)
+    kernel_variants.setenv("MMDFN_GRU_KPART_BWD", kpart)
+    q = _party_case(L, lengths, P, 7 + L, **kw)
+    seg = _run_party(True, L, lengths, P, 11, q)
+    kernel_variants.delenv("MMDFN_GRU_IO")
+    kernel_variants.delenv("MMDFN_GRU_KPART_BWD")
+    full = _run_party(False, L, lengths, P, 11, q)
+    assert torch.equal(seg["ctx"], full["ctx"]) and torch.equal(seg["E"], full["E"])
+    for a, b in zip(seg["dX"] + [seg["dXc"]], full["dX"] + [full["dXc"]]):
+        assert rel_err(a, b) < 2e-5
     for k in full["grads"]:
         assert rel_err(seg["grads"][k], full["grads"][k]) < 5e-5, k

@@ -56,8 +56,9 @@ def test_end_to_end_against_reference_golden(name):
         assert np.abs(grads[k].cpu().numpy() - want).max() / np.abs(want).max() < 2e-4, k
 
 
+@pytest.mark.parametrize("table", ["l1plain", "l1seg", "table"])
 @pytest.mark.parametrize("name", sorted(E2E))
-def test_end_to_end_golden_with_valid_length_party_launches(name):
+def test_end_to_end_golden_with_valid_length_party_launches(name, table):
     """The same reference goldens with the party encoder on the valid-length launches (gru.TRUNCATE forced on: at these batch
     sizes "auto" keeps the full-length form): log-probabilities, loss and every gradient digest, through the queued
     weight-gradient batch (the all-padding sequence's segments are queued from the side stream)."""
@@ -66,6 +67,8 @@ def test_end_to_end_golden_with_valid_length_party_launches(name):
     g = load("e2e_%s.npz" % name)
     b = synthetic.make_batch(seed + 1, lengths=lengths, **cfg)
     prev, fused.TRUNCATE = fused.TRUNCATE, True
+    prev_tab, fused.USE_TABLE = fused.USE_TABLE, table == "table"
+    prev_l1, fused.L1_SKIPS_SILENT = fused.L1_SKIPS_SILENT, table != "l1plain"
     try:
         m = hip_model(cfg, seed).eval()
         with torch.no_grad():
@@ -78,7 +81,7 @@ def test_end_to_end_golden_with_valid_length_party_launches(name):
         assert abs(loss.item() - float(g["loss"])) < 1e-5
         train.backward(loss)
     finally:
-        fused.TRUNCATE = prev
+        fused.TRUNCATE, fused.USE_TABLE, fused.L1_SKIPS_SILENT = prev, prev_tab, prev_l1
     grads = {k: p.grad for k, p in m.named_parameters()}
     for k in [str(x) for x in g["live_params"]]:
         want = g["gd/" + k]
