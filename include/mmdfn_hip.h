@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce). */
+/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, and the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -356,6 +356,12 @@ int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const float* dh0, c
 int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
                         const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
                         void* stream);
+/* the same with a row stride ldh (floats, >= H, % 4 == 0) on BOTH h and h_out: the layers' hidden states live as column blocks of
+ * one (R, nl H) buffer, which is then the Y operand of ONE mmdfn_tile_outer(d = nl H) for the whole stack (model_GCN.py:461-472
+ * shares `adj` across the layers: dA = sum_l dhi_l zin_l^T is one contraction of width nl H) */
+int mmdfn_lstm_gate_fwd_ld(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                           const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                           int ldh, void* stream);
 int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh_a, const float* dh_b,
                         const float* dc_next, const float* Wih, const float* Whh, const float* dres, float* dG,
                         float* dc_prev, float* dq, float* dh_prev, int R, int H, int has_h, int lddres, void* stream);
@@ -363,6 +369,9 @@ int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const float* W, cons
                           float* gmask, float theta, float alpha, int R, int H, int ldo, float mscale, void* stream);
 int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
                           float theta, float alpha, int R, int H, int lddo, int acc_h0, void* stream);
+/* the same with a row stride lddhi on dhi (the X operand of the stack's single mmdfn_tile_outer, see mmdfn_lstm_gate_fwd_ld) */
+int mmdfn_gcnii_layer_bwd_ld(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
+                             float theta, float alpha, int R, int H, int lddo, int acc_h0, int lddhi, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Batch form: EVERY weight-gradient contraction of a training step in one launch pair (they feed nothing but the

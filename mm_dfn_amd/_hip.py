@@ -34,9 +34,11 @@ SIGNATURES = {
     "mmdfn_gcn_input_fwd": [_P] * 8 + [_I] * 4 + [_F, _P],
     "mmdfn_gcn_input_bwd": [_P] * 9 + [_I] * 4 + [_F, _P],
     "mmdfn_lstm_gate_fwd": [_P] * 10 + [_I] * 2 + [_P],
+    "mmdfn_lstm_gate_fwd_ld": [_P] * 10 + [_I] * 3 + [_P],
     "mmdfn_lstm_gate_bwd": [_P] * 13 + [_I] * 4 + [_P],
     "mmdfn_gcnii_layer_fwd": [_P] * 7 + [_F, _F, _I, _I, _I, _F, _P],
     "mmdfn_gcnii_layer_bwd": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _P],
+    "mmdfn_gcnii_layer_bwd_ld": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear_group_supported": [_I, _I, _I],

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gmask,
                                                               const float* __restrict__ W, float* __restrict__ dP,
                                                               float* __restrict__ dhi, float* __restrict__ dh0,
-                                                              float theta, float alpha, int R, int H, int lddo, int acc_h0) {
+                                                              float theta, float alpha, int R, int H, int lddo, int acc_h0, int lddhi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N = 2 * H;
     const int ldw = lds_stride(H), ldp = ((N + 15) & ~15) + 4;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
             const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
             if (i >= RB * H4 || row >= R) continue;
             const float4 dp = ld4(A + r * ldw + n);
-            st4(dhi + (int64_t)row * H + n, fma4(dp, c1, ld4(sP + r * ldp + n)));
+            st4(dhi + (int64_t)row * lddhi + n, fma4(dp, c1, ld4(sP + r * ldp + n)));
             st4(dh0 + (int64_t)row * H + n, add4(fma4(dp, c2, ld4(sP + r * ldp + H + n)), eo[s]));
         }
         if (nxt < nrb) park(nxt, sA + (buf ^ 1) * RB * ldw);
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
                                                             const float* __restrict__ c, const float* __restrict__ Wih,
                                                             const float* __restrict__ Whh, const float* __restrict__ bsum, const float* __restrict__ bsum2,
                                                             float* __restrict__ gates, float* __restrict__ h_out,
-                                                            float* __restrict__ c_out, int R, int H) {
+                                                            float* __restrict__ c_out, int R, int H, int ldh) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = h ? 2 * H : H;
     const int ldw = lds_stride(K), lde = UB + 4;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
             const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             rq[s] = ok ? ld4(q + (int64_t)row * H + k) : zero4();
-            rh[s] = (ok && h) ? ld4(h + (int64_t)row * H + k) : zero4();
+            rh[s] = (ok && h) ? ld4(h + (int64_t)row * ldh + k) : zero4();
         }
     };
     auto park = [&](float* dst) {
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
             *reinterpret_cast<float2*>(gr) = gi; *reinterpret_cast<float2*>(gr + H) = gf;
             *reinterpret_cast<float2*>(gr + 2 * H) = gg; *reinterpret_cast<float2*>(gr + 3 * H) = go;
             *reinterpret_cast<float2*>(c_out + (int64_t)erow * H + u0 + eu) = cn;
-            *reinterpret_cast<float2*>(h_out + (int64_t)erow * H + u0 + eu) = hn;
+            *reinterpret_cast<float2*>(h_out + (int64_t)erow * ldh + u0 + eu) = hn;
         }
         if (nxt < nrb) park(sA + (buf ^ 1) * RB * ldw);
         __syncthreads();
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
                                                                const float* __restrict__ c, const float* __restrict__ Wih,
                                                                const float* __restrict__ Whh, const float* __restrict__ bsum, const float* __restrict__ bsum2,
                                                                float* __restrict__ gates, float* __restrict__ h_out,
-                                                               float* __restrict__ c_out, int R, int H) {
+                                                               float* __restrict__ c_out, int R, int H, int ldh) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = h ? 2 * H : H;
     const int ldw = lds_stride(K), lde = UB + 4;
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
             const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             rq[s] = ok ? ld4(q + (int64_t)row * H + k) : zero4();
-            rh[s] = (ok && h) ? ld4(h + (int64_t)row * H + k) : zero4();
+            rh[s] = (ok && h) ? ld4(h + (int64_t)row * ldh + k) : zero4();
         }
     };
     auto park = [&](float* dst) {
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
         float* gr = gates + (int64_t)erow * 4 * H + u0 + eu;
         nt_store2(gr, gi); nt_store2(gr + H, gf); nt_store2(gr + 2 * H, gg); nt_store2(gr + 3 * H, go);
         *reinterpret_cast<float2*>(c_out + (int64_t)erow * H + u0 + eu) = cn;
-        *reinterpret_cast<float2*>(h_out + (int64_t)erow * H + u0 + eu) = hn;
+        *reinterpret_cast<float2*>(h_out + (int64_t)erow * ldh + u0 + eu) = hn;
     };
     auto load_c = [&](int rb) {
         const int erow = rb * RB + er;
@@ -1171,14 +1171,14 @@ extern "C" int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const fl
     return 0;
 }
 
-extern "C" int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
-                                   const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
-                                   void* stream) {
-    if (bad_dims(R, H) || (h == nullptr) != (c == nullptr)) return -1;
+extern "C" int mmdfn_lstm_gate_fwd_ld(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                                      const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                                      int ldh, void* stream) {
+    if (bad_dims(R, H) || (h == nullptr) != (c == nullptr) || ldh < H || (ldh & 3)) return -1;
     if (gate_split(R, H)) {
         // many rows: the contraction on the bf16 matrix path, cell math from the accumulators (lstm_gate_split.hip)
         const int rc = mmdfn_launch_lstm_gate_fwd_split(q, h, c, Wih, Whh, bsum, bsum2, gates, h_out, c_out, R, H,
-                                                        (hipStream_t)stream);
+                                                        ldh, (hipStream_t)stream);
         if (rc != -2) return rc;
     }
     const int ncb = (H + UB - 1) / UB;
@@ -1187,14 +1187,20 @@ extern "C" int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* 
         if (ldsw > 156 * 1024) return -1;
         if (int e_ = mmdfn_allow_big_lds(lstm_gate_fwd_ws_kernel)) return e_;
         hipLaunchKernelGGL(lstm_gate_fwd_ws_kernel, dim3(row_groups(R, ncb), ncb), dim3(512), ldsw, (hipStream_t)stream, q, h, c, Wih,
-                           Whh, bsum, bsum2, gates, h_out, c_out, R, H);
+                           Whh, bsum, bsum2, gates, h_out, c_out, R, H, ldh);
         MMDFN_CHECK_LAUNCH();
         return 0;
     }
     const size_t lds = ((size_t)(4 * UB + 2 * RB) * lds_stride(h ? 2 * H : H) + 4 * RB * (UB + 4)) * sizeof(float);
     LAUNCH_BIG_LDS(lstm_gate_fwd_kernel, dim3(row_groups(R, ncb), ncb), lds, stream, q, h, c, Wih, Whh, bsum, bsum2, gates,
-                   h_out, c_out, R, H);
+                   h_out, c_out, R, H, ldh);
     return 0;
+}
+
+extern "C" int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                                   const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                                   void* stream) {
+    return mmdfn_lstm_gate_fwd_ld(q, h, c, Wih, Whh, bsum, bsum2, gates, h_out, c_out, R, H, H, stream);
 }
 
 extern "C" int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh_a,
@@ -1247,11 +1253,16 @@ extern "C" int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const flo
     return 0;
 }
 
-extern "C" int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
-                                     float theta, float alpha, int R, int H, int lddo, int acc_h0, void* stream) {
-    if (bad_dims(R, H) || lddo < H || (lddo & 3) || !(theta > 0.f)) return -1;
+extern "C" int mmdfn_gcnii_layer_bwd_ld(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
+                                        float theta, float alpha, int R, int H, int lddo, int acc_h0, int lddhi, void* stream) {
+    if (bad_dims(R, H) || lddo < H || (lddo & 3) || lddhi < H || (lddhi & 3) || !(theta > 0.f)) return -1;
     const size_t lds = ((size_t)(2 * H + 2 * RB) * lds_stride(H) + RB * (((2 * H + 15) & ~15) + 4)) * sizeof(float);
     LAUNCH_BIG_LDS(gcnii_layer_bwd_kernel, dim3(row_groups(R, 1)), lds, stream, dout, gmask, W, dP, dhi, dh0, theta, alpha, R, H,
-                   lddo, acc_h0);
+                   lddo, acc_h0, lddhi);
     return 0;
+}
+
+extern "C" int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
+                                     float theta, float alpha, int R, int H, int lddo, int acc_h0, void* stream) {
+    return mmdfn_gcnii_layer_bwd_ld(dout, gmask, W, dP, dhi, dh0, theta, alpha, R, H, lddo, acc_h0, H, stream);
 }

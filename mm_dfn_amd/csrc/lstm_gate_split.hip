@@ -40,7 +40,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builti
 __global__ __launch_bounds__(256, 2) void lstm_gate_fwd_split_kernel(
     const float* __restrict__ q, const float* __restrict__ h, const float* __restrict__ c, const float* __restrict__ Wih,
     const float* __restrict__ Whh, const float* __restrict__ bsum, const float* __restrict__ bsum2, float* __restrict__ gates,
-    float* __restrict__ h_out, float* __restrict__ c_out, int R, int H) {
+    float* __restrict__ h_out, float* __restrict__ c_out, int R, int H, int ldh) {
     constexpr int NCT = 4;
     constexpr int ABLC = 0;
     constexpr int WROWS = 32;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void lstm_gate_fwd_split_kernel(
     const int arow = r0 + wrow0 + l32;
     const int64_t aoff = (int64_t)(arow < R ? arow : R - 1) * H;
     const float* q_lane = q + aoff;
-    const float* h_lane = h ? h + aoff : q + aoff;
+    const float* h_lane = h ? h + (int64_t)(arow < R ? arow : R - 1) * ldh : q + aoff;
     int boff[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) boff[ct] = (32 * ct + l32) * SROW + 4 * kg;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void lstm_gate_fwd_split_kernel(
         __builtin_nontemporal_store(gg, gr + 2 * H);
         __builtin_nontemporal_store(go, gr + 3 * H);
         c_out[(int64_t)row * H + unit] = cn;
-        h_out[(int64_t)row * H + unit] = hn;
+        h_out[(int64_t)row * ldh + unit] = hn;
     }
 }
 
@@ -146,13 +146,13 @@ __global__ __launch_bounds__(256, 2) void lstm_gate_fwd_split_kernel(
 // -2: shape not covered (the caller keeps the exact-f32 kernels of gcn_stack.hip)
 int mmdfn_launch_lstm_gate_fwd_split(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
                                      const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R,
-                                     int H, hipStream_t s) {
+                                     int H, int ldh, hipStream_t s) {
     if (H < 8 || (H & 3) || R <= 0) return -2;
     const int nub = (H + 31) / 32;
     const int lds_bytes = 2 * 3 * 128 * SROW * 4;
     dim3 grid(((R + 127) / 128) * nub);
     hipLaunchKernelGGL(lstm_gate_fwd_split_kernel, grid, dim3(256), lds_bytes, s, q, h, c, Wih, Whh, bsum, bsum2, gates, h_out,
-                       c_out, R, H);
+                       c_out, R, H, ldh);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -413,26 +413,61 @@ int mmdfn_launch_tile_dot(const float* X, const float* Y, float* out_tiles, floa
                            accumulate, s, nullptr);
 }
 
+// cross-modal diagonals of one contraction piece (d <= 208 takes the register-resident kernels)
+static void cross_piece(const float* X, const float* Y, float* dcross, int M, int N, int d, int ldx, int ldy, int accumulate,
+                        hipStream_t s) {
+#define CROSS_DOT(MM, KS) \
+    hipLaunchKernelGGL((cross_dot_kernel<MM, KS>), dim3((N + 15) / 16), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy, accumulate)
+    if (M <= 3 && d <= 112) CROSS_DOT(3, 7);
+    else if (M <= 3 && d <= 208) CROSS_DOT(3, 13);
+    else if (M <= 6 && d <= 112) CROSS_DOT(6, 7);
+    else if (M <= 6 && d <= 208) CROSS_DOT(6, 13);
+    else
+        hipLaunchKernelGGL(cross_dot_generic_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy,
+                           accumulate);
+#undef CROSS_DOT
+}
+
 extern "C" int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, float* dcross,
                                 const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                                 int B, int M, int N, int d, int ldx, int ldy, int max_len, int accumulate,
                                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_tile_dot(X, Y, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, d, ldx, ldy, max_len, 0,
-                             accumulate, s, &dcross);
-    if (rc) return rc;
-    if (M > 1 && dcross) {              // (NULL by now if the tile launch took the cross diagonals along)
-#define CROSS_DOT(MM, KS) \
-    hipLaunchKernelGGL((cross_dot_kernel<MM, KS>), dim3((N + 15) / 16), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy, accumulate)
-        if (M <= 3 && d <= 112) CROSS_DOT(3, 7);
-        else if (M <= 3 && d <= 208) CROSS_DOT(3, 13);
-        else if (M <= 6 && d <= 112) CROSS_DOT(6, 7);
-        else if (M <= 6 && d <= 208) CROSS_DOT(6, 13);
-        else
-            hipLaunchKernelGGL(cross_dot_generic_kernel, dim3((N + 3) / 4), dim3(256), 0, s, X, Y, dcross, M, N, d, ldx, ldy,
-                               accumulate);
-#undef CROSS_DOT
-        MMDFN_CHECK_LAUNCH();
+    if (d <= 0 || (d & 3)) return -1;
+    // A wide contraction (the GCN stack hands over all its layers at once: d = nl H, gcn_stack.py) is ONE launch on the bf16-piece
+    // kernel, which walks K; the exact-f32 kernels keep their A strip in registers (K <= 208), so there the contraction index
+    // is cut into pieces of <= 200 columns that accumulate (any cut of the index is exact up to the order of the sum).  The
+    // cross-modal diagonals are cut the same way in both cases.
+    const int mrb = (max_len + 127) / 128;
+    const bool piece_kernel = (d > 512) || (max_len >= 128 && (long)B * M * mrb * mrb >= 48);
+    constexpr int CUT = 200;
+    if (piece_kernel || d <= 208) {
+        float* dc = dcross;
+        int rc = launch_tile_dot(X, Y, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, d, ldx, ldy, max_len, 0,
+                                 accumulate, s, &dc);
+        if (rc) return rc;
+        if (M > 1 && dc) {              // (NULL by now if the tile launch took the cross diagonals along)
+            for (int c0 = 0; c0 < d; c0 += CUT) {
+                const int kc = d - c0 < CUT + 8 ? d - c0 : CUT;          // (no sliver at the end: 208 stays one piece)
+                cross_piece(X + c0, Y + c0, dc, M, N, kc, ldx, ldy, (accumulate || c0 > 0) ? 1 : 0, s);
+                if (kc != CUT) break;
+            }
+            MMDFN_CHECK_LAUNCH();
+        }
+        return 0;
+    }
+    for (int c0 = 0; c0 < d; c0 += CUT) {
+        const int kc = d - c0 < CUT + 8 ? d - c0 : CUT;
+        const int acc = (accumulate || c0 > 0) ? 1 : 0;
+        float* dc = dcross;
+        int rc = launch_tile_dot(X + c0, Y + c0, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, kc, ldx, ldy,
+                                 max_len, 0, acc, s, &dc);
+        if (rc) return rc;
+        if (M > 1 && dc) {
+            cross_piece(X + c0, Y + c0, dc, M, N, kc, ldx, ldy, acc, s);
+            MMDFN_CHECK_LAUNCH();
+        }
+        if (kc != CUT) break;
     }
     return 0;
 }

@@ -1,7 +1,8 @@
 """The GCNII "dynamic fusion" stack (reference GCNII_lyc.forward, model_GCN.py:444-488) as ONE autograd node.
 
 Forward = 1 + 3 launches per layer (input stage; per layer: LSTM gate K8, propagate K6, GCNII update K7), backward =
-1 + 5 per layer (K7', K6', the two tile-pattern kernels of dA, K8') -- every stage is a fused kernel of
+1 + 3 per layer (K7', K6, K8') + ONE adjacency-gradient contraction for the whole stack (round 5: the layers' propagated
+states and their gradients are column blocks of two (R, nl H) buffers) -- every stage is a fused kernel of
 csrc/gcn_stack.hip / propagate.hip / tile_dot.hip.  Written as a single ``torch.autograd.Function`` with a
 hand-scheduled backward because the stack's dataflow has three fan-outs that autograd would serve with accumulation
 kernels: h0 feeds every layer (the kernels accumulate dh0 in place), the adjacency feeds every layer (tile_outer
@@ -57,13 +58,17 @@ class _GcnStack(torch.autograd.Function):
                    "mmdfn_gcn_input_fwd")
         h = c = None
         layers = []
+        # the layers' hidden states are column blocks of ONE (R, nl H) buffer: what every layer propagates (zin_l) is then the
+        # Y operand of a single adjacency-gradient contraction of width nl H in the backward pass (the adjacency is shared by
+        # the layers, model_GCN.py:461-472), instead of nl read-modify-write passes over the tile array
+        zin_all = new(R, nl * H) if reason else None
         for i in range(nl):
             q = cur
             rec = dict(q=q, h_prev=h, c_prev=c)
             if reason:
-                gates, h_new, c_new = new(R, 4 * H), new(R, H), new(R, H)
-                _hip.check(lib.mmdfn_lstm_gate_fwd(P(q), P(h), P(c), P(w_ih), P(w_hh), P(b_ih), P(b_hh), P(gates), P(h_new),
-                                                   P(c_new), R, H, st), "mmdfn_lstm_gate_fwd")
+                gates, h_new, c_new = new(R, 4 * H), zin_all[:, i * H:(i + 1) * H], new(R, H)
+                _hip.check(lib.mmdfn_lstm_gate_fwd_ld(P(q), P(h), P(c), P(w_ih), P(w_hh), P(b_ih), P(b_hh), P(gates), P(h_new),
+                                                      P(c_new), R, H, nl * H, st), "mmdfn_lstm_gate_fwd_ld")
                 rec.update(gates=gates, c_new=c_new)
                 h, c = h_new, c_new
                 zin = h_new
@@ -89,7 +94,7 @@ class _GcnStack(torch.autograd.Function):
         ctx.layers = layers
         # (xd is a detached alias: holding the output itself would tie this node and its output into a reference cycle)
         ctx.misc = dict(lay=lay, symmetric=symmetric, alpha=alpha, reason=reason, use_residue=use_residue, R=R, F=F, H=H,
-                        mx=mx, m0=m0, xd=xd.detach(), h0=h0, tiles=tiles, cross=cross, mscale=mscale)
+                        mx=mx, m0=m0, xd=xd.detach(), h0=h0, tiles=tiles, cross=cross, mscale=mscale, zin_all=zin_all)
         ctx.params = (W0, b0, w_ih, w_hh, b_ih, b_hh, convW)
         return out
 
@@ -134,17 +139,22 @@ class _GcnStack(torch.autograd.Function):
         acc_h0 = 0
         dtiles = dcross = None
         dh_carry = dc_carry = None
-        for i in reversed(range(len(ctx.layers))):
+        nl = len(ctx.layers)
+        # one adjacency-gradient launch for the whole stack: dhi_l are column blocks of one buffer, like zin_l (see forward)
+        one_outer = want_adj and m["zin_all"] is not None
+        dhi_all = new(R, nl * H) if one_outer else None
+        for i in reversed(range(nl)):
             L = ctx.layers[i]
-            dP, dhi = new(R, H), new(R, H)
-            _hip.check(lib.mmdfn_gcnii_layer_bwd(P(dcur), P(L["gmask"]), P(convW[i]), P(dP), P(dhi), P(dh0), L["theta"],
-                                                 m["alpha"], R, H, lddo, acc_h0, st), "mmdfn_gcnii_layer_bwd")
+            dP = new(R, H)
+            dhi = dhi_all[:, i * H:(i + 1) * H] if one_outer else new(R, H)
+            _hip.check(lib.mmdfn_gcnii_layer_bwd_ld(P(dcur), P(L["gmask"]), P(convW[i]), P(dP), P(dhi), P(dh0), L["theta"],
+                                                    m["alpha"], R, H, lddo, acc_h0, dhi.stride(0), st), "mmdfn_gcnii_layer_bwd_ld")
             acc_h0 = 1
             # dW_i = [hi | h0]^T dP: two row ranges of the (2H, H) parameter, the concatenated operand never exists
             wgrad(L["hi"], dP, convW[i], rows=(0, H))
             wgrad(m["h0"], dP, convW[i], rows=(H, 2 * H))
             dz = ops.propagate_raw(tiles, cross, dhi, lay, transpose=not m["symmetric"])
-            if want_adj:
+            if want_adj and not one_outer:
                 dtiles, dcross = ops.tile_outer_raw(dhi, L["zin"], lay, dtiles, dcross)
             if m["reason"]:
                 has_h = L["h_prev"] is not None
@@ -161,6 +171,9 @@ class _GcnStack(torch.autograd.Function):
                 dh_carry, dc_carry = dh_prev, dc_prev
             else:
                 dcur, lddo = dz, H
+        if one_outer:
+            # dA = [dhi_1 | .. | dhi_nl] [zin_1 | .. | zin_nl]^T on the tile / diagonal pattern: the tile array is written once
+            dtiles, dcross = ops.tile_outer_raw(dhi_all, m["zin_all"], lay)
         dpre, dx = new(R, H), new(R, F)
         _hip.check(lib.mmdfn_gcn_input_bwd(P(dcur), P(m["m0"]), P(dh0), P(m["h0"]), P(W0), P(dxd), P(m["mx"]), P(dpre), P(dx), R,
                                            F, H, lddxd, m["mscale"], st), "mmdfn_gcn_input_bwd")

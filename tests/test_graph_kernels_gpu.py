@@ -440,6 +440,72 @@ def test_tile_outer_bf16_piece_kernel(lengths, M, d, kernel_variants):
     assert float((acc_t - 2 * dt0).abs().max()) / float(dt0.abs().max()) < 4e-6
 
 
+@pytest.mark.parametrize("lengths,M,nl,H", [([40, 17, 5], 3, 2, 100), ([33, 9], 3, 4, 100), ([20, 7], 2, 3, 36),
+                                            ([130, 129, 128, 140], 6, 8, 100), ([257, 31], 2, 5, 100), ([12], 3, 16, 100)])
+def test_tile_outer_over_all_layers_at_once(lengths, M, nl, H):
+    """The GCN stack's adjacency gradient as ONE contraction of width nl H (the layers' operands are column blocks of two
+    buffers) against nl accumulating launches of width H: the exact-f32 kernels cut the index into pieces of <= 200 columns,
+    the bf16-piece kernel walks it; tiles against a float64 product, cross diagonals against the per-layer sum."""
+    rs = np.random.RandomState(43)
+    lay = DialogueLayout.get(lengths, M, DEV)
+    N = sum(lengths)
+    X = torch.from_numpy(rs.randn(M * N, nl * H).astype(np.float32)).to(DEV)
+    Y = torch.from_numpy(rs.randn(M * N, nl * H).astype(np.float32)).to(DEV)
+    dt, dc = ops.tile_outer_raw(X, Y, lay)
+    dt0 = dc0 = None
+    for i in range(nl):
+        dt0, dc0 = ops.tile_outer_raw(X[:, i * H:(i + 1) * H], Y[:, i * H:(i + 1) * H], lay, dt0, dc0)
+    assert float((dt - dt0).abs().max()) / float(dt0.abs().max()) < 4e-6
+    if dc.numel():
+        assert float((dc - dc0).abs().max()) / float(dc0.abs().max()) < 4e-6
+    Xc, Yc = X.double().cpu(), Y.double().cpu()
+    start = 0
+    for i, L in enumerate(lengths):
+        ld = int(lay.ld_host[i]); base = int(lay.tile_base_host[i])
+        for m in range(M):
+            got = dt[base + m * L * ld: base + (m + 1) * L * ld].view(L, ld).double().cpu()
+            want = Xc[m * N + start:m * N + start + L] @ Yc[m * N + start:m * N + start + L].t()
+            assert float((got[:, :L] - want).abs().max()) / float(want.abs().max()) < 4e-6
+            if ld > L:
+                assert float(got[:, L:].abs().max()) == 0.0
+        start += L
+
+
+@pytest.mark.parametrize("R,H,nl", [(37, 100, 2), (5280, 100, 4), (24576, 100, 8), (600, 36, 3)])
+def test_strided_state_forms_of_the_stack_kernels(R, H, nl):
+    """mmdfn_lstm_gate_fwd_ld / mmdfn_gcnii_layer_bwd_ld: hidden states / dhi as column blocks of an (R, nl H) buffer -- bit-equal
+    to the contiguous forms, neighbouring blocks untouched."""
+    from mm_dfn_amd import _hip
+    lib, P, st = _hip.lib(), _hip.ptr, _hip.stream
+    rs = np.random.RandomState(84)
+    q, c = _rnd(rs, R, H), _rnd(rs, R, H)
+    Wih, Whh, b_ih, b_hh = _rnd(rs, 4 * H, H, scale=0.2), _rnd(rs, 4 * H, H, scale=0.2), _rnd(rs, 4 * H), _rnd(rs, 4 * H)
+    wide = _rnd(rs, R, nl * H)
+    keep = wide.clone()
+    h = wide[:, H:2 * H]                              # state of "layer 1" in place, result goes to block 2 (or 0)
+    dst = 2 if nl > 2 else 0
+    g0, h0, c0 = (torch.empty(R, n, device=DEV) for n in (4 * H, H, H))
+    assert lib.mmdfn_lstm_gate_fwd(P(q), P(h.contiguous()), P(c), P(Wih), P(Whh), P(b_ih), P(b_hh), P(g0), P(h0), P(c0), R, H, st()) == 0
+    g1, c1 = torch.empty_like(g0), torch.empty_like(c0)
+    assert lib.mmdfn_lstm_gate_fwd_ld(P(q), P(h), P(c), P(Wih), P(Whh), P(b_ih), P(b_hh), P(g1), P(wide[:, dst * H:(dst + 1) * H]),
+                                      P(c1), R, H, nl * H, st()) == 0
+    assert torch.equal(wide[:, dst * H:(dst + 1) * H], h0) and torch.equal(g1, g0) and torch.equal(c1, c0)
+    for b in range(nl):
+        if b != dst:
+            assert torch.equal(wide[:, b * H:(b + 1) * H], keep[:, b * H:(b + 1) * H])
+    # layer backward: dhi into a column block
+    dout, W = _rnd(rs, R, H), _rnd(rs, 2 * H, H, scale=0.2)
+    gmask = (torch.from_numpy(rs.rand(R, H).astype(np.float32)) > 0.4).float().to(DEV) * 2.0
+    dP0, dhi0, dh00 = (torch.empty(R, H, device=DEV) for _ in range(3))
+    assert lib.mmdfn_gcnii_layer_bwd(P(dout), P(gmask), P(W), P(dP0), P(dhi0), P(dh00), 0.4, 0.2, R, H, H, 0, st()) == 0
+    wide2 = keep.clone()
+    dP1, dh01 = torch.empty_like(dP0), torch.empty_like(dh00)
+    assert lib.mmdfn_gcnii_layer_bwd_ld(P(dout), P(gmask), P(W), P(dP1), P(wide2[:, H:2 * H]), P(dh01), 0.4, 0.2, R, H, H, 0,
+                                        nl * H, st()) == 0
+    assert torch.equal(wide2[:, H:2 * H], dhi0) and torch.equal(dP1, dP0) and torch.equal(dh01, dh00)
+    assert torch.equal(wide2[:, :H], keep[:, :H]) and (nl < 3 or torch.equal(wide2[:, 2 * H:], keep[:, 2 * H:]))
+
+
 def test_weight_gradient_batch_kernel():
     """mmdfn_gemm_tn_batch: every weight-gradient contraction of a step in one launch pair -- several segments per
     output (summed in the slab reduction), row shifts, strided operand views, two bias destinations, accumulate."""
