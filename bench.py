@@ -644,6 +644,17 @@ def roofline_legs(out, a, dev, n_utt, lengths):
                                 "avg_launch_us": ms5 * 1e3,
                                 "buffers": "3 rotating (adjacency, H, out) sets = %.0f MB > 256 MB MALL" % (3 * b5 / 1e6),
                                 "useful_tflops": lay5.propagate_flops(d) / (ms5 * 1e-3) / 1e12}
+        # the second figure of this leg: at 36 flop per algorithmic byte the launch sits ABOVE the exact-fp32
+        # matrix ridge (157.3 TFLOP/s / 8 TB/s = 19.7 flop/B), so the matrix side is its binding roof; priced against the
+        # dense fp32 matrix peak (the fp32 product rides on six bf16-piece MFMAs per K = 16)
+        fl5 = lay5.propagate_flops(d)
+        out["roofline_cfg5"]["second_bound"] = {
+            "bound": "mfma_f32", "achieved": fl5 / (ms5 * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+            "frac": fl5 / (ms5 * 1e-3) / 1e12 / 157.3, "flop_per_algorithmic_byte": fl5 / b5,
+            "ridge_flop_per_byte": 157.3e12 / (HBM_PEAK_GBS * 1e9),
+            "note": "useful fp32 flop (2 d nnz) per launch / launch time; the kernel's issue-side accounting (MFMA 23 us + "
+                    "piece cutting and other issue 25 us + epilogue per workgroup pair, no overlap between them on a SIMD) "
+                    "is in DESIGN.md 4g / profiles/r03_k6_memory_path.md"}
         # K6 backward at the same workload, reported separately: dH = A^T dO (the forward kernel, A is
         # symmetric) + dA = dO . H^T on the tile pattern (tile_dot + cross_dot); bytes_bwd = 8 nnz + 16 M N d
         adj5, H5 = mk5(0)

@@ -63,12 +63,6 @@ int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const f
                                  const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                                  int B, int M, int N, int d, int ldh, int ldo, int max_len, hipStream_t s);
 
-// producer / consumer form of the bf16-piece product (propagate_pc.hip: persistent workgroups, MFMA-only consumer waves);
-// -2 = shape not covered
-int mmdfn_launch_propagate_pc(const float* tiles, const float* cross, const float* H, float* out,
-                              const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
-                              int B, int M, int N, int d, int ldh, int ldo, int max_len, hipStream_t s);
-
 // bf16-piece variant of the dense projection for many-row launches (linear_split.hip); -2 = shape not covered
 int mmdfn_launch_linear_split(const float* X, const float* W, const float* W2, int N1, const float* bias,
                               const float* bias2, float* Y, int R, int K, int N, int ldx, int ldy, int act, int accumulate,

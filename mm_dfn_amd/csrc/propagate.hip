@@ -460,12 +460,6 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
                 if (rc != -2) return rc;
                 break;
             }
-            case 10: {
-                const int rc = mmdfn_launch_propagate_pc(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d,
-                                                         ldh, ldo, max_len, s);
-                if (rc != -2) return rc;
-                break;
-            }
             default: break;
         }
     }

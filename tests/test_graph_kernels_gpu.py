@@ -82,43 +82,6 @@ def test_propagate_bf16_piece_kernel(lengths, M, d, kernel_variants):
     assert e_split <= 4 * e_f32 + 1e-7
 
 
-PC_CASES = [
-    ([5], 3, 100),
-    ([7, 3, 1], 3, 100),
-    ([110, 64, 65, 27], 3, 100),
-    ([129, 127, 128, 200], 2, 100),
-    ([260, 40], 6, 64),
-    ([513], 3, 100),
-    ([140, 77], 3, 112),
-    ([300, 512, 17, 129, 1, 255, 256, 257, 400], 3, 100),
-    ([161] * 40, 6, 36),
-]
-
-
-@pytest.mark.parametrize("lengths,M,d", PC_CASES)
-def test_propagate_producer_consumer_kernel(lengths, M, d, kernel_variants):
-    """The producer / consumer form of the bf16-piece product (csrc/propagate_pc.hip: persistent workgroups, MFMA-only
-    consumer waves, asm loads with hand-counted waits; measured slower than propagate_split.hip and therefore not
-    dispatched, profiles/r04_k6_producer_consumer.md) forced through the tuning switch: fp32-level error against fp64 on
-    ragged batches, items with a single row, more workgroups than items and NaN-poisoned tile padding."""
-    adj, dense, _, _ = random_block_adjacency(13, lengths, M, DEV)
-    lay = adj.layout
-    tiles = adj.tiles.clone()
-    for i, L in enumerate(lengths):
-        ld = int(lay.ld_host[i]); base = int(lay.tile_base_host[i])
-        if ld > L:
-            tiles[base: base + M * L * ld].view(M * L, ld)[:, L:] = float("nan")
-    rs = np.random.RandomState(7)
-    H = torch.from_numpy(rs.randn(M * sum(lengths), d).astype(np.float32))
-    kernel_variants.setenv("MMDFN_PROP_CFG", "10")
-    out = ops.propagate_raw(tiles, adj.cross, H.to(DEV), lay)
-    want = dense.double() @ H.double()
-    kernel_variants.setenv("MMDFN_PROP_CFG", "9")
-    ref = ops.propagate_raw(tiles, adj.cross, H.to(DEV), lay)
-    e_pc = float((out.double().cpu() - want).abs().max())
-    e_f32 = float((ref.double().cpu() - want).abs().max())
-    assert e_pc <= 4 * e_f32 + 1e-7
-    assert float((out - ref).abs().max()) > 0.0 or sum(lengths) < 16      # it really was a different kernel
 
 
 def test_propagate_bf16_piece_kernel_is_the_large_launch_default(kernel_variants):

@@ -1,7 +1,8 @@
-"""Accuracy + timing of the producer / consumer bf16-piece propagate (MMDFN_PROP_CFG=10) against the bf16-piece kernel of
-rounds 1-3 (MMDFN_PROP_CFG=8), the exact-f32 kernels (9) and an fp64 dense product.
+"""Accuracy + timing of the producer / consumer bf16-piece propagate (kernel "10": tools/k6_pc/bin/libk6pc.so, outside the
+product library since round 5) against the bf16-piece kernel of rounds 1-3 (MMDFN_PROP_CFG=8), the exact-f32 kernels (9) and
+an fp64 dense product.
 
-    python tools/check_pc.py            # correctness cases + cfg5 timing (rotating buffer sets, captured graph)
+    bash tools/k6_pc/build.sh && python tools/k6_pc/check_pc.py    # correctness cases + cfg5 timing (rotating buffer sets, captured graph)
 """
 import os
 
@@ -11,10 +12,14 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 for sub in ("tests", "oracle"):   # tests/util.py builds the dense fp64 reference (test infrastructure only)
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), sub))
+    sys.path.insert(0, os.path.join(ROOT, sub))
 from mm_dfn_amd import ops  # noqa: E402
+import pc_ops  # noqa: E402
 from util import random_block_adjacency  # noqa: E402
 
 DEV = "cuda"
@@ -26,6 +31,8 @@ CASES = [
 
 
 def run(cfg, tiles, cross, H, lay, out=None):
+    if int(cfg) == 10:
+        return pc_ops.propagate_pc(tiles, cross, H, lay, out=out)
     os.environ["MMDFN_PROP_CFG"] = str(cfg)
     return ops.propagate_raw(tiles, cross, H, lay, out=out)
 
@@ -66,10 +73,9 @@ for B in (32, 8):
     by = sets[0][4].propagate_bytes(d)
     runs = [(8, 0), (10, 0), (8, 0), (10, 0)] + [(10, int(a)) for a in os.environ.get("PC_ABLS", "").split(",") if a]
     for cfg, abl in runs:
-        os.environ["MMDFN_PROP_CFG"] = str(cfg)
         os.environ["MMDFN_PC_ABL"] = str(abl)
         for t, c, h, o, lay in sets:
-            ops.propagate_raw(t, c, h, lay, out=o)
+            run(cfg, t, c, h, lay, out=o)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         st = torch.cuda.Stream()
@@ -77,7 +83,7 @@ for B in (32, 8):
             with torch.cuda.graph(g, stream=st):
                 for rep in range(7):
                     for t, c, h, o, lay in sets:
-                        ops.propagate_raw(t, c, h, lay, out=o)
+                        run(cfg, t, c, h, lay, out=o)
             for _ in range(12):
                 g.replay()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -88,9 +94,8 @@ for B in (32, 8):
         e1.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (5 * 7 * nset)
         if abl & 64:
-            os.environ["MMDFN_PROP_CFG"] = "10"
             t, c, h, o, lay = sets[0]
-            ops.propagate_raw(t, c, h, lay, out=o)
+            run(10, t, c, h, lay, out=o)
             torch.cuda.synchronize()
             nwg = min(256, B * M * 4)
             st_ = o.view(-1)[: nwg * 16].view(nwg, 16).double().mean(0).cpu().numpy()

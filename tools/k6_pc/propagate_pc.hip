@@ -37,7 +37,7 @@
 //
 // Item order: item t <-> (dialogue, modality, row block) with t % 8 == dialogue % 8, workgroup g takes t = g, g + G, ...
 // (G a multiple of 8), so every tile of a dialogue is served by one XCD's L2 as in the other K6 kernels.
-#include "mmdfn_internal.h"
+#include "../../mm_dfn_amd/csrc/mmdfn_internal.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -605,8 +605,8 @@ int pc_num_cus() {
 
 }  // namespace
 
-// returns -2 when the shape is not covered (the caller goes on to propagate_split.hip / the f32-MFMA kernels)
-int mmdfn_launch_propagate_pc(const float* tiles, const float* cross, const float* H, float* out,
+// returns -2 when the shape is not covered
+static int launch_propagate_pc(const float* tiles, const float* cross, const float* H, float* out,
                               const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                               int B, int M, int N, int d, int ldh, int ldo, int max_len, hipStream_t s) {
     if ((d & 3) || d > 112 || d < 4 || (M != 2 && M != 3 && M != 6)) return -2;
@@ -634,4 +634,12 @@ int mmdfn_launch_propagate_pc(const float* tiles, const float* cross, const floa
 #undef PC_LAUNCH
     MMDFN_CHECK_LAUNCH();
     return 0;
+}
+
+// the experiment's C entry (tools/k6_pc/pc_ops.py binds it with ctypes; not part of libmmdfn_hip.so since round 5)
+extern "C" int k6pc_propagate(const float* tiles, const float* cross, const float* H, float* out, const int32_t* dia_len,
+                              const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int d, int ldh, int ldo,
+                              int max_len, void* stream) {
+    return launch_propagate_pc(tiles, cross, H, out, dia_len, row_start, tile_base, B, M, N, d, ldh, ldo, max_len,
+                               (hipStream_t)stream);
 }

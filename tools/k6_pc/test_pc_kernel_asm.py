@@ -1,5 +1,5 @@
-"""The producer / consumer K6 kernel (csrc/propagate_pc.hip) issues its producers' global loads from inline asm with
-hand-counted waits; tools/verify_pc_asm.py checks on the ISA hipcc generates from the library's own sources that every wait
+"""The producer / consumer K6 kernel (tools/k6_pc/propagate_pc.hip, an experiment kept outside the product library) issues its producers' global loads from inline asm with
+hand-counted waits; tools/k6_pc/verify_pc_asm.py checks on the ISA hipcc generates from its source that every wait
 names the registers its load wrote and that nothing touches them in between (CPU test: hipcc cross-compiles without a
 GPU)."""
 import os
@@ -8,8 +8,7 @@ import sys
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")

@@ -1,4 +1,4 @@
-"""Check the hand-counted vector-memory waits of csrc/propagate_pc.hip in the ISA hipcc generated.
+"""Check the hand-counted vector-memory waits of tools/k6_pc/propagate_pc.hip in the ISA hipcc generated.
 
 The producer waves of the producer / consumer K6 kernel issue their global loads from inline asm and retire them with
 hand-counted ``s_waitcnt vmcnt(N)``.  Between such a load and its wait the compiler believes the destination registers
@@ -12,8 +12,8 @@ register sets); this tool VERIFIES the outcome on the generated code:
   * every ``pc-load`` is retired by a ``pc-wait`` (an orphan means the value was copied and the wait names the copy);
   * no scratch (spill) instruction appears in the kernel: spills are vector-memory operations the counts do not know.
 
-    python tools/verify_pc_asm.py            # compiles csrc/propagate_pc.hip (device ISA only) and checks every instance
-    python tools/verify_pc_asm.py file.s     # checks an existing listing
+    python tools/k6_pc/verify_pc_asm.py            # compiles tools/k6_pc/propagate_pc.hip (device ISA only) and checks every instance
+    python tools/k6_pc/verify_pc_asm.py file.s     # checks an existing listing
 
 Exit code 0 = every instance passes.  tests/test_pc_kernel_asm.py runs it on the library's sources (CPU: hipcc
 cross-compiles without a GPU).
@@ -24,8 +24,9 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "mm_dfn_amd", "csrc", "propagate_pc.hip")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SRC = os.path.join(HERE, "propagate_pc.hip")
 
 REG_RANGE = re.compile(r"\bv\[(\d+):(\d+)\]")
 REG_ONE = re.compile(r"\bv(\d+)\b")
