@@ -492,12 +492,22 @@ def main():
                 allreduce_mode = "captured in the step's hipGraph"
                 step = captured.replay
             except Exception as exc:
+                allreduce_fallback = "%s: %s" % (type(exc).__name__, exc)
+                allreduce_mode = "eager after the step (capturing it failed: %s)" % allreduce_fallback
                 print("[bench] capturing the all-reduce failed (%s: %s); all-reduce stays eager" % (type(exc).__name__, exc),
                       file=sys.stderr)
                 torch.cuda.synchronize()
                 captured = None
                 dp = distributed.GradientBucket(model, average=False, parts=2 if a.two_part_bucket else 1)
         if captured is None:
+            if dp is not None and a.two_part_bucket:
+                # a two-part bucket armed inside a capture bakes its first collective into the graph; with the second one
+                # issued eagerly after every replay nothing re-arms it and the first part would be reduced twice:
+                # without the in-graph all-reduce the bucket is one part
+                print("[bench] --two-part-bucket needs the all-reduce inside the captured step; using a one-part bucket",
+                      file=sys.stderr)
+                dp = distributed.GradientBucket(model, average=False, parts=1)
+                allreduce_mode = (allreduce_mode or "") + " (two-part bucket dropped: all-reduce not captured)"
             try:
                 captured = CapturedStep(model, fwd_bwd, warmup=3, bucket=dp)
 
@@ -532,6 +542,36 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- multi-GPU self-check (the first real N-GPU run has no earlier measurement to be compared with): every rank
+    # times ITS OWN shard without the collective, rank 0 adds the modelled ring all-reduce of --predict-scaling and prints
+    # the prediction next to what was measured, plus the per-rank times (imbalance) and whether the collective was captured.
+    self_check = None
+    if use_dp and world > 1:
+        try:
+            from mm_dfn_amd.graphs import CapturedStep
+
+            def fwd_bwd_local():
+                logp = model(batch["textf"], batch["qmask"], batch["umask"], lengths, batch["acouf"], batch["visuf"])[0]
+                loss = loss_f(logp, label) * scale
+                train.backward(loss)
+                return loss
+            local_ms = timed_replays(CapturedStep(model, fwd_bwd_local, warmup=2), max(10, a.steps // 4), 3) * 1e3
+            every = [None] * world
+            torch.distributed.all_gather_object(every, local_ms)
+            bucket_bytes = dp.flat.numel() * 4 if (dp is not None and dp.flat is not None) else 0
+            comm_ms = (2.0 * (world - 1) / world * bucket_bytes / 153e9 + 20e-6) * 1e3
+            measured = dt / a.steps * 1e3
+            predicted = max(every) + comm_ms
+            self_check = {"compute_only_ms_per_rank": every, "imbalance": sum(every) / world / max(every),
+                          "allreduce_model_ms": comm_ms, "allreduce_model": "ring over xGMI: 2 (N-1)/N x bytes / 153 GB/s + 20 us, "
+                          "not overlapped (one-part bucket)", "predicted_ms_per_step": predicted, "measured_ms_per_step": measured,
+                          "measured_over_predicted": measured / predicted,
+                          "allreduce_captured": bool(allreduce_mode and allreduce_mode.startswith("captured")),
+                          "verdict": ("within 10 % of the model" if abs(measured / predicted - 1.0) <= 0.10 else
+                                      "OFF the model by more than 10 %: look at per_rank / allreduce before trusting the value")}
+        except Exception as exc:
+            self_check = {"skipped": "%s: %s" % (type(exc).__name__, exc)}
 
     # ---- the same step followed by the fused Adam update (one extra launch), reported next to the headline.
     # Parameters and gradients are flat buffers here, so the step is re-captured against the flat storage.
@@ -574,6 +614,8 @@ def main():
             out["per_rank"] = {"ms_per_step": [x[0] for x in per_rank], "utterances": [x[1] for x in per_rank]}
             if shard_info is not None:
                 out["shard"] = shard_info
+            if self_check is not None:
+                out["self_check"] = self_check
         if dp is not None and dp.flat is not None:
             out["gradient_bucket"] = {"floats": dp.flat.numel(), "bytes": dp.flat.numel() * 4, "backend": a.backend}
         if not a.no_roofline:

@@ -19,9 +19,10 @@ from torch.utils.data import DataLoader, Dataset, Sampler
 from torch.utils.data.sampler import SubsetRandomSampler
 
 
-def _odd_feature(t):
+def _odd_feature(t, slot):
+    """``slot``: the tensor's position in the reference's batch tuple (textf, visuf, acouf, qmask, umask, label)."""
     from . import ops
-    return ops.is_odd_feature_tensor(t)
+    return ops.is_odd_feature_tensor(t, slot in ops.FEATURE_SLOTS)
 
 
 def _collate(data):
@@ -255,7 +256,7 @@ class DevicePrefetcher:
         with torch.cuda.stream(stream):
             dev = []
             for slot, t in enumerate(tensors):
-                if _odd_feature(t):
+                if _odd_feature(t, slot):
                     # feature width not a multiple of 4 (1582-d audio, 342-d visual features): the pinned staging buffer
                     # is row-padded to the next multiple of 4 (pad columns zero), so the device copy is the operand the
                     # MFMA kernels fetch in 16-byte units (ops.py "row padding") -- no pad launch on the device
@@ -265,7 +266,7 @@ class DevicePrefetcher:
                     hn = h.numpy()
                     hn[..., :K] = t.numpy()
                     hn[..., K:] = 0.0
-                    base = ops.register_row_padded(h.to(self.device, non_blocking=True))
+                    base = ops.register_row_padded(h.to(self.device, non_blocking=True), K=K)
                     view = base[..., :K]
                     view._mmdfn_padbase = base
                     dev.append(view)

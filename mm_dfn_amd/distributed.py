@@ -127,13 +127,21 @@ def register_slots(flat, params):
     off = 0
     for p in params:
         if _row_padded(p):
-            ops.register_row_padded(flat, (flat.storage_offset() + off, p.shape[0], (p.shape[1] + 3) & ~3))
+            ops.register_row_padded(flat, (flat.storage_offset() + off, p.shape[0], (p.shape[1] + 3) & ~3), K=p.shape[1])
         off += slot_size(p)
 
 
 # parameters whose gradients are complete when the graph part of the backward pass ends (graph stack, fusion modules, head):
 # the first part of a two-part bucket
 EARLY_PREFIXES = ("graph_model.", "graph_net_", "smax_fc.", "mfn.", "gatedatt.")
+# ... except the speaker / modality embeddings of MM_GCN (use_speaker / use_modal): they are added to the features BEFORE the
+# adjacency is built, so their gradients come out of the adjacency builder's backward, i.e. after the point where the first
+# part is packed (with them in the early part the two-part path never engaged, or packed incomplete gradients)
+LATE_EXCEPTIONS = ("speaker_embeddings", "modal_embeddings", "_spk_embs")
+
+
+def is_early(name):
+    return name.startswith(EARLY_PREFIXES) and not any(tag in name for tag in LATE_EXCEPTIONS)
 
 
 class GradientBucket:
@@ -167,8 +175,8 @@ class GradientBucket:
         self.params = bucket_order(self.model, live)
         if self.parts == 2:
             names = {id(p): n for n, p in self.model.named_parameters()}
-            early = [p for p in self.params if names[id(p)].startswith(EARLY_PREFIXES)]
-            late = [p for p in self.params if not names[id(p)].startswith(EARLY_PREFIXES)]
+            early = [p for p in self.params if is_early(names[id(p)])]
+            late = [p for p in self.params if not is_early(names[id(p)])]
             self.params = early + late
             self._n_early = len(early)
             self.split = sum(slot_size(p) for p in early)
@@ -234,7 +242,16 @@ class GradientBucket:
         early = self.params[:self._n_early]
         ops.flush_queued_wgrads_now()                  # weight gradients queued so far (all of them belong to this part)
         if any(p.grad is None for p in early):
-            return                                     # not complete (an unusual graph): this step reduces in one piece
+            # not complete (an unusual graph): this step reduces in one piece -- said once, a silent fallback hides that the
+            # overlap never engages
+            if not getattr(self, "_warned_incomplete", False):
+                import warnings
+                names = {id(p): n for n, p in self.model.named_parameters()}
+                missing = [names.get(id(p), "?") for p in early if p.grad is None]
+                warnings.warn("GradientBucket(parts=2): %d early-part gradients are not ready where the graph part of the "
+                              "backward pass ends (%s ...); reducing in one piece" % (len(missing), ", ".join(missing[:3])))
+                self._warned_incomplete = True
+            return
         torch.cat([piece for p in early for piece in slot_pieces(p.grad, p)], out=self.flat[:self.split])
         self._early = "packed"
         part = self.flat[:self.split]

@@ -46,25 +46,33 @@ def pad4(n):
     return (int(n) + 3) & ~3
 
 
-def is_odd_feature_tensor(t):
+# positions of the FEATURE tensors in the reference's batch tuple (textf, visuf, acouf, qmask, umask, label), run_train_erc.py:169
+FEATURE_SLOTS = (0, 1, 2)
+
+
+def is_odd_feature_tensor(t, is_feature):
     """An (L, B, D) fp32 FEATURE tensor whose width is not a multiple of 4 (1582-d audio, 342-d visual): what the data
-    pipeline stages row-padded.  The speaker mask (L, B, P) has the same rank and dtype; its P <= 9 columns are not a
-    contraction width and it stays as it is (padding it made every step copy it back into a contiguous tensor)."""
-    return t.dim() == 3 and t.dtype == torch.float32 and t.shape[-1] % 4 != 0 and t.shape[-1] > 16
+    pipeline stages row-padded.  ``is_feature`` is the tensor's ROLE, stated by the caller (its slot in the batch tuple is in
+    FEATURE_SLOTS): the speaker mask (L, B, P) has the same rank and dtype and is never padded whatever P is (a width
+    heuristic took a 12-d feature stream for a mask and a 17-speaker mask for features)."""
+    return bool(is_feature) and t.dim() == 3 and t.dtype == torch.float32 and t.shape[-1] % 4 != 0
 
 
-def register_row_padded(base, region=None):
-    """``base``: a contiguous (..., Kp) fp32 tensor whose columns past the logical width are zero and stay zero (nobody
-    writes them).  Views of its leading columns are recognised as row-padded operands WHILE THE ``base`` OBJECT IS ALIVE
+def register_row_padded(base, region=None, K=None):
+    """``base``: a contiguous (..., Kp) fp32 tensor whose columns past the logical width ``K`` are zero and stay zero (nobody
+    writes them).  Views of its leading K columns are recognised as row-padded operands WHILE THE ``base`` OBJECT IS ALIVE
     (the registry holds a weak reference: whoever stages the buffer keeps it).  ``region = (storage offset, rows, Kp)``
-    registers a padded block inside a larger flat buffer ``base`` (FlatAdam's parameter slots)."""
+    registers a padded block inside a larger flat buffer ``base`` (FlatAdam's parameter slots).  ``K``: the logical width; a
+    view of FEWER columns with the same padded width (x[:, :K-1]) is then NOT taken for a zero-padded operand (its column
+    K-1 holds data) -- None accepts any width that pads to Kp (callers that do not know K)."""
     import weakref
     if region is None:
         b2 = base.view(-1, base.shape[-1])
         region = (b2.storage_offset(), b2.shape[0], b2.shape[1])
+    region = tuple(int(v) for v in region)[:3] + (None if K is None else int(K),)
     key = base.untyped_storage().data_ptr()
-    live = [e for e in _PAD_REG.get(key, []) if e[0]() is not None and (e[0]() is not base or e[1:] != tuple(region))]
-    live.append((weakref.ref(base),) + tuple(int(v) for v in region))
+    live = [e for e in _PAD_REG.get(key, []) if e[0]() is not None and (e[0]() is not base or e[1:] != region)]
+    live.append((weakref.ref(base),) + region)
     _PAD_REG[key] = live
     if len(_PAD_REG) > 4096:                      # stale keys of freed buffers
         for k in [k for k, v in _PAD_REG.items() if all(e[0]() is None for e in v)]:
@@ -80,7 +88,7 @@ def padded_zeros(shape, device, keep=None):
     base = torch.zeros(*lead, Kp, dtype=torch.float32, device=device)
     if Kp == K:
         return base
-    register_row_padded(base)
+    register_row_padded(base, K=K)
     if keep is not None:
         keep.append(base)
     view = base[..., :K]
@@ -105,8 +113,8 @@ def row_padded_view(x2):
     ents = _PAD_REG.get(x2.untyped_storage().data_ptr())
     if not ents or x2.data_ptr() % 16:
         return None
-    for ref, off, rows, width in ents:
-        if ref() is None or width != Kp:
+    for ref, off, rows, width, logical in ents:
+        if ref() is None or width != Kp or (logical is not None and logical != K):
             continue
         rel = x2.storage_offset() - off
         if rel < 0 or rel % Kp or rel // Kp + R > rows or (R > 1 and x2.stride(0) != Kp):
@@ -136,7 +144,7 @@ def ensure_row_padded(p):
     with torch.no_grad():
         base = torch.zeros(p.shape[0], pad4(p.shape[1]), dtype=p.dtype, device=p.device)
         base[:, :p.shape[1]].copy_(p.data)
-        register_row_padded(base)
+        register_row_padded(base, K=p.shape[1])
         p.data = base[:, :p.shape[1]]
         p._mmdfn_padbase = base
         if p.grad is not None:
@@ -149,7 +157,7 @@ def padded_grad_like(p, g=None, zero=True):
     ``g``), or uninitialised when the caller's kernel writes every one of the Kp columns (the weight-gradient batch does:
     the pad columns come out as dY^T . 0)."""
     base = (torch.zeros if zero else torch.empty)(p.shape[0], pad4(p.shape[1]), dtype=torch.float32, device=p.device)
-    register_row_padded(base)
+    register_row_padded(base, K=p.shape[1])
     view = base[:, :p.shape[1]]
     view._mmdfn_padbase = base
     if g is not None:

@@ -57,16 +57,16 @@ def make_batch(seed, B, L, P, C, D_t, D_a, D_v, ragged=False, lengths=None, devi
         qmask[np.arange(n), b, spk[:n, b]] = 1
         umask[b, :n] = 1
         lab[b, n:] = 0
-    def t(a):
+    def t(a, feature=False):
         x = torch.from_numpy(a).to(device)
         from . import ops
-        if x.is_cuda and ops.is_odd_feature_tensor(x):
+        if x.is_cuda and ops.is_odd_feature_tensor(x, feature):
             # a feature width that is not a multiple of 4 (1582-d audio, 342-d visual): staged row-padded, as the data
             # pipeline does (ops.py "row padding"; same values, the modules see the (L, B, D) view)
             return ops.pad_rows(x)
         return x
 
-    return dict(textf=t(textf), visuf=t(visuf), acouf=t(acouf), qmask=t(qmask), umask=t(umask), label=t(lab),
+    return dict(textf=t(textf, True), visuf=t(visuf, True), acouf=t(acouf, True), qmask=t(qmask), umask=t(umask), label=t(lab),
                 lengths=[int(x) for x in lens])
 
 
@@ -112,16 +112,16 @@ def make_stream_batch(seed, B, L, P, C, D_streams, ragged=False, lengths=None, d
         qmask[np.arange(n), b, spk[:n, b]] = 1
         umask[b, :n] = 1
         lab[b, n:] = 0
-    def t(a):
+    def t(a, feature=False):
         x = torch.from_numpy(a).to(device)
         from . import ops
-        if x.is_cuda and ops.is_odd_feature_tensor(x):
+        if x.is_cuda and ops.is_odd_feature_tensor(x, feature):
             # a feature width that is not a multiple of 4 (1582-d audio, 342-d visual): staged row-padded, as the data
             # pipeline does (ops.py "row padding"; same values, the modules see the (L, B, D) view)
             return ops.pad_rows(x)
         return x
 
-    return dict(streams=[t(s_) for s_ in streams], qmask=t(qmask), umask=t(umask), label=t(lab),
+    return dict(streams=[t(s_, True) for s_ in streams], qmask=t(qmask), umask=t(umask), label=t(lab),
                 lengths=[int(x) for x in lens])
 
 

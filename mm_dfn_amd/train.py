@@ -123,8 +123,8 @@ class StepGraphCache:
         if ent is None:
             self.misses += 1
             # (feature widths that are not multiples of 4 get row-padded static buffers: ops.py "row padding")
-            static = [ops.pad_rows(t) if ops.is_odd_feature_tensor(t) else t.clone()
-                      for t in inputs]
+            static = [ops.pad_rows(t) if ops.is_odd_feature_tensor(t, i in ops.FEATURE_SLOTS) else t.clone()
+                      for i, t in enumerate(inputs)]
             textf, visuf, acouf, qmask, umask, label = static
             # dialogue-major label flatten (run_train_erc.py:201) as a static gather: a boolean-mask select has a
             # data-dependent shape and cannot be captured

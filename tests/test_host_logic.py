@@ -261,10 +261,14 @@ def test_only_feature_tensors_are_row_padded():
     """Row padding (ops.py) is for contraction operands: an (L, B, D) feature tensor with D % 4 != 0.  The speaker mask
     (L, B, P) has the same rank and dtype and stays as it is -- padding it made every step copy it back."""
     from mm_dfn_amd import ops
-    assert ops.is_odd_feature_tensor(torch.zeros(5, 3, 342))
-    assert ops.is_odd_feature_tensor(torch.zeros(5, 3, 1582))
-    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 100))
-    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 2))           # qmask, two speakers
-    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 9))           # qmask, MELD
-    assert not ops.is_odd_feature_tensor(torch.zeros(3, 5))              # umask
-    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 342, dtype=torch.int64))
+    assert ops.is_odd_feature_tensor(torch.zeros(5, 3, 342), True)
+    assert ops.is_odd_feature_tensor(torch.zeros(5, 3, 1582), True)
+    assert ops.is_odd_feature_tensor(torch.zeros(5, 3, 10), True)               # a narrow feature stream is still a feature stream
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 100), True)
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 2), False)           # qmask, two speakers
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 9), False)           # qmask, MELD
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 17), False)          # qmask of a 17-speaker corpus: the role decides
+    assert not ops.is_odd_feature_tensor(torch.zeros(3, 5), False)              # umask
+    assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 342, dtype=torch.int64), True)
+    # the role is the slot in the reference's batch tuple (textf, visuf, acouf, qmask, umask, label)
+    assert ops.FEATURE_SLOTS == (0, 1, 2)
