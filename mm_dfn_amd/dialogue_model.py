@@ -93,10 +93,11 @@ class DialogueGNNModel(nn.Module):
             raise NotImplementedError("att_type must be 'concat_subsequently' (the MM-DFN scripts) or 'mfn'")
         if graph_type == 'DeepGCN' and att_type not in ('concat_subsequently', 'gated'):
             raise NotImplementedError("DeepGCN: att_type must be 'concat_subsequently' or 'gated'")
-        if av_using_lstm:
-            raise NotImplementedError("av_using_lstm=True is not part of the MM-DFN configuration")
-        if sorted(modals) != ['a', 'l', 'v']:
-            raise NotImplementedError("the GDF path is trimodal ('avl')")
+        present = [m for m in 'avl' if m in modals]
+        if sorted(modals) != sorted(present) or len(present) < 2:
+            raise NotImplementedError("modals must name two or three of 'a', 'v', 'l' (model_mm.py:97-106), got %r" % (modals,))
+        if len(present) < 3 and (graph_type != 'GDF' or att_type != 'concat_subsequently'):
+            raise NotImplementedError("two-modality graphs: graph_type='GDF' with att_type='concat_subsequently' only")
         if 2 * D_e != 200:
             raise NotImplementedError("the reference hard-codes a 200-wide encoder (model.py:847-849,1074); D_e must be 100")
         self.base_model = base_model
@@ -108,6 +109,8 @@ class DialogueGNNModel(nn.Module):
         self.use_residue = use_residue
         self.return_feature = True
         self.modals = [x for x in modals]
+        self.present = present                  # modalities in the order the graph stacks them: a, v, l (model_mm.py:98-104)
+        self.av_using_lstm = av_using_lstm
         self.use_speaker = use_speaker
         self.use_modal = use_modal
         self.att_type = att_type
@@ -123,12 +126,21 @@ class DialogueGNNModel(nn.Module):
         self.nodal_attention = nodal_attention
 
         hidden = 2 * D_e
-        self.linear_a = nn.Linear(D_m_a, hidden)
-        self.linear_v = nn.Linear(D_m_v, hidden)
-        self.linear_l = nn.Linear(D_m, hidden)
-        self.lstm_l = nn.GRU(input_size=hidden, hidden_size=D_e, num_layers=2, bidirectional=True, dropout=dropout)
-        self.rnn_parties = nn.GRU(input_size=hidden, hidden_size=D_e, num_layers=2, bidirectional=True,
-                                  dropout=dropout)
+        # model.py:851-868: only the modules of the modalities in ``modals`` exist (and with them the state_dict keys); the
+        # audio / visual streams get a context GRU of their own with av_using_lstm (keys lstm_a.* / lstm_v.*)
+        gru = lambda: nn.GRU(input_size=hidden, hidden_size=D_e, num_layers=2, bidirectional=True, dropout=dropout)
+        if 'a' in present:
+            self.linear_a = nn.Linear(D_m_a, hidden)
+            if av_using_lstm:
+                self.lstm_a = gru()
+        if 'v' in present:
+            self.linear_v = nn.Linear(D_m_v, hidden)
+            if av_using_lstm:
+                self.lstm_v = gru()
+        if 'l' in present:
+            self.linear_l = nn.Linear(D_m, hidden)
+            self.lstm_l = gru()
+        self.rnn_parties = gru()
         self.att_model = _EdgeAttentionParams(hidden, max_seq_len)
         if graph_type == 'DeepGCN':
             # one unimodal GCNII per modality, lamda / alpha hard-wired (model.py:922-941)
@@ -159,63 +171,73 @@ class DialogueGNNModel(nn.Module):
         return fused_gru.bigru2(xs, grus, self.dropout, self.training)
 
     def encode(self, U, qmask, seq_lengths, U_a, U_v):
-        """Projection + context BiGRU (text) + speaker-party BiGRU (all modalities) ->
-        (3, N, 200) dialogue-major stack in the order a, v, l (model.py:1062-1154,1183-1209).
-        The context GRU and the batched party GRU are independent and share every recurrence launch;
-        the party gather / scatter / pad-strip are the fused K3/K4 kernels (csrc/encoder_glue.hip)."""
+        """Projection + context BiGRUs (text; audio / visual too with av_using_lstm) + speaker-party BiGRU (every modality with
+        a non-zero speaker weight) -> (M, N, 200) dialogue-major stack of the modalities in ``modals``, order a, v, l
+        (model.py:1062-1154,1183-1209).  All GRUs are independent and share every recurrence launch; the party gather /
+        scatter / pad-strip are the fused K3/K4 kernels (csrc/encoder_glue.hip)."""
+        present = self.present
+        raw = {'a': U_a, 'v': U_v, 'l': U}
+        lin = {m: getattr(self, "linear_" + m) for m in present}
+        L, B = raw[present[0]].shape[0], raw[present[0]].shape[1]
+        P = qmask.shape[2]
+        wts = dict(zip('avl', self.speaker_weights))
+        # modalities with a context GRU of their own (model.py:1067-1068,1096-1097,1132)
+        ctx_mods = [m for m in present if m == 'l' or self.av_using_lstm]
+        ctx_grus = [getattr(self, "lstm_" + m) for m in ctx_mods]
+        # only modalities with a non-zero speaker weight go through the party encoder: the reference also encodes the others
+        # and multiplies the result by 0 (model.py:1090,1121,1154 with '3-0-1'), which changes neither the features nor any
+        # gradient
+        act = [m for m in present if self.use_crn_speaker and wts[m] != 0.0]
         # valid-length launches of the party encoder (gru.py TRUNCATE): their all-padding sequence depends on the weights only
-        # and starts NOW, on a side stream, under the projections and the gather
-        table = None
-        n_act = sum(1 for w in self.speaker_weights if w != 0.0)
-        L_, B_, P_ = U.shape[0], U.shape[1], qmask.shape[2]
-        truncate = (self.use_crn_speaker and n_act and P_ <= 16 and P_ * L_ <= 2048
-                    and fused_gru.wants_truncation(B_ + n_act * B_ * P_))
+        # and starts on a side stream, under the gather
+        truncate = bool(act) and P <= 16 and P * L <= 2048 and fused_gru.wants_truncation(len(ctx_mods) * B + len(act) * B * P)
         use_table = truncate and fused_gru.USE_TABLE
         if use_table:
             fork = torch.cuda.Event()
             fork.record()
-        Xa, Xv, Xl = ops.linear_group([U_a, U_v, U], [self.linear_a.weight, self.linear_v.weight, self.linear_l.weight],
-                                      [self.linear_a.bias, self.linear_v.bias, self.linear_l.bias])
+        proj = ops.linear_group([raw[m] for m in present], [lin[m].weight for m in present], [lin[m].bias for m in present])
+        X = dict(zip(present, proj))
+        idx = _flat_index([int(x) for x in seq_lengths], L, B, proj[0].device)
+        table = None
         if use_table:
             # (launched behind the projections in program order, so the main stream's first kernel is not held up by the
             # side branch's launches; ordered behind the point BEFORE them)
-            table = fused_gru.start_party_table(self.rnn_parties, L_, after=fork)
-        L, B, H = Xa.shape
-        idx = _flat_index([int(x) for x in seq_lengths], L, B, Xa.device)
-        if self.use_crn_speaker:
-            # only modalities with a non-zero speaker weight go through the party encoder: the reference also encodes
-            # the others and multiplies the result by 0 (model.py:1090,1121,1154 with '3-0-1'), which changes neither
-            # the features nor any gradient
-            Xs = [Xa, Xv, Xl]
-            act = [x for x, w in zip(Xs, self.speaker_weights) if w != 0.0]
-            P = qmask.shape[2]
-            if act and (len(act) * L * B * P >= PROJECT_THEN_GATHER_ROWS or P >= 4):
-                # first party-GRU layer: gather(X) W_ih^T + b == gather(X W_ih^T) + b (padding rows = b), so the input
-                # contraction runs over the n_act*L*B projected utterances, not over the n_act*L*P*B party rows of
-                # which all but one in P are zero (the reference projects every padded party row, model.py:1082).
-                # Pays off once the party batch is large (measured: cfg4 2.27 -> 2.22 ms, cfg3 2.25 -> 2.19 ms; at
-                # cfg2's 7040 party rows the extra small launches cost more than the halved GEMMs save: 1.146 vs
-                # 1.125 ms per step, tools/ab_project_then_gather.py, round 2)
-                w_ih, b_ih, _ = fused_gru._layer_params(self.rnn_parties, 0)
-                gi_p, rank, *passed = ops.project_gather(act, qmask, w_ih[0], w_ih[1], b_ih[0], b_ih[1],
-                                                         fused_gru._stacked_view(*w_ih), fused_gru._stacked_view(*b_ih))
-                passed = iter(passed)
-                Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
-                ctx, E = fused_gru.bigru2([Xl_, None], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
-                                          gi0=[None, gi_p], party=(1, rank, table) if truncate else None)
-                return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
-            if act:
-                # the gathered modalities come back as identities (passthrough): the combine stage below reads those, so
-                # each projected modality has one consumer and its two gradient paths meet inside the gather's backward
-                S, rank, *passed = ops.party_gather(act, qmask, passthrough=True)
-                passed = iter(passed)
-                Xa, Xv, Xl_ = [next(passed) if w != 0.0 else x for x, w in zip(Xs, self.speaker_weights)]
-                ctx, E = fused_gru.bigru2([Xl_, S], [self.lstm_l, self.rnn_parties], self.dropout, self.training,
-                                          party=(1, rank, table) if truncate else None)
-                return ops.party_combine([Xa, Xv, ctx], E, rank, idx, self.speaker_weights)
-        ctx = self._run_grus([Xl], [self.lstm_l])[0]
-        rank = torch.full((L, B, qmask.shape[2]), -1, dtype=torch.int32, device=Xa.device)
-        return ops.party_combine([Xa, Xv, ctx], None, rank, idx, [0.0, 0.0, 0.0])
+            table = fused_gru.start_party_table(self.rnn_parties, L, after=fork)
+        weights = [wts[m] if m in act else 0.0 for m in present]
+        if not act:
+            outs = self._run_grus([X[m] for m in ctx_mods], ctx_grus) if ctx_mods else []
+            base = dict(X)
+            base.update(zip(ctx_mods, outs))
+            rank = torch.full((L, B, P), -1, dtype=torch.int32, device=proj[0].device)
+            return ops.party_combine([base[m] for m in present], None, rank, idx, [0.0] * len(present))
+        party = None
+        if len(act) * L * B * P >= PROJECT_THEN_GATHER_ROWS or P >= 4:
+            # first party-GRU layer: gather(X) W_ih^T + b == gather(X W_ih^T) + b (padding rows = b), so the input
+            # contraction runs over the n_act*L*B projected utterances, not over the n_act*L*P*B party rows of
+            # which all but one in P are zero (the reference projects every padded party row, model.py:1082).
+            # Pays off once the party batch is large (measured: cfg4 2.27 -> 2.22 ms, cfg3 2.25 -> 2.19 ms; at
+            # cfg2's 7040 party rows the extra small launches cost more than the halved GEMMs save: 1.146 vs
+            # 1.125 ms per step, tools/ab_project_then_gather.py, round 2)
+            w_ih, b_ih, _ = fused_gru._layer_params(self.rnn_parties, 0)
+            gi_p, rank, *passed = ops.project_gather([X[m] for m in act], qmask, w_ih[0], w_ih[1], b_ih[0], b_ih[1],
+                                                     fused_gru._stacked_view(*w_ih), fused_gru._stacked_view(*b_ih))
+            X.update(zip(act, passed))          # the gathered modalities come back as identities (one consumer each)
+            if truncate:
+                party = (len(ctx_mods), rank, table)
+            outs = fused_gru.bigru2([X[m] for m in ctx_mods] + [None], ctx_grus + [self.rnn_parties], self.dropout,
+                                    self.training, gi0=[None] * len(ctx_mods) + [gi_p], party=party)
+        else:
+            # the gathered modalities come back as identities (passthrough): the combine stage below reads those, so
+            # each projected modality has one consumer and its two gradient paths meet inside the gather's backward
+            S, rank, *passed = ops.party_gather([X[m] for m in act], qmask, passthrough=True)
+            X.update(zip(act, passed))
+            if truncate:
+                party = (len(ctx_mods), rank, table)
+            outs = fused_gru.bigru2([X[m] for m in ctx_mods] + [S], ctx_grus + [self.rnn_parties], self.dropout,
+                                    self.training, party=party)
+        base = dict(X)
+        base.update(zip(ctx_mods, outs[:-1]))
+        return ops.party_combine([base[m] for m in present], outs[-1], rank, idx, weights)
 
     # ------------------------------------------------------------------ forward
     def forward(self, U, qmask, umask, seq_lengths, U_a=None, U_v=None, test_label=False):
@@ -224,8 +246,9 @@ class DialogueGNNModel(nn.Module):
             return self._forward(U, qmask, umask, seq_lengths, U_a, U_v, test_label)
 
     def _forward(self, U, qmask, umask, seq_lengths, U_a, U_v, test_label):
-        if U_a is None or U_v is None:
-            raise ValueError("the trimodal GDF path needs U_a and U_v")
+        if ('a' in self.present and U_a is None) or ('v' in self.present and U_v is None):
+            raise ValueError("modals=%r needs %s" % (''.join(self.present), "U_a and U_v" if len(self.present) == 3 else
+                                                     "U_a" if 'a' in self.present and U_a is None else "U_v"))
         feats = self.encode(U, qmask, seq_lengths, U_a, U_v)
         if self.graph_type == 'DeepGCN':
             # model.py:1242-1290: three independent unimodal graphs, fused after the graph stage;
@@ -240,7 +263,8 @@ class DialogueGNNModel(nn.Module):
         # cat([a, v, l], -1) of model_mm.py:113-117 and its backward are never materialised
         stacked = self.att_type != 'mfn'
         if self.use_speaker or self.use_modal:
-            fused = self.graph_model(feats[0], feats[1], feats[2], seq_lengths, qmask, test_label, stacked)
+            by = dict(zip(self.present, (feats[i] for i in range(len(self.present)))))
+            fused = self.graph_model(by.get('a', []), by.get('v', []), by.get('l', []), seq_lengths, qmask, test_label, stacked)
         else:
             fused = self.graph_model.forward_stacked(feats, seq_lengths, qmask, test_label, stacked)
         if test_label:

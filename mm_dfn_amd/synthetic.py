@@ -84,13 +84,13 @@ def seeded_state_dict(reference_state, seed, scale=1.0):
 
 
 def build_model(D_t, D_a, D_v, P, C, nlayers, dropout=0.0, speaker_weights="3-0-1", att_type="concat_subsequently",
-                graph_type="GDF", reason_flag=True, **_):
+                graph_type="GDF", reason_flag=True, modals="avl", av_using_lstm=False, **_):
     """The MM-DFN configuration of run_train_erc.py:418-452 + the IEMOCAP script flags."""
     from .dialogue_model import DialogueGNNModel
     return DialogueGNNModel("LSTM", D_t, 150, 150, 100, 100, 100, 100, n_speakers=P, max_seq_len=200,
                             window_past=10, window_future=10, n_classes=C, dropout=dropout, no_cuda=False,
-                            graph_type=graph_type, alpha=0.2, lamda=0.5, D_m_v=D_v, D_m_a=D_a, modals="avl",
-                            att_type=att_type, Deep_GCN_nlayers=nlayers, dataset="IEMOCAP",
+                            graph_type=graph_type, alpha=0.2, lamda=0.5, D_m_v=D_v, D_m_a=D_a, modals=modals,
+                            att_type=att_type, av_using_lstm=av_using_lstm, Deep_GCN_nlayers=nlayers, dataset="IEMOCAP",
                             use_speaker=False, use_modal=False, reason_flag=reason_flag, multi_modal=True,
                             use_crn_speaker=True, speaker_weights=speaker_weights)
 

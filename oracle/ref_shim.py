@@ -75,7 +75,7 @@ def modules():
 
 def build_reference_model(D_t, D_a, D_v, n_speakers, n_classes, nlayers, dropout=0.0,
                           speaker_weights="3-0-1", modals="avl", reason_flag=True,
-                          att_type="concat_subsequently", alpha=0.2, lamda=0.5, graph_type="GDF"):
+                          att_type="concat_subsequently", alpha=0.2, lamda=0.5, graph_type="GDF", av_using_lstm=False):
     """The MM-DFN configuration of run_train_erc.py:418-452 + script flags."""
     ref_model, _, _, _ = modules()
     import contextlib, io
@@ -86,5 +86,5 @@ def build_reference_model(D_t, D_a, D_v, n_speakers, n_classes, nlayers, dropout
             graph_type=graph_type, alpha=alpha, lamda=lamda, D_m_v=D_v, D_m_a=D_a, modals=modals,
             att_type=att_type, Deep_GCN_nlayers=nlayers, dataset="IEMOCAP",
             use_speaker=False, use_modal=False, reason_flag=reason_flag, multi_modal=True,
-            use_crn_speaker=True, speaker_weights=speaker_weights)
+            use_crn_speaker=True, speaker_weights=speaker_weights, av_using_lstm=av_using_lstm)
     return m

@@ -80,6 +80,56 @@ def export_e2e():
         print(name, "N=%d" % sum(lengths), "loss", loss.item(), "train-vs-eval", out["train_log_prob_maxdiff"])
 
 
+VARIANT_CASES = {
+    # name: (modals, av_using_lstm, speaker_weights, cfg, seed, lengths) -- the two flags of the same GDF path the reference driver
+    # exposes next to the MM-DFN scripts' setting (run_train_erc.py --modals, --av_using_lstm; model.py:851-868,1067,1096)
+    "av": ("av", False, "3-0-1", dict(B=3, L=20, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512), 111, [20, 13, 7]),
+    "al": ("al", False, "3-0-1", dict(B=3, L=20, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512), 112, [20, 13, 7]),
+    "vl": ("vl", False, "1-2-1", dict(B=4, L=17, P=3, C=7, nlayers=3, D_t=100, D_a=100, D_v=342), 113, [17, 9, 1, 12]),
+    "avl_lstm": ("avl", True, "3-0-1", dict(B=3, L=20, P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512), 114, [20, 13, 7]),
+    "al_lstm": ("al", True, "1-1-1", dict(B=2, L=15, P=2, C=6, nlayers=2, D_t=100, D_a=1582, D_v=342), 115, [15, 6]),
+}
+
+
+def export_variants():
+    """Bimodal graphs and av_using_lstm: eval log-probabilities, loss, gradient digests of every live parameter, a few
+    full gradients, and the state_dict key list (the modules of absent modalities do not exist in the reference)."""
+    _, _, _, ref_loss = ref_shim.modules()
+    out = {}
+    for name, (modals, lstm, sw, cfg, seed, lengths) in VARIANT_CASES.items():
+        batch = synthetic.make_batch(seed + 1, lengths=lengths, **cfg)
+        args = (batch["textf"], batch["qmask"], batch["umask"], batch["lengths"], batch["acouf"], batch["visuf"])
+
+        def build(dropout):
+            m = ref_shim.build_reference_model(cfg["D_t"], cfg["D_a"], cfg["D_v"], cfg["P"], cfg["C"], cfg["nlayers"],
+                                               dropout=dropout, speaker_weights=sw, modals=modals, av_using_lstm=lstm)
+            m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), seed))
+            return m
+        m = build(0.0).eval()
+        with torch.no_grad():
+            out[name + "/log_prob"] = m(*args)[0].numpy()
+        with open(os.path.join(HERE, "state_dict_keys_variant_%s.txt" % name), "w") as f:
+            for k, v in m.state_dict().items():
+                f.write("%s %s\n" % (k, " ".join(str(d) for d in v.shape)))
+        m = build(TINY).train()
+        logp = m(*args)[0]
+        label = torch.cat([batch["label"][j][:n] for j, n in enumerate(batch["lengths"])])
+        loss = ref_loss.FocalLoss(gamma=0.5)(logp, label)
+        loss.backward()
+        out[name + "/loss"] = np.array(loss.item(), dtype=np.float64)
+        live = []
+        for k, p in m.named_parameters():
+            if p.grad is not None and float(p.grad.abs().max()) > 0:
+                live.append(k)
+                out[name + "/gd/" + k] = grad_digest(p.grad)
+        out[name + "/live_params"] = np.array(live)
+        for k in ("smax_fc.weight", "rnn_parties.weight_hh_l0", "graph_model.graph_net.convs.0.weight") + \
+                (("lstm_a.weight_hh_l1_reverse",) if lstm and "a" in modals else ()):
+            out[name + "/g/" + k] = dict(m.named_parameters())[k].grad.numpy()
+        print("variant", name, "N=%d" % sum(lengths), "loss", loss.item(), "live", len(live), "keys", len(m.state_dict()))
+    np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
+
+
 def export_adjacency():
     ref = ref_shim.build_reference_model(100, 100, 512, 2, 6, 2)
     out = {}
@@ -300,6 +350,10 @@ def export_state_keys():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--variants-only" in sys.argv:          # (round 5: the bimodal / av_using_lstm fixtures, without touching the others)
+        export_variants()
+        sys.exit(0)
+    export_variants()
     export_state_keys()
     export_fusion_modules()
     export_encoders_and_graphconv()

@@ -611,3 +611,50 @@ def test_odd_feature_widths_training_trajectory_flat_adam_vs_torch_adam():
     for i in (1, 2):
         assert float((traj["torch"][i] - traj["flat"][i]).abs().max()) < 5e-5
         assert float((traj["torch"][i] - sd["linear_a.weight" if i == 1 else "linear_v.weight"]).abs().max()) > 1e-5   # it moved
+
+
+def test_thirty_step_trajectory_flat_adam_vs_torch_adam_at_the_reference_widths():
+    """the captured step + FlatAdam + row-padded parameters against torch.optim.Adam over THIRTY steps (the
+    3-step tests above cannot see a slow drift): losses step by step, and every parameter at the end, on six different
+    ragged batches cycled through the captured-step cache (so every signature is replayed several times) with the party
+    encoder on the valid-length launches.  Adam divides by sqrt(v) + eps: a gradient difference at fp32 rounding level moves
+    a parameter whose second moment is tiny by a visible amount, so the bound on the parameters is relative to the distance
+    they travelled."""
+    from mm_dfn_amd.optim import FlatAdam
+    from mm_dfn_amd import gru as fused
+    lens = [[23, 9, 17], [19, 19, 4], [23, 2, 11], [8, 23, 15], [23, 23, 23], [5, 6, 7]]
+    sd = None
+    traj = {}
+    prev, fused.TRUNCATE = fused.TRUNCATE, True
+    try:
+        for kind in ("torch", "flat"):
+            m = synthetic.build_model(dropout=0.0, **REF_DIMS)
+            sd = sd or synthetic.seeded_state_dict(m.state_dict(), 3)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            opt = (torch.optim.Adam(m.parameters(), lr=3e-4, weight_decay=1e-4) if kind == "torch"
+                   else FlatAdam(m, lr=3e-4, weight_decay=1e-4))
+            cache = T.StepGraphCache(m, FocalLoss(gamma=0.5))
+            losses = []
+            for step in range(30):
+                lengths = lens[step % len(lens)]
+                b = synthetic.make_batch(40 + step % len(lens), lengths=lengths, device="cuda", B=3, L=23, **REF_DIMS)
+                loss, _, _ = cache.step((b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"]), lengths, True)
+                losses.append(float(loss))
+                opt.step()
+            assert cache.hits >= 20
+            traj[kind] = (losses, {k: v.detach().cpu().clone() for k, v in m.named_parameters()})
+    finally:
+        fused.TRUNCATE = prev
+    for a, c in zip(traj["torch"][0], traj["flat"][0]):
+        assert abs(a - c) < 5e-4 * max(1.0, abs(a))
+    assert traj["torch"][0][-1] < traj["torch"][0][0]                    # it trains
+    worst = 0.0
+    for k, a in traj["torch"][1].items():
+        c = traj["flat"][1][k]
+        moved = float((a - sd[k]).abs().max())
+        if moved == 0.0:
+            assert float((c - sd[k]).abs().max()) == 0.0, k              # parameters the path never reaches stay put in both
+            continue
+        worst = max(worst, float((a - c).abs().max()) / moved)
+    assert worst < 0.05, worst
