@@ -620,7 +620,7 @@ def main():
             out["gradient_bucket"] = {"floats": dp.flat.numel(), "bytes": dp.flat.numel() * 4, "backend": a.backend}
         if not a.no_roofline:
             roofline_legs(out, a, dev, n_utt, lengths)
-        out["dominant"] = (profile_json("r04_step_breakdown_%s.json" % a.config) or profile_json("r03_step_breakdown_%s.json" % a.config)
+        out["dominant"] = (profile_json("r05_step_breakdown_%s.json" % a.config) or profile_json("r04_step_breakdown_%s.json" % a.config) or profile_json("r03_step_breakdown_%s.json" % a.config)
                            or profile_json("r02_step_breakdown_%s.json" % a.config))
         if world == 1 and not a.no_extra and not use_dp:
             out["other_workloads"] = []

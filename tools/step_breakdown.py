@@ -14,7 +14,7 @@ import re
 import sys
 
 FAMILIES = [
-    ("gru_recurrence", r"gru_seq_"),
+    ("gru_recurrence", r"gru_seq_|gru_tab_"),
     ("weight_gradients", r"gemm_tn"),
     ("gcn_stack_fused", r"lstm_gate_|gcnii_layer_|gcn_input_|lstm_pointwise|gcnii_combine"),
     ("propagate_K6", r"propagate_"),
@@ -32,7 +32,8 @@ FAMILIES = [
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     calls = {r["Name"]: int(r["Calls"]) for r in rows}
-    steps = max((c for n, c in calls.items() if "gru_seq_fwd" in n), default=0) // 2
+    # two forward recurrence launches per step (one per GRU layer), whichever kernel variants they ran on
+    steps = sum(c for n, c in calls.items() if "gru_seq_fwd" in n) // 2
     if steps <= 0:
         raise SystemExit("no gru_seq_fwd kernel in the trace: cannot tell the step count")
     fam = {k: dict(us_per_step=0.0, launches_per_step=0.0) for k, _ in FAMILIES}
