@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, and the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld). */
+/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, and mmdfn_focal_loss_{fwd,bwd}_ignore). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -432,6 +432,15 @@ int mmdfn_focal_loss_fwd(const float* logp, const int64_t* target, const float* 
                          int64_t N, int C, float gamma, int size_average, void* stream);
 int mmdfn_focal_loss_bwd(const float* coef, const int64_t* target, const float* dloss, float* dlogp, int64_t N, int C,
                          void* stream);
+/* the same with rows to leave out (target == ignore_index: no loss, zero gradient row; the mean divides by the rows that
+ * count, on the device).  An extension of the reference's FocalLoss (loss.py has no ignore_index): train.StepGraphCache pads
+ * a batch to its size bucket with a dummy dialogue labelled ignore_index, so one captured step serves batches with different
+ * numbers of utterances.  scale_out: 1 float (1 / count, or 1 without size_average), handed to the backward. */
+int mmdfn_focal_loss_fwd_ignore(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
+                                float* scale_out, int64_t N, int C, float gamma, int size_average, int64_t ignore_index,
+                                void* stream);
+int mmdfn_focal_loss_bwd_ignore(const float* coef, const int64_t* target, const float* dloss, const float* scale,
+                                float* dlogp, int64_t N, int C, int64_t ignore_index, void* stream);
 
 #ifdef __cplusplus
 }

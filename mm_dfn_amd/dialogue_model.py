@@ -24,7 +24,7 @@ from . import gru as fused_gru
 from . import ops
 from .fusion import MFN, MMGatedAttention
 from .graph_conv import GCNII
-from .layout import PinnedLRU
+from .layout import IndexScope, PinnedLRU
 from .mm_gcn import MM_GCN
 
 _FLAT_CACHE = PinnedLRU(64)
@@ -32,10 +32,12 @@ _FLAT_CACHE = PinnedLRU(64)
 
 def _flat_index(lengths, L, B, device):
     """Row ids t*B+b of the (L*B) padded grid in dialogue-major order (simple_batch_graphify)."""
-    def make():
-        parts = [np.arange(int(n), dtype=np.int64) * B + j for j, n in enumerate(lengths)]
-        return torch.from_numpy(np.concatenate(parts)).to(device)
-    return _FLAT_CACHE.get((tuple(lengths), L, B, str(device)), make)
+    def rows(lens):
+        return np.concatenate([np.arange(int(n), dtype=np.int64) * B + j for j, n in enumerate(lens)])
+    scope = IndexScope.current()
+    if scope is not None:             # a captured step replayed for other length lists owns (and rewrites) its index tensors
+        return scope.tensor(("flat", L, B, str(device)), lengths, rows, device)
+    return _FLAT_CACHE.get((tuple(lengths), L, B, str(device)), lambda: torch.from_numpy(rows(lengths)).to(device))
 
 
 class _Scalar(nn.Module):

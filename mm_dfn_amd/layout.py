@@ -66,6 +66,86 @@ class recording:
 _LAYOUT_CACHE = PinnedLRU(64)
 
 
+class IndexScope:
+    """Owner of the host-built device index tensors of ONE captured step that is replayed for batches with different
+    dialogue lengths (train.StepGraphCache, bucketed entries).  Inside ``with scope:`` the layout / index caches hand out
+    PRIVATE objects (never shared through the LRUs, so re-pointing their contents cannot corrupt another user) and remember
+    how each was built; ``scope.retarget(lengths)`` rewrites all of them, in place, for another batch of the same bucket
+    (same number of dialogues, same total and maximum length): the hipGraph's baked pointers stay valid, only the index
+    data changes.  The kernels read lengths, row offsets and tile offsets from these arrays; their grids depend on
+    (B, M, N, max_len) only."""
+
+    _active = []
+
+    def __init__(self, slots=4):
+        self.layouts = {}           # (M, device) -> DialogueLayout
+        self.tensors = {}           # key -> (device tensor, maker(lengths) -> numpy array)
+        self.lengths = None
+        # pinned staging for retarget(): the host runs ahead of the stream, so a staging buffer is rewritten only after the
+        # copies that read it have executed (a ring of ``slots`` generations, one event each)
+        self._slots = [dict(event=None, bufs={}) for _ in range(max(2, int(slots)))]
+        self._turn = 0
+
+    def __enter__(self):
+        IndexScope._active.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        IndexScope._active.pop()
+        return False
+
+    @staticmethod
+    def current():
+        return IndexScope._active[-1] if IndexScope._active else None
+
+    def layout(self, lengths, M, device):
+        key = (int(M), str(device))
+        lay = self.layouts.get(key)
+        if lay is None:
+            lay = self.layouts[key] = DialogueLayout(lengths, M, device, capacity=True)
+        elif lay.lengths != [int(x) for x in lengths]:
+            raise RuntimeError("IndexScope: one step, two different dialogue-length lists")
+        return lay
+
+    def tensor(self, key, lengths, maker, device):
+        ent = self.tensors.get(key)
+        if ent is None:
+            ent = self.tensors[key] = (torch.from_numpy(maker(lengths)).to(device), maker)
+        return ent[0]
+
+    def _stage(self, slot, name, arr, dev):
+        host = slot["bufs"].get(name)
+        if host is None or tuple(host.shape) != arr.shape or host.dtype != dev.dtype:
+            host = torch.empty(arr.shape, dtype=dev.dtype)
+            host = host.pin_memory() if dev.is_cuda else host
+            slot["bufs"][name] = host
+        host.numpy()[...] = arr
+        dev.copy_(host, non_blocking=True)
+
+    def retarget(self, lengths):
+        lengths = [int(x) for x in lengths]
+        slot = self._slots[self._turn % len(self._slots)]
+        self._turn += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        cuda = False
+        for key, lay in self.layouts.items():
+            i32, tile_base = lay.retarget_host(lengths)
+            self._stage(slot, ("i32",) + key, i32, lay._i32)
+            self._stage(slot, ("tb",) + key, tile_base, lay.tile_base)
+            cuda = cuda or lay._i32.is_cuda
+        for key, (dev, maker) in self.tensors.items():
+            arr = maker(lengths)
+            if arr.shape != tuple(dev.shape):
+                raise RuntimeError("IndexScope.retarget: the batch does not fit this step's bucket")
+            self._stage(slot, ("t",) + tuple(key), arr, dev)
+            cuda = cuda or dev.is_cuda
+        if cuda:
+            slot["event"] = torch.cuda.Event()
+            slot["event"].record()
+        self.lengths = lengths
+
+
 def pair_list(M):
     return [(m, n) for m in range(M) for n in range(m + 1, M)]
 
@@ -73,14 +153,28 @@ def pair_list(M):
 class DialogueLayout:
     """Index arrays describing a batch of B dialogues x M modalities."""
 
-    def __init__(self, lengths, M, device):
+    def __init__(self, lengths, M, device, capacity=False):
+        """``capacity``: a layout owned by an IndexScope -- ``tile_elems`` (what callers allocate tile arrays with) is the
+        upper bound M N round4(max_len) over every batch of the same (B, N, max_len), so retarget() never outgrows a buffer
+        a captured step has baked in."""
+        self.M = int(M)
+        self.device = torch.device(device)
+        self._capacity = bool(capacity)
+        i32, tile_base = self._host_arrays(lengths)
+        self.tile_elems = int(tile_base[-1])
+        if capacity:
+            self.tile_elems = self.M * self.N * ((self.max_len + 3) & ~3)
+        self._i32 = torch.from_numpy(i32).to(self.device)
+        self.dia_len = self._i32[:self.B]
+        self.row_start = self._i32[self.B:]
+        self.tile_base = torch.from_numpy(tile_base).to(self.device)
+
+    def _host_arrays(self, lengths):
         lens = np.asarray([int(x) for x in lengths], dtype=np.int64)
         if lens.ndim != 1 or lens.size == 0 or (lens <= 0).any():
             raise ValueError("dialogue lengths must be a non-empty list of positive ints")
         self.lengths = [int(x) for x in lens]
         self.B = int(lens.size)
-        self.M = int(M)
-        self.device = torch.device(device)
         row_start = np.zeros(self.B + 1, dtype=np.int64)
         row_start[1:] = np.cumsum(lens)
         ld = (lens + 3) & ~3
@@ -88,20 +182,31 @@ class DialogueLayout:
         tile_base[1:] = np.cumsum(self.M * lens * ld)
         self.N = int(row_start[-1])
         self.max_len = int(lens.max())
-        self.tile_elems = int(tile_base[-1])
         self.npairs = self.M * (self.M - 1) // 2
         self.nnz = int((self.M * lens * lens + self.M * (self.M - 1) * lens).sum())
         self.row_start_host = row_start
         self.tile_base_host = tile_base
         self.ld_host = ld
-        i32 = np.concatenate([lens.astype(np.int32), row_start.astype(np.int32)])
-        self._i32 = torch.from_numpy(i32).to(self.device)
-        self.dia_len = self._i32[:self.B]
-        self.row_start = self._i32[self.B:]
-        self.tile_base = torch.from_numpy(tile_base).to(self.device)
+        return np.concatenate([lens.astype(np.int32), row_start.astype(np.int32)]), tile_base
+
+    def retarget_host(self, lengths):
+        """Re-point this (scope-owned) layout's HOST side at another batch with the same number of dialogues, the same total
+        and the same maximum length; returns the new (dia_len | row_start, tile_base) arrays -- IndexScope.retarget writes them
+        over the device arrays in place (a captured step keeps reading those)."""
+        if not self._capacity:
+            raise RuntimeError("only layouts owned by an IndexScope can be retargeted (shared ones live in an LRU)")
+        B, N, mx = self.B, self.N, self.max_len
+        i32, tile_base = self._host_arrays(lengths)
+        if (self.B, self.N, self.max_len) != (B, N, mx) or int(tile_base[-1]) > self.tile_elems:
+            raise RuntimeError("DialogueLayout.retarget: (B, N, max_len) = %s does not match this layout's %s"
+                               % ((self.B, self.N, self.max_len), (B, N, mx)))
+        return i32, tile_base
 
     @staticmethod
     def get(lengths, M, device):
+        scope = IndexScope.current()
+        if scope is not None:
+            return scope.layout(lengths, M, device)
         key = (tuple(int(x) for x in lengths), int(M), str(device))
         return _LAYOUT_CACHE.get(key, lambda: DialogueLayout(lengths, M, device))
 

@@ -34,10 +34,48 @@ class _FocalLossHip(torch.autograd.Function):
         return dlogp, None, None, None, None
 
 
+class _FocalLossIgnoreHip(torch.autograd.Function):
+    """The fused launches with rows to leave out (csrc/focal_loss.hip, *_ignore): the row count of the mean is taken on
+    the device, so a captured step serves batches with different numbers of rows that count."""
+
+    @staticmethod
+    def forward(ctx, logp, target, alpha, gamma, size_average, ignore_index):
+        from . import _hip
+        logp = logp.contiguous()
+        target = target.reshape(-1).contiguous()
+        N, C = logp.shape
+        loss = torch.empty((), dtype=torch.float32, device=logp.device)
+        scale = torch.empty(1, dtype=torch.float32, device=logp.device)
+        coef = torch.empty(N, dtype=torch.float32, device=logp.device)
+        rc = _hip.lib().mmdfn_focal_loss_fwd_ignore(_hip.ptr(logp), _hip.ptr(target), _hip.ptr(alpha), _hip.ptr(loss),
+                                                    _hip.ptr(coef), _hip.ptr(scale), N, C, float(gamma),
+                                                    1 if size_average else 0, int(ignore_index), _hip.stream())
+        _hip.check(rc, "mmdfn_focal_loss_fwd_ignore")
+        ctx.save_for_backward(coef, target, scale)
+        ctx.C, ctx.ignore = C, int(ignore_index)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        from . import _hip
+        coef, target, scale = ctx.saved_tensors
+        N = coef.shape[0]
+        dlogp = torch.empty(N, ctx.C, dtype=torch.float32, device=coef.device)
+        dl = dloss.contiguous().to(torch.float32)
+        rc = _hip.lib().mmdfn_focal_loss_bwd_ignore(_hip.ptr(coef), _hip.ptr(target), _hip.ptr(dl), _hip.ptr(scale),
+                                                    _hip.ptr(dlogp), N, ctx.C, ctx.ignore, _hip.stream())
+        _hip.check(rc, "mmdfn_focal_loss_bwd_ignore")
+        return dlogp, None, None, None, None, None
+
+
 class FocalLoss(nn.Module):
-    def __init__(self, gamma=0, alpha=None, size_average=True):
+    """``ignore_index`` (not in the reference, default None = the reference's behaviour): rows with that label add nothing to
+    the loss or the gradient and are not counted by the mean."""
+
+    def __init__(self, gamma=0, alpha=None, size_average=True, ignore_index=None):
         super().__init__()
         self.gamma = gamma
+        self.ignore_index = ignore_index
         if isinstance(alpha, (float, int)) and not isinstance(alpha, bool):
             alpha = torch.tensor([alpha, 1 - alpha], dtype=torch.float32)
         elif isinstance(alpha, list):
@@ -55,8 +93,13 @@ class FocalLoss(nn.Module):
                 raise IndexError("FocalLoss: alpha has %d entries for %d classes" % (alpha.numel(), input.shape[1]))
             if alpha is not None and (alpha.device != input.device or alpha.dtype != input.dtype):
                 alpha = self.alpha = alpha.to(device=input.device, dtype=input.dtype)
+            if self.ignore_index is not None:
+                return _FocalLossIgnoreHip.apply(input, target, alpha, self.gamma, self.size_average, self.ignore_index)
             return _FocalLossHip.apply(input, target, alpha, self.gamma, self.size_average)
         # host tensors (the loss is plain glue in the reference; the gloo data-parallel test runs it on the CPU)
+        if self.ignore_index is not None:
+            keep = target.view(-1) != self.ignore_index
+            input, target = input[keep], target.view(-1)[keep]
         target = target.view(-1, 1)
         logpt = input.gather(1, target).view(-1)
         pt = logpt.detach().exp()

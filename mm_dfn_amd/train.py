@@ -67,13 +67,140 @@ class StepGraphCache:
     outputs; gradients are handed to ``p.grad`` after the replay, the optimizer step stays outside the graph.  Least
     recently used entries are dropped beyond ``max_entries`` (each holds a private memory pool)."""
 
-    def __init__(self, model, loss_f, max_entries=96, warmup=2):
+    IGNORE = -100                  # label of the padding dialogue's utterances (bucketed entries)
+
+    def __init__(self, model, loss_f, max_entries=96, warmup=2, bucket_rows=0):
+        """``bucket_rows`` = g > 0: BUCKETED entries -- one captured step per (train / eval, B, padded length L, ceil((N + 1) /
+        g) g) instead of per exact tuple of dialogue lengths (N = the batch's utterances).  The batch is padded to its
+        bucket with ONE extra dialogue of 1..g utterances (fixed random features, labels IGNORE: dialogues never interact
+        -- per-sequence GRUs, block-diagonal adjacency, row-wise stack -- so the real dialogues' results are those of the
+        batch alone, the padding rows add exact zeros to every gradient, and the loss is the mean over the real
+        utterances, counted on the device); before a replay the step's index arrays (dialogue lengths, row / tile
+        offsets, pad-strip and label gather indices) are rewritten for the new lengths (layout.IndexScope): the kernels
+        read them from device memory and their grids depend on (B, N, L) only.  A loader that reshuffles every epoch
+        (run_train_erc.py:165-212 with a different seed per pass, any sampler but the reference's) then stays on replays.
+        Needs a mm_dfn_amd FocalLoss (its ignore_index form) and a model without use_speaker / use_modal (they slice by
+        dialogue length on the host); anything else falls back to exact signatures."""
         from collections import OrderedDict
         self.model, self.loss_f = model, loss_f
         self.max_entries, self.warmup = max_entries, warmup
+        self.bucket_rows = int(bucket_rows or 0)
         self.entries = OrderedDict()
         self.queued = {}           # signature -> batches a staging loader has announced (claim_static) and not stepped yet
         self.hits = self.misses = self.recaptures = 0
+        self._loss_ign = None
+        if self.bucket_rows:
+            from .loss import FocalLoss
+            if isinstance(loss_f, FocalLoss) and loss_f.ignore_index is None:
+                self._loss_ign = FocalLoss(gamma=loss_f.gamma, alpha=loss_f.alpha, size_average=loss_f.size_average,
+                                           ignore_index=self.IGNORE)
+
+    def _bucketable(self, inputs, lengths, test_label):
+        m = self.model
+        L = int(inputs[0].shape[0])
+        return (self._loss_ign is not None and not test_label and not getattr(m, "use_speaker", False)
+                and not getattr(m, "use_modal", False) and self.bucket_rows <= L and all(t.is_cuda for t in inputs)
+                and int(max(lengths)) == L)
+
+    def _step_bucketed(self, inputs, lengths, train_flag):
+        """One step through a bucketed entry (see __init__).  Returns (loss, log_prob[:N], flat_labels[:N])."""
+        from .graphs import CapturedStep
+        from .layout import IndexScope
+        g = self.bucket_rows
+        lengths = [int(x) for x in lengths]
+        B, N, L = len(lengths), sum(lengths), int(inputs[0].shape[0])
+        Nb = ((N + 1 + g - 1) // g) * g
+        pad = Nb - N                                       # 1 .. g utterances of the padding dialogue
+        lens2 = lengths + [pad]
+        key = ("bucket", bool(train_flag), B, L, Nb) + tuple(tuple(t.shape[2:]) for t in inputs[:4])
+        ent = self.entries.get(key)
+        dev = inputs[0].device
+        Lp = int(inputs[5].shape[1])
+
+        def label_pos(lens):
+            return np.concatenate([np.arange(int(n), dtype=np.int64) + j * Lp for j, n in enumerate(lens)])
+
+        if ent is None:
+            self.misses += 1
+            gen = torch.Generator().manual_seed(20210 + B)
+            static = []
+            for i, t in enumerate(inputs):
+                if i in ops.FEATURE_SLOTS:                 # (L, B, D) -> (L, B + 1, D): the padding dialogue's features are fixed noise
+                    full = torch.cat([t, torch.randn(L, 1, t.shape[2], generator=gen).to(dev)], 1)
+                    static.append(ops.pad_rows(full) if ops.is_odd_feature_tensor(full, True) else full)
+                elif i == 3:                               # qmask (L, B, P): the padding dialogue is speaker 0's monologue
+                    static.append(torch.cat([t, torch.zeros(L, 1, t.shape[2], dtype=t.dtype, device=dev)], 1))
+                elif i == 4:                               # umask (B, L)
+                    static.append(torch.cat([t, torch.zeros(1, t.shape[1], dtype=t.dtype, device=dev)], 0))
+                else:                                      # label (B, L): never counted
+                    static.append(torch.cat([t, torch.full((1, t.shape[1]), self.IGNORE, dtype=t.dtype, device=dev)], 0))
+            textf, visuf, acouf, qmask, umask, label = static
+            scope = IndexScope()
+            ramp = torch.arange(L, device=dev)
+            out = {}
+            model, loss_f = self.model, self._loss_ign
+            with scope:
+                pos = scope.tensor(("labelpos", Lp), lens2, label_pos, dev)
+            flat = label.reshape(-1).index_select(0, pos)
+            state = dict(lens2=lens2)
+
+            def set_padding(n):
+                # the padding dialogue's speaker / utterance masks for n utterances (two tiny launches, outside the graph)
+                torch.lt(ramp, n, out=qmask[:, B, 0]) if qmask.dtype == torch.bool else qmask[:, B, 0].copy_(ramp < n)
+                umask[B, :L].copy_(ramp < n)
+
+            set_padding(pad)
+
+            def fn():
+                with scope:
+                    torch.index_select(label.reshape(-1), 0, pos, out=flat)
+                    out["log_prob"] = model(textf, qmask, umask, state["lens2"], acouf, visuf, False)[0]
+                    out["pred"] = torch.argmax(out["log_prob"], 1)
+                    loss = loss_f(out["log_prob"], flat)
+                    if train_flag:
+                        backward(loss)
+                return loss
+
+            mode = model.training
+            model.train(train_flag)
+            with torch.set_grad_enabled(bool(train_flag)):
+                cap = CapturedStep(model, fn, warmup=self.warmup)
+            model.train(mode)
+            ent = dict(static=static, cap=cap, out=out, flat=flat, pos=pos, pending=None, scope=scope, set_padding=set_padding,
+                       state=state, bucketed=True, B=B)
+            self.entries[key] = ent
+            while len(self.entries) > self.max_entries:
+                self.entries.popitem(last=False)
+        else:
+            self.hits += 1
+            self.entries.move_to_end(key)
+            if ent.get("pending") is not None:
+                ent["pending"]()
+                ent["pending"] = None
+            ent["state"]["lens2"] = lens2
+            ent["scope"].retarget(lens2)                   # lengths, row / tile offsets, pad-strip and label gather indices
+            ent["set_padding"](pad)
+            dst = [d[:, :B] if i < 4 else d[:B] for i, d in enumerate(ent["static"])]
+            fl = [(d, s_) for d, s_ in zip(dst, inputs) if d.is_floating_point()]
+            it = [(d, s_) for d, s_ in zip(dst, inputs) if not d.is_floating_point()]
+            for grp in (fl, it):
+                if grp:
+                    torch._foreach_copy_([x[0] for x in grp], [x[1] for x in grp], non_blocking=True)
+        cap = ent["cap"]
+        try:
+            loss = cap.replay()
+        except RuntimeError as exc:
+            if "storage moved" not in str(exc):
+                raise
+            del self.entries[key]
+            self.recaptures += 1
+            return self._step_bucketed(inputs, lengths, train_flag)
+        if train_flag:
+            for name, p in self.model.named_parameters():
+                p.grad = cap.grads.get(name)
+        self.last_entry = ent
+        self.last_pred = ent["out"]["pred"][:N]
+        return loss, ent["out"]["log_prob"][:N], ent["flat"][:N]
 
     @staticmethod
     def signature(shapes, lengths, train_flag, test_label=False):
@@ -86,6 +213,8 @@ class StepGraphCache:
         waiting for ``entry["done"]``, the event behind the entry's last replay) and hands exactly these tensors to
         ``step``, which then has nothing to copy."""
         key = self.signature(shapes, lengths, train_flag, test_label)
+        if self.bucket_rows:
+            return None               # bucketed entries serve many batches: their static buffers are filled by the step itself
         # every announced batch counts, claimed or not: the static buffers are handed out only when NO earlier batch of this
         # signature is still waiting to be stepped -- such a batch (staged elsewhere) is copied into the same buffers by its
         # step, on the compute stream, unordered with a later batch's direct copy on the loader's stream (with repeated
@@ -110,6 +239,8 @@ class StepGraphCache:
         tensors owned by the cache entry -- consume (or clone) them before this signature is stepped again."""
         from .graphs import CapturedStep
         key = self.signature([t.shape for t in inputs], lengths, train_flag, test_label)
+        if self.bucket_rows and self._bucketable(inputs, lengths, test_label):
+            return self._step_bucketed(inputs, lengths, train_flag)
         ent = self.entries.get(key)
         if self.queued.get(key, 0) > 0:
             self.queued[key] -= 1
@@ -182,6 +313,7 @@ class StepGraphCache:
             for name, p in self.model.named_parameters():
                 p.grad = cap.grads.get(name)
         self.last_entry = ent
+        self.last_pred = ent["out"]["pred"]
         if loss.is_cuda:
             done = ent.get("done")
             if done is None:
@@ -216,7 +348,7 @@ def train_or_eval_graph_model(model, loss_f, dataloader, epoch=0, train_flag=Fal
             # which case they are copied out first (StepGraphCache runs the entry's ``pending`` closure)
             ent = graph_cache.last_entry
             slot = len(preds)
-            preds.append(ent["out"]["pred"])
+            preds.append(graph_cache.last_pred)
             labels.append(flat)
             losses.append(loss.detach())
 

@@ -658,3 +658,87 @@ def test_thirty_step_trajectory_flat_adam_vs_torch_adam_at_the_reference_widths(
             continue
         worst = max(worst, float((a - c).abs().max()) / moved)
     assert worst < 0.05, worst
+
+
+def _eager_step(m, loss_f, b):
+    m.zero_grad(set_to_none=True)
+    logp = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+    flat = T.flatten_labels(b["label"], b["lengths"])
+    loss = loss_f(logp, flat)
+    T.backward(loss)
+    return float(loss), logp.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("cfg_name", ["small", "refdims", "meld"])
+def test_bucketed_step_cache_serves_unseen_length_tuples(cfg_name):
+    """StepGraphCache(bucket_rows=g): one captured step per (B, L, utterance bucket); batches whose length TUPLES were never
+    seen replay it -- padded to the bucket with a dummy dialogue, index arrays rewritten before the replay -- and give the
+    eager step's log-probabilities (bit for bit: every row's arithmetic is that of its own dialogue), loss and gradients
+    (to summation-order noise: the padding rows add exact zeros) on the batch alone."""
+    cfgs = {"small": (CFG, 2, 8), "refdims": (REF_DIMS, 2, 8), "meld": (dict(P=9, C=7, nlayers=3, D_t=100, D_a=100, D_v=512), 9, 16)}
+    cfg, P, g = cfgs[cfg_name]
+    L, B = 23, 3
+    m = synthetic.build_model(dropout=0.0, **cfg)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 31))
+    m = m.cuda().train()
+    loss_f = FocalLoss(gamma=0.5)
+    cache = T.StepGraphCache(m, loss_f, bucket_rows=g)
+    tuples = [[23, 9, 17], [23, 17, 9], [19, 23, 4], [23, 2, 21], [8, 15, 23], [23, 23, 1], [23, 12, 12], [23, 11, 15], [5, 23, 6]]
+    keys = set()
+    for i, lengths in enumerate(tuples):
+        b = synthetic.make_batch(60 + i, lengths=lengths, device="cuda", B=B, L=L, **cfg)
+        want_loss, want_logp, want_g = _eager_step(m, loss_f, b)
+        loss, logp, flat = cache.step((b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"]), lengths, True)
+        N = sum(lengths)
+        assert tuple(logp.shape) == (N, cfg["C"]) and tuple(flat.shape) == (N,)
+        assert torch.equal(flat, T.flatten_labels(b["label"], lengths))
+        assert torch.equal(logp, want_logp), float((logp - want_logp).abs().max())
+        assert abs(float(loss) - want_loss) < 2e-6 * max(1.0, abs(want_loss))
+        got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        assert set(got) == set(want_g)
+        for k in want_g:
+            den = float(want_g[k].abs().max())
+            assert float((got[k] - want_g[k]).abs().max()) <= 2e-5 * den + 1e-9, (k, lengths)
+        assert torch.equal(cache.last_pred, torch.argmax(want_logp, 1))
+        keys.add(((N + 1 + g - 1) // g) * g)
+    assert cache.misses == len(keys) < len(tuples) and cache.hits == len(tuples) - len(keys)
+    # eval entries are separate
+    b = synthetic.make_batch(90, lengths=[23, 9, 17], device="cuda", B=B, L=L, **cfg)
+    m.eval()
+    with torch.no_grad():
+        want = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+    loss, logp, _ = cache.step((b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"]), [23, 9, 17], False)
+    assert torch.equal(logp, want)
+    m.train()
+    # a batch padded beyond its own maximum length (the reference's collate never does that) takes the exact-signature path
+    b2 = synthetic.make_batch(91, lengths=[20, 9, 17], device="cuda", B=B, L=L, **cfg)
+    padL = lambda t, dim: torch.cat([t, torch.zeros_like(t.narrow(dim, 0, 3))], dim)
+    inp = (padL(b2["textf"], 0), padL(b2["visuf"], 0), padL(b2["acouf"], 0), padL(b2["qmask"], 0), padL(b2["umask"], 1),
+           padL(b2["label"], 1))
+    before = cache.misses
+    loss, logp, _ = cache.step(inp, [20, 9, 17], True)
+    assert cache.misses == before + 1 and sum(1 for k in cache.entries if k[0] != "bucket") == 1
+    assert tuple(logp.shape) == (46, cfg["C"])
+
+
+def test_reshuffled_epochs_stay_on_replays_with_the_bucketed_cache(tmp_path):
+    """A loader that reshuffles every epoch (a different seed per pass -- unlike the reference's per-pass reseed,
+    run_train_erc.py:164): with exact signatures every batch of every epoch is a new capture; with bucketed entries the
+    later epochs are replays.  The evaluation pass gives the eager loop's metrics on every epoch."""
+    p = D.write_synthetic_pickle(str(tmp_path / "f.pkl"), n_train=40, n_test=4, max_len=26, min_len=9, seed=12)
+    names = ['hap', 'sad', 'neu', 'ang', 'exc', 'fru']
+    loss_f = FocalLoss(gamma=0.5)
+    m = _model(27)
+    tr, _, _ = D.get_IEMOCAP_loaders(p, batch_size=4, valid_rate=0.0)
+    cache = T.StepGraphCache(m, loss_f, bucket_rows=16)
+    stats = []
+    for e in range(6):
+        before = (cache.hits, cache.misses)
+        want = T.train_or_eval_graph_model(m, loss_f, tr, e, False, None, True, 'avl', names, seed=100 + e)
+        got = T.train_or_eval_graph_model(m, loss_f, D.DevicePrefetcher(tr), e, False, None, False, 'avl', names, seed=100 + e,
+                                          graph_cache=cache)
+        assert got[3] == want[3] and got[6] == want[6] and np.array_equal(got[5], want[5]) and abs(got[2] - want[2]) < 1e-4
+        stats.append((cache.hits - before[0], cache.misses - before[1]))
+    late_hits = sum(h for h, _ in stats[3:])
+    late = sum(h + mi for h, mi in stats[3:])
+    assert late_hits >= 0.8 * late, stats
