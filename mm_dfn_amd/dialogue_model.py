@@ -33,7 +33,10 @@ _FLAT_CACHE = PinnedLRU(64)
 def _flat_index(lengths, L, B, device):
     """Row ids t*B+b of the (L*B) padded grid in dialogue-major order (simple_batch_graphify)."""
     def rows(lens):
-        return np.concatenate([np.arange(int(n), dtype=np.int64) * B + j for j, n in enumerate(lens)])
+        lens = np.asarray([int(n) for n in lens], dtype=np.int64)
+        start = np.cumsum(lens) - lens
+        t = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(start, lens)             # position inside the dialogue
+        return t * B + np.repeat(np.arange(lens.size, dtype=np.int64), lens)
     scope = IndexScope.current()
     if scope is not None:             # a captured step replayed for other length lists owns (and rewrites) its index tensors
         return scope.tensor(("flat", L, B, str(device)), lengths, rows, device)

@@ -95,6 +95,16 @@ class StepGraphCache:
                 self._loss_ign = FocalLoss(gamma=loss_f.gamma, alpha=loss_f.alpha, size_average=loss_f.size_average,
                                            ignore_index=self.IGNORE)
 
+    def _hand_over_grads(self, ent):
+        """``p.grad`` = the gradient tensors the entry's graph writes (walking named_parameters() on every step cost the
+        host 0.3 ms, a third of a cfg2 step: the (parameter, gradient) pairs are listed once per entry)."""
+        pairs = ent.get("grad_pairs")
+        if pairs is None:
+            grads = ent["cap"].grads
+            pairs = ent["grad_pairs"] = [(p, grads.get(name)) for name, p in self.model.named_parameters()]
+        for p, g in pairs:
+            p.grad = g
+
     def _bucketable(self, inputs, lengths, test_label):
         m = self.model
         L = int(inputs[0].shape[0])
@@ -118,7 +128,9 @@ class StepGraphCache:
         Lp = int(inputs[5].shape[1])
 
         def label_pos(lens):
-            return np.concatenate([np.arange(int(n), dtype=np.int64) + j * Lp for j, n in enumerate(lens)])
+            lens = np.asarray(lens, dtype=np.int64)
+            start = np.cumsum(lens) - lens
+            return np.arange(int(lens.sum()), dtype=np.int64) + np.repeat(np.arange(lens.size, dtype=np.int64) * Lp - start, lens)
 
         if ent is None:
             self.misses += 1
@@ -136,7 +148,9 @@ class StepGraphCache:
                     static.append(torch.cat([t, torch.full((1, t.shape[1]), self.IGNORE, dtype=t.dtype, device=dev)], 0))
             textf, visuf, acouf, qmask, umask, label = static
             scope = IndexScope()
-            ramp = torch.arange(L, device=dev)
+            # tri[n][t] = (t < n): the padding dialogue's masks for n utterances are one row copy each
+            tri = (torch.arange(L, device=dev).unsqueeze(0) < torch.arange(L + 1, device=dev).unsqueeze(1))
+            tri_q, tri_u = tri.to(qmask.dtype), tri.to(umask.dtype)
             out = {}
             model, loss_f = self.model, self._loss_ign
             with scope:
@@ -146,8 +160,8 @@ class StepGraphCache:
 
             def set_padding(n):
                 # the padding dialogue's speaker / utterance masks for n utterances (two tiny launches, outside the graph)
-                torch.lt(ramp, n, out=qmask[:, B, 0]) if qmask.dtype == torch.bool else qmask[:, B, 0].copy_(ramp < n)
-                umask[B, :L].copy_(ramp < n)
+                qmask[:, B, 0].copy_(tri_q[n])
+                umask[B, :L].copy_(tri_u[n])
 
             set_padding(pad)
 
@@ -196,8 +210,7 @@ class StepGraphCache:
             self.recaptures += 1
             return self._step_bucketed(inputs, lengths, train_flag)
         if train_flag:
-            for name, p in self.model.named_parameters():
-                p.grad = cap.grads.get(name)
+            self._hand_over_grads(ent)
         self.last_entry = ent
         self.last_pred = ent["out"]["pred"][:N]
         return loss, ent["out"]["log_prob"][:N], ent["flat"][:N]
@@ -310,8 +323,7 @@ class StepGraphCache:
             self.recaptures += 1
             return self.step(inputs, lengths, train_flag, test_label)
         if train_flag:
-            for name, p in self.model.named_parameters():
-                p.grad = cap.grads.get(name)
+            self._hand_over_grads(ent)
         self.last_entry = ent
         self.last_pred = ent["out"]["pred"]
         if loss.is_cuda:
