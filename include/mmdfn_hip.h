@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, and mmdfn_focal_loss_{fwd,bwd}_ignore). */
+/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -430,6 +430,10 @@ int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const 
  * ------------------------------------------------------------------------- */
 int mmdfn_focal_loss_fwd(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
                          int64_t N, int C, float gamma, int size_average, void* stream);
+/* the same, additionally writing dlogp_unit (N, C) = d loss / d log_prob for an upstream gradient of exactly 1 (NULL: not
+ * wanted): loss.backward() then needs no launch for the loss (mmdfn_focal_loss_bwd remains for other upstream gradients) */
+int mmdfn_focal_loss_fwd_grad(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
+                              float* dlogp_unit, int64_t N, int C, float gamma, int size_average, void* stream);
 int mmdfn_focal_loss_bwd(const float* coef, const int64_t* target, const float* dloss, float* dlogp, int64_t N, int C,
                          void* stream);
 /* the same with rows to leave out (target == ignore_index: no loss, zero gradient row; the mean divides by the rows that

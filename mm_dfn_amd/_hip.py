@@ -62,6 +62,7 @@ SIGNATURES = {
     "mmdfn_head_bwd": [_P] * 9 + [_L, _I, _I, _I, _I, _I, _F, _P],
     "mmdfn_focal_loss_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "mmdfn_focal_loss_bwd": [_P, _P, _P, _P, _L, _I, _P],
+    "mmdfn_focal_loss_fwd_grad": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
     "mmdfn_focal_loss_fwd_ignore": [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _L, _P],
     "mmdfn_focal_loss_bwd_ignore": [_P, _P, _P, _P, _P, _L, _I, _L, _P],
     "mmdfn_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],

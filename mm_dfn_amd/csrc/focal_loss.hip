@@ -16,7 +16,7 @@ constexpr int FL_NT = 1024;
 __global__ __launch_bounds__(FL_NT) void focal_loss_fwd_kernel(const float* __restrict__ logp, const int64_t* __restrict__ target,
                                                                const float* __restrict__ alpha, float* __restrict__ loss,
                                                                float* __restrict__ coef, int64_t N, int C, float gamma,
-                                                               float scale) {
+                                                               float scale, float* __restrict__ dunit) {
     __shared__ float part[FL_NT / 64];
     float acc = 0.f;
     for (int64_t i = threadIdx.x; i < N; i += FL_NT) {
@@ -32,6 +32,11 @@ __global__ __launch_bounds__(FL_NT) void focal_loss_fwd_kernel(const float* __re
         if (bad) wgt = __builtin_nanf("");               // (fmaxf / powf above swallow the NaN of lp)
         coef[i] = -wgt * scale;
         acc += -wgt * lp;
+        // d loss / d log_prob for an upstream gradient of exactly 1 (the usual case: loss.backward()): written here, so the
+        // backward pass of the step needs no launch of its own for the loss (a bad label poisons its whole row, as the
+        // backward kernel does)
+        if (dunit != nullptr)
+            for (int c = 0; c < C; ++c) dunit[i * C + c] = (c == t || bad) ? -wgt * scale : 0.f;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -142,14 +147,19 @@ extern "C" int mmdfn_focal_loss_bwd_ignore(const float* coef, const int64_t* tar
     return 0;
 }
 
-extern "C" int mmdfn_focal_loss_fwd(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
-                                    int64_t N, int C, float gamma, int size_average, void* stream) {
+extern "C" int mmdfn_focal_loss_fwd_grad(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
+                                         float* dlogp_unit, int64_t N, int C, float gamma, int size_average, void* stream) {
     if (N <= 0 || C <= 0) return -1;
     const float scale = size_average ? 1.0f / (float)N : 1.0f;
     hipLaunchKernelGGL(focal_loss_fwd_kernel, dim3(1), dim3(FL_NT), 0, (hipStream_t)stream, logp, target, alpha, loss, coef, N, C,
-                       gamma, scale);
+                       gamma, scale, dlogp_unit);
     MMDFN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mmdfn_focal_loss_fwd(const float* logp, const int64_t* target, const float* alpha, float* loss, float* coef,
+                                    int64_t N, int C, float gamma, int size_average, void* stream) {
+    return mmdfn_focal_loss_fwd_grad(logp, target, alpha, loss, coef, nullptr, N, C, gamma, size_average, stream);
 }
 
 extern "C" int mmdfn_focal_loss_bwd(const float* coef, const int64_t* target, const float* dloss, float* dlogp, int64_t N,

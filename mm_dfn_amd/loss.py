@@ -3,8 +3,15 @@ import torch
 import torch.nn as nn
 
 
+# data pointers of the cached scalar 1 that train.backward seeds loss.backward() with: an upstream gradient that IS one of
+# them is exactly 1, and the gradient the forward launch already wrote is the answer
+UNIT_SEED_PTRS = set()
+
+
 class _FocalLossHip(torch.autograd.Function):
-    """One fused launch each way on device tensors (csrc/focal_loss.hip)."""
+    """One fused launch on device tensors (csrc/focal_loss.hip): when a gradient will be wanted the forward launch also
+    writes d loss / d log_prob for an upstream gradient of 1, and the backward pass launches nothing for the loss when it
+    is seeded with train.backward's cached 1 (any other upstream gradient takes the backward kernel)."""
 
     @staticmethod
     def forward(ctx, logp, target, alpha, gamma, size_average):
@@ -14,16 +21,22 @@ class _FocalLossHip(torch.autograd.Function):
         N, C = logp.shape
         loss = torch.empty((), dtype=torch.float32, device=logp.device)
         coef = torch.empty(N, dtype=torch.float32, device=logp.device)
-        rc = _hip.lib().mmdfn_focal_loss_fwd(_hip.ptr(logp), _hip.ptr(target), _hip.ptr(alpha), _hip.ptr(loss), _hip.ptr(coef),
-                                             N, C, float(gamma), 1 if size_average else 0, _hip.stream())
-        _hip.check(rc, "mmdfn_focal_loss_fwd")
+        want = ctx.needs_input_grad[0]
+        dunit = torch.empty(N, C, dtype=torch.float32, device=logp.device) if want else None
+        rc = _hip.lib().mmdfn_focal_loss_fwd_grad(_hip.ptr(logp), _hip.ptr(target), _hip.ptr(alpha), _hip.ptr(loss),
+                                                  _hip.ptr(coef), _hip.ptr(dunit), N, C, float(gamma),
+                                                  1 if size_average else 0, _hip.stream())
+        _hip.check(rc, "mmdfn_focal_loss_fwd_grad")
         ctx.save_for_backward(coef, target)
+        ctx.dunit = dunit
         ctx.C = C
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         from . import _hip
+        if ctx.dunit is not None and dloss.data_ptr() in UNIT_SEED_PTRS:
+            return ctx.dunit, None, None, None, None
         coef, target = ctx.saved_tensors
         N = coef.shape[0]
         dlogp = torch.empty(N, ctx.C, dtype=torch.float32, device=coef.device)

@@ -53,6 +53,8 @@ def backward(loss):
             if loss.is_cuda and torch.cuda.is_current_stream_capturing():
                 return loss.backward()           # a tensor created under capture belongs to that graph's pool
             one = _UNIT_SEED[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+            from . import loss as _loss_mod
+            _loss_mod.UNIT_SEED_PTRS.add(one.data_ptr())       # (FocalLoss then knows the upstream gradient is exactly 1)
         loss.backward(one)
 
 
