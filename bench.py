@@ -771,7 +771,42 @@ def roofline_legs(out, a, dev, n_utt, lengths):
         out["roofline_cfg5_bwd"]["traffic"] = tb
         if srcb:
             out["roofline_cfg5_bwd"]["traffic_source"] = srcb
-        del adj5, H5, dO5, gb
+        # the same leg as the GCN stack runs it since round 5 ("if several layers are fused, count A-hat once per
+        # fused group"): nl = 8 layers share the adjacency, so the backward is 8 x dH = A^T dO_l and ONE dA = [dhi_1 | .. |
+        # dhi_8] [zin_1 | .. | zin_8]^T over the tile pattern (width nl d): bytes = nl (4 nnz + 8 M N d) + 8 M N d nl + 4 nnz
+        nl5 = 8
+        X8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
+        Y8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
+        for _ in range(2):
+            for l in range(nl5):
+                ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout)
+            ops.tile_outer_raw(X8, Y8, adj5.layout)
+        torch.cuda.synchronize()
+        gs = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gs):
+            for _ in range(3):
+                for l in range(nl5):
+                    ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout)
+                ops.tile_outer_raw(X8, Y8, adj5.layout)
+        for _ in range(5):
+            gs.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            gs.replay()
+        e1.record()
+        e1.synchronize()
+        mss = e0.elapsed_time(e1) / 15
+        bs = nl5 * (4 * lay5.nnz + 8 * 6 * sum(l5) * d) + 8 * 6 * sum(l5) * d * nl5 + 4 * lay5.nnz
+        out["roofline_cfg5_bwd_stack"] = {
+            "workload": "cfg5 backward of the K6 calls of one 8-layer stack: 8 x dH (propagate) + ONE dA over all layers "
+                        "(tile_dot_split d = 800 + cross_dot pieces)", "bound": "hbm", "achieved": bs / (mss * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs / (mss * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": bs,
+            "avg_us": mss * 1e3, "per_layer_equivalent_us": mss * 1e3 / nl5,
+            "note": "A-hat's gradient counted once per stack (one write of the tile array); the per-call leg above is what "
+                    "rounds 1-4 ran once per layer (8 read-modify-writes of the tile array)"}
+        del adj5, H5, dO5, gb, gs, X8, Y8
         torch.cuda.empty_cache()
         # the d = 512 stress variant SURVEY 8d asks for next to the reference-faithful d = 100: 18.94 MB and 1.63 GFLOP per
         # dialogue-layer = 86 flop/B, above the fp32 ridge (157 TFLOP/s / 8 TB/s = 20 flop/B): MFMA-bound, priced against
