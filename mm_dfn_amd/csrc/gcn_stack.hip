@@ -535,6 +535,222 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// K7 producer / consumer forms (round 5; the structure of the K8 kernels below).  The 4-wave kernels above run a row block
+// as load -> park -> barrier -> 100 MFMAs per wave -> LDS round trip -> epilogue with everybody in every phase: at 98 304
+// rows the launch reaches 0.25 of the exact-f32 matrix rate and 0.3 of HBM (profiles/r04_cfg5_stream_b32_kernel_stats.csv).
+// Here waves 0-3 only contract (A(i) against the parked weights, results to sP[i & 1]) while waves 4-7 run the epilogue of
+// block i - 1 (from sP[(i - 1) & 1] and the A rows of block i - 1, which they read back from the LDS buffer right before they
+// overwrite it with block i + 1 -- same thread, same elements), keep block i + 2's rows and block i's epilogue operands in
+// flight, and park block i + 1.  One barrier per block; every SIMD holds one wave of each kind.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gcnii_layer_fwd_ws_kernel(const float* __restrict__ hi, const float* __restrict__ h0,
+                                                                 const float* __restrict__ W, const float* __restrict__ q,
+                                                                 const float* __restrict__ m, float* __restrict__ out,
+                                                                 float* __restrict__ gmask, float theta, float alpha, int R,
+                                                                 int H, int ldo, float ms) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = 2 * H;
+    const int ldw = lds_stride(K), ldp = ((H + 15) & ~15) + 4;
+    float* sW = smem;                         // [H][ldw]
+    float* sA = sW + H * ldw;                 // [2][16][ldw]   rows [hi | h0]
+    float* sP = sA + 2 * RB * ldw;            // [2][16][ldp]
+    const int nrb = (R + RB - 1) / RB;
+    const int H4 = H >> 2;
+    const int tid = threadIdx.x & 255;
+    const bool producer = threadIdx.x >= 256;
+    const int first = blockIdx.x, stride = gridDim.x;
+    constexpr int NS = 2;                     // per source: 16 * H / 4 / 256 <= 2
+    float4 ra[NS], rb_[NS], eq[NS], em[NS];
+    auto issue = [&](int rb) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * H4 && row < R;
+            ra[s] = ok ? ld4(hi + (int64_t)row * H + k) : zero4();
+            rb_[s] = ok ? ld4(h0 + (int64_t)row * H + k) : zero4();
+        }
+    };
+    auto park = [&](float* dst) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            if (i >= RB * H4) continue;
+            const int r = i / H4, k = (i - r * H4) * 4;
+            st4(dst + r * ldw + k, ra[s]);
+            st4(dst + r * ldw + H + k, rb_[s]);
+        }
+    };
+    auto issue_epi = [&](int rb) {            // q / keep flags of block rb: requested one iteration before its epilogue
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * H4 && row < R;
+            eq[s] = (ok && q) ? ld4(q + (int64_t)row * H + n) : zero4();
+            em[s] = (ok && m) ? ld4(m + (int64_t)row * H + n) : one4();
+        }
+    };
+    auto epilogue = [&](int rb, const float* A, const float* P) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            if (i >= RB * H4 || row >= R) continue;
+            const float4 p = ld4(P + r * ldp + n), vh = ld4(A + r * ldw + n), v0 = ld4(A + r * ldw + H + n);
+            const float4 ems = scl4(em[s], m ? ms : 1.0f);
+            float4 o, gm;
+#define K7F(F_)                                                                                            \
+    {                                                                                                      \
+        const float pre = theta * p.F_ + (1.0f - theta) * ((1.0f - alpha) * vh.F_ + alpha * v0.F_);       \
+        o.F_ = fmaxf(pre, 0.f) * ems.F_ + eq[s].F_;                                                        \
+        gm.F_ = pre > 0.f ? ems.F_ : 0.f;                                                                  \
+    }
+            K7F(x) K7F(y) K7F(z) K7F(w)
+#undef K7F
+            st4(out + (int64_t)row * ldo + n, o);
+            st4_nt(gmask + (int64_t)row * H + n, gm);            // (saved for the backward pass)
+        }
+    };
+    if (producer) {
+        if (first < nrb) { issue(first); issue_epi(first); }
+    } else {
+        WeightStager<true> wst;
+        wst.issue(W, H, 0, H, K);
+        wst.commit(sW, ldw, H, K);
+        zero_pads(sA, 2 * RB, ldw, K);
+    }
+    if (producer) {
+        if (first < nrb) park(sA);
+        if (first + stride < nrb) issue(first + stride);
+    }
+    __syncthreads();
+    int wrow0[2];
+    const int nt = wave_tiles<2>(wrow0, (H + 15) >> 4);        // (consumer waves: threadIdx.x >> 6 = 0..3)
+    int buf = 0, prev_rb = -1;
+    for (int rb = first; rb < nrb; rb += stride) {
+        const int nxt = rb + stride;
+        if (producer) {
+            // epilogue of the previous block (its A rows still sit in the buffer that block nxt is parked into right after),
+            // then this block's epilogue operands and block nxt + stride's rows go out
+            if (prev_rb >= 0) epilogue(prev_rb, sA + (buf ^ 1) * RB * ldw, sP + (buf ^ 1) * RB * ldp);
+            if (prev_rb >= 0) issue_epi(rb);
+            if (nxt < nrb) {
+                park(sA + (buf ^ 1) * RB * ldw);
+                if (nxt + stride < nrb) issue(nxt + stride);
+            }
+        } else {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            contract<2>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, K);
+            spill_tiles<2>(acc, wrow0, nt, sP + buf * RB * ldp, ldp);
+        }
+        __syncthreads();
+        prev_rb = rb;
+        buf ^= 1;
+    }
+    if (producer && prev_rb >= 0) epilogue(prev_rb, sA + (buf ^ 1) * RB * ldw, sP + (buf ^ 1) * RB * ldp);
+}
+
+__global__ __launch_bounds__(512) void gcnii_layer_bwd_ws_kernel(const float* __restrict__ dout, const float* __restrict__ gmask,
+                                                                 const float* __restrict__ W, float* __restrict__ dP,
+                                                                 float* __restrict__ dhi, float* __restrict__ dh0,
+                                                                 float theta, float alpha, int R, int H, int lddo, int acc_h0,
+                                                                 int lddhi) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = 2 * H;
+    const int ldw = lds_stride(H), ldp = ((N + 15) & ~15) + 4;
+    float* sW = smem;                         // [2H][ldw]
+    float* sA = sW + N * ldw;                 // [2][16][ldw]   rows dP
+    float* sP = sA + 2 * RB * ldw;            // [2][16][ldp]
+    const int nrb = (R + RB - 1) / RB;
+    const int H4 = H >> 2;
+    const int tid = threadIdx.x & 255;
+    const bool producer = threadIdx.x >= 256;
+    const int first = blockIdx.x, stride = gridDim.x;
+    constexpr int NS = 2;
+    float4 rd[NS], rg[NS], eo[NS];
+    auto issue = [&](int rb) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const bool ok = i < RB * H4 && row < R;
+            rd[s] = ok ? ld4(dout + (int64_t)row * lddo + k) : zero4();
+            rg[s] = ok ? ld4(gmask + (int64_t)row * H + k) : zero4();
+        }
+    };
+    auto park = [&](int rb, float* dst) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            if (i >= RB * H4) continue;
+            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const float4 v = scl4(mul4(rd[s], rg[s]), theta);
+            st4(dst + r * ldw + k, v);
+            if (row < R) st4_nt(dP + (int64_t)row * H + k, v);
+        }
+    };
+    auto issue_epi = [&](int rb) {            // running dh0 of block rb (the h0 half is the accumulating one)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            eo[s] = (acc_h0 && i < RB * H4 && row < R) ? ld4(dh0 + (int64_t)row * H + n) : zero4();
+        }
+    };
+    // (1 - theta)(1 - alpha) gg = c1 dP, (1 - theta) alpha gg = c2 dP   (theta = ln(lamda / l + 1) > 0)
+    const float c1 = (1.0f - theta) * (1.0f - alpha) / theta, c2 = (1.0f - theta) * alpha / theta;
+    auto epilogue = [&](int rb, const float* A, const float* P) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = tid + 256 * s;
+            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            if (i >= RB * H4 || row >= R) continue;
+            const float4 dp = ld4(A + r * ldw + n);
+            st4(dhi + (int64_t)row * lddhi + n, fma4(dp, c1, ld4(P + r * ldp + n)));
+            st4(dh0 + (int64_t)row * H + n, add4(fma4(dp, c2, ld4(P + r * ldp + H + n)), eo[s]));
+        }
+    };
+    if (producer) {
+        if (first < nrb) { issue(first); issue_epi(first); }
+    } else {
+        WeightStager<false> wst;
+        wst.issue(W, H, 0, N, H);
+        wst.commit(sW, ldw, N, H);
+        zero_pads(sA, 2 * RB, ldw, H);
+    }
+    if (producer) {
+        if (first < nrb) park(first, sA);
+        if (first + stride < nrb) issue(first + stride);
+    }
+    __syncthreads();
+    int wrow0[4];
+    const int nt = wave_tiles<4>(wrow0, (N + 15) >> 4);
+    int buf = 0, prev_rb = -1;
+    for (int rb = first; rb < nrb; rb += stride) {
+        const int nxt = rb + stride;
+        if (producer) {
+            if (prev_rb >= 0) epilogue(prev_rb, sA + (buf ^ 1) * RB * ldw, sP + (buf ^ 1) * RB * ldp);
+            if (prev_rb >= 0) issue_epi(rb);
+            if (nxt < nrb) {
+                park(nxt, sA + (buf ^ 1) * RB * ldw);
+                if (nxt + stride < nrb) issue(nxt + stride);
+            }
+        } else {
+            f32x4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            contract<4>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, H);
+            spill_tiles<4>(acc, wrow0, nt, sP + buf * RB * ldp, ldp);
+        }
+        __syncthreads();
+        prev_rb = rb;
+        buf ^= 1;
+    }
+    if (producer && prev_rb >= 0) epilogue(prev_rb, sA + (buf ^ 1) * RB * ldw, sP + (buf ^ 1) * RB * ldp);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // K8 forward: LSTM-cell step of the reasoning module.  G = q W_ih^T + h W_hh^T + bsum (gate order i, f, g, o);
 //   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c').   h / c may be null (zero state, first layer).
 //   Saves the gate ACTIVATIONS (R, 4H) for the backward pass.  W_ih, W_hh: (4H, H) nn.LSTM layout.
@@ -1122,6 +1338,15 @@ inline bool gate_ws(int R) {
     return R >= 64;
 }
 
+// producer / consumer forms of the K7 kernels (tuning build: MMDFN_LAYER_WS=0|1 forces)
+constexpr int LAYER_WS_ROWS = 64;        // measured ahead of the 4-wave kernels from 5 280 rows (cfg2: 15.1 / 14.9 -> 13.4 / 12.3 us) to 98 304 (97 / 101 -> 84 / 94 us), tools/bench_layer.py
+inline bool layer_ws(int R) {
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_LAYER_WS")) return atoi(e) != 0;
+#endif
+    return R >= LAYER_WS_ROWS;
+}
+
 // bf16-piece form of the K8 forward (lstm_gate_split.hip) from GATE_SPLIT_ROWS rows on (tuning build: MMDFN_GATE_SPLIT=0|1 forces)
 constexpr int GATE_SPLIT_ROWS = 16384;
 inline bool gate_split(int R, int H) {
@@ -1247,6 +1472,15 @@ extern "C" int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const flo
                                      float* out, float* gmask, float theta, float alpha, int R, int H, int ldo, float mscale,
                                      void* stream) {
     if (bad_dims(R, H) || ldo < H || (ldo & 3)) return -1;
+    if (layer_ws(R)) {
+        const size_t ldsw = ((size_t)(H + 2 * RB) * lds_stride(2 * H) + 2 * RB * (((H + 15) & ~15) + 4)) * sizeof(float);
+        if (ldsw > 156 * 1024) return -1;
+        if (int e_ = mmdfn_allow_big_lds(gcnii_layer_fwd_ws_kernel)) return e_;
+        hipLaunchKernelGGL(gcnii_layer_fwd_ws_kernel, dim3(row_groups(R, 1)), dim3(512), ldsw, (hipStream_t)stream, hi, h0, W, q, m,
+                           out, gmask, theta, alpha, R, H, ldo, mscale);
+        MMDFN_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = ((size_t)(H + 2 * RB) * lds_stride(2 * H) + RB * (((H + 15) & ~15) + 4)) * sizeof(float);
     LAUNCH_BIG_LDS(gcnii_layer_fwd_kernel, dim3(row_groups(R, 1)), lds, stream, hi, h0, W, q, m, out, gmask, theta, alpha, R, H,
                    ldo, mscale);
@@ -1256,6 +1490,15 @@ extern "C" int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const flo
 extern "C" int mmdfn_gcnii_layer_bwd_ld(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
                                         float theta, float alpha, int R, int H, int lddo, int acc_h0, int lddhi, void* stream) {
     if (bad_dims(R, H) || lddo < H || (lddo & 3) || lddhi < H || (lddhi & 3) || !(theta > 0.f)) return -1;
+    if (layer_ws(R)) {
+        const size_t ldsw = ((size_t)(2 * H + 2 * RB) * lds_stride(H) + 2 * RB * (((2 * H + 15) & ~15) + 4)) * sizeof(float);
+        if (ldsw > 156 * 1024) return -1;
+        if (int e_ = mmdfn_allow_big_lds(gcnii_layer_bwd_ws_kernel)) return e_;
+        hipLaunchKernelGGL(gcnii_layer_bwd_ws_kernel, dim3(row_groups(R, 1)), dim3(512), ldsw, (hipStream_t)stream, dout, gmask, W,
+                           dP, dhi, dh0, theta, alpha, R, H, lddo, acc_h0, lddhi);
+        MMDFN_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = ((size_t)(2 * H + 2 * RB) * lds_stride(H) + RB * (((2 * H + 15) & ~15) + 4)) * sizeof(float);
     LAUNCH_BIG_LDS(gcnii_layer_bwd_kernel, dim3(row_groups(R, 1)), lds, stream, dout, gmask, W, dP, dhi, dh0, theta, alpha, R, H,
                    lddo, acc_h0, lddhi);

@@ -805,10 +805,17 @@ def test_lstm_gate_forward_bf16_piece_form_against_the_exact_f32_form(kernel_var
         assert float((res["0"][1] - res["1"][1]).abs().max()) > 0.0          # it really was another kernel
 
 
+@pytest.mark.parametrize("ws", ["auto", "1", "0"])
 @pytest.mark.parametrize("R,H,masked,has_q,ldo", [(37, 100, True, True, 300), (500, 100, False, False, 100), (9, 36, True, True, 36),
-                                                  (2100, 96, True, False, 96), (5280, 100, True, True, 300)])
-def test_gcnii_layer_kernels(R, H, masked, has_q, ldo):
+                                                  (2100, 96, True, False, 96), (5280, 100, True, True, 300),
+                                                  # many rows: the producer / consumer forms (round 5) by default; ragged last block
+                                                  (24576, 100, True, True, 300), (16401, 100, False, True, 100)])
+def test_gcnii_layer_kernels(R, H, masked, has_q, ldo, ws, kernel_variants):
+    """``ws``: the 4-wave kernels ("0") / the 8-wave producer / consumer kernels ("1") forced through the tuning build, or the
+    dispatcher's own choice ("auto": producer / consumer from 64 rows on)."""
     from mm_dfn_amd import _hip
+    if ws != "auto":
+        kernel_variants.setenv("MMDFN_LAYER_WS", ws)
     lib, P, st = _hip.lib(), _hip.ptr, _hip.stream
     rs = np.random.RandomState(83)
     hi, h0, W = _rnd(rs, R, H), _rnd(rs, R, H), _rnd(rs, 2 * H, H, scale=0.1)
