@@ -89,7 +89,7 @@ def profile_json(name):
         return None
 
 
-TRAFFIC_JSON = "r04_propagate_traffic.json"      # (this round's PMC passes)
+TRAFFIC_JSON = "r05_propagate_traffic.json"      # (this round's PMC passes)
 
 
 def measured_traffic(key, kernel):
@@ -777,16 +777,17 @@ def roofline_legs(out, a, dev, n_utt, lengths):
         nl5 = 8
         X8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
         Y8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
+        dz8 = torch.empty(6 * sum(l5), d, device=dev)
         for _ in range(2):
             for l in range(nl5):
-                ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout)
+                ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout, out=dz8)
             ops.tile_outer_raw(X8, Y8, adj5.layout)
         torch.cuda.synchronize()
         gs = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gs):
             for _ in range(3):
-                for l in range(nl5):
-                    ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout)
+                for l in range(nl5):      # (dhi_l: a column block of the stack's (MN, nl d) buffer, as gcn_stack.py hands it over)
+                    ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout, out=dz8)
                 ops.tile_outer_raw(X8, Y8, adj5.layout)
         for _ in range(5):
             gs.replay()
@@ -806,7 +807,7 @@ def roofline_legs(out, a, dev, n_utt, lengths):
             "avg_us": mss * 1e3, "per_layer_equivalent_us": mss * 1e3 / nl5,
             "note": "A-hat's gradient counted once per stack (one write of the tile array); the per-call leg above is what "
                     "rounds 1-4 ran once per layer (8 read-modify-writes of the tile array)"}
-        del adj5, H5, dO5, gb, gs, X8, Y8
+        del adj5, H5, dO5, gb, gs, X8, Y8, dz8
         torch.cuda.empty_cache()
         # the d = 512 stress variant SURVEY 8d asks for next to the reference-faithful d = 100: 18.94 MB and 1.63 GFLOP per
         # dialogue-layer = 86 flop/B, above the fp32 ridge (157 TFLOP/s / 8 TB/s = 20 flop/B): MFMA-bound, priced against
