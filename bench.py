@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs (cfg2 ragged, cfg3, cfg4 shard, cfg5, streamed)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the K6 roofline legs (profiling runs of the step alone)")
     ap.add_argument("--only-roofline", action="store_true", help="profiling aid: run only the K6 roofline legs (clean rocprof traces)")
+    ap.add_argument("--roofline-legs", default="fwd,bwd,stack,d512",
+                    help="profiling aid: which cfg5 legs to run (tools/collect_traffic.py separates the per-call legs from the "
+                         "stack leg, whose launches share kernel names and grids with them)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per cpu_baseline mode")
@@ -741,92 +744,102 @@ def roofline_legs(out, a, dev, n_utt, lengths):
                     "is in DESIGN.md 4g / profiles/r03_k6_memory_path.md"}
         # K6 backward at the same workload, reported separately: dH = A^T dO (the forward kernel, A is
         # symmetric) + dA = dO . H^T on the tile pattern (tile_dot + cross_dot); bytes_bwd = 8 nnz + 16 M N d
+        legs5 = set(a.roofline_legs.split(","))
         adj5, H5 = mk5(0)
         dO5 = torch.randn_like(H5)
-        for _ in range(3):
-            ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
-            ops.tile_outer_raw(dO5, H5, adj5.layout)
-        torch.cuda.synchronize()
-        gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb):
-            for _ in range(10):
+        gb = None
+        if "bwd" in legs5:
+            for _ in range(3):
                 ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
                 ops.tile_outer_raw(dO5, H5, adj5.layout)
-        for _ in range(10):
-            gb.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            gb.replay()
-        e1.record()
-        e1.synchronize()
-        msb = e0.elapsed_time(e1) / 50
-        bb = 8 * lay5.nnz + 16 * 6 * sum(l5) * d
-        out["roofline_cfg5_bwd"] = {"workload": "cfg5 backward of one K6 call: dH (propagate) + dA (tile_dot + cross_dot)",
-                                    "bound": "hbm", "achieved": bb / (msb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "algorithmic_bytes": bb, "avg_us": msb * 1e3}
-        tb, srcb = measured_traffic_bwd()
-        out["roofline_cfg5_bwd"]["traffic"] = tb
-        if srcb:
-            out["roofline_cfg5_bwd"]["traffic_source"] = srcb
+            torch.cuda.synchronize()
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                for _ in range(10):
+                    ops.propagate_raw(adj5.tiles, adj5.cross, dO5, adj5.layout)
+                    ops.tile_outer_raw(dO5, H5, adj5.layout)
+            for _ in range(10):
+                gb.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                gb.replay()
+            e1.record()
+            e1.synchronize()
+            msb = e0.elapsed_time(e1) / 50
+            bb = 8 * lay5.nnz + 16 * 6 * sum(l5) * d
+            out["roofline_cfg5_bwd"] = {"workload": "cfg5 backward of one K6 call: dH (propagate) + dA (tile_dot + cross_dot)",
+                                        "bound": "hbm", "achieved": bb / (msb * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": bb / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes": bb, "avg_us": msb * 1e3}
+            tb, srcb = measured_traffic_bwd()
+            out["roofline_cfg5_bwd"]["traffic"] = tb
+            if srcb:
+                out["roofline_cfg5_bwd"]["traffic_source"] = srcb
         # the same leg as the GCN stack runs it since round 5 ("if several layers are fused, count A-hat once per
         # fused group"): nl = 8 layers share the adjacency, so the backward is 8 x dH = A^T dO_l and ONE dA = [dhi_1 | .. |
         # dhi_8] [zin_1 | .. | zin_8]^T over the tile pattern (width nl d): bytes = nl (4 nnz + 8 M N d) + 8 M N d nl + 4 nnz
-        nl5 = 8
-        X8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
-        Y8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
-        dz8 = torch.empty(6 * sum(l5), d, device=dev)
-        for _ in range(2):
-            for l in range(nl5):
-                ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout, out=dz8)
-            ops.tile_outer_raw(X8, Y8, adj5.layout)
-        torch.cuda.synchronize()
-        gs = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gs):
-            for _ in range(3):
-                for l in range(nl5):      # (dhi_l: a column block of the stack's (MN, nl d) buffer, as gcn_stack.py hands it over)
+        if "stack" in legs5:
+            nl5 = 8
+            X8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
+            Y8 = torch.randn(6 * sum(l5), nl5 * d, device=dev)
+            dz8 = torch.empty(6 * sum(l5), d, device=dev)
+            for _ in range(2):
+                for l in range(nl5):
                     ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout, out=dz8)
                 ops.tile_outer_raw(X8, Y8, adj5.layout)
-        for _ in range(5):
-            gs.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            gs.replay()
-        e1.record()
-        e1.synchronize()
-        mss = e0.elapsed_time(e1) / 15
-        bs = nl5 * (4 * lay5.nnz + 8 * 6 * sum(l5) * d) + 8 * 6 * sum(l5) * d * nl5 + 4 * lay5.nnz
-        out["roofline_cfg5_bwd_stack"] = {
-            "workload": "cfg5 backward of the K6 calls of one 8-layer stack: 8 x dH (propagate) + ONE dA over all layers "
-                        "(tile_dot_split d = 800 + cross_dot pieces)", "bound": "hbm", "achieved": bs / (mss * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs / (mss * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": bs,
-            "avg_us": mss * 1e3, "per_layer_equivalent_us": mss * 1e3 / nl5,
-            "note": "A-hat's gradient counted once per stack (one write of the tile array); the per-call leg above is what "
-                    "rounds 1-4 ran once per layer (8 read-modify-writes of the tile array)"}
-        del adj5, H5, dO5, gb, gs, X8, Y8, dz8
+            torch.cuda.synchronize()
+            gs = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gs):
+                for _ in range(3):
+                    for l in range(nl5):      # (dhi_l: a column block of the stack's (MN, nl d) buffer, as gcn_stack.py hands it over)
+                        ops.propagate_raw(adj5.tiles, adj5.cross, X8[:, l * d:(l + 1) * d], adj5.layout, out=dz8)
+                    ops.tile_outer_raw(X8, Y8, adj5.layout)
+            for _ in range(5):
+                gs.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                gs.replay()
+            e1.record()
+            e1.synchronize()
+            mss = e0.elapsed_time(e1) / 15
+            bs = nl5 * (4 * lay5.nnz + 8 * 6 * sum(l5) * d) + 8 * 6 * sum(l5) * d * nl5 + 4 * lay5.nnz
+            out["roofline_cfg5_bwd_stack"] = {
+                "workload": "cfg5 backward of the K6 calls of one 8-layer stack: 8 x dH (propagate) + ONE dA over all layers "
+                            "(tile_dot_split d = 800 + cross_dot pieces)", "bound": "hbm", "achieved": bs / (mss * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bs / (mss * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": bs,
+                "avg_us": mss * 1e3, "per_layer_equivalent_us": mss * 1e3 / nl5,
+                "note": "A-hat's gradient counted once per stack (one write of the tile array); the per-call leg above is what "
+                        "rounds 1-4 ran once per layer (8 read-modify-writes of the tile array)"}
+            ts_, srcs_ = measured_traffic("cfg5_b32_bwd_stack", "tile_dot_split_kernel")
+            out["roofline_cfg5_bwd_stack"]["traffic"] = ts_
+            if srcs_:
+                out["roofline_cfg5_bwd_stack"]["traffic_source"] = srcs_
+            del gs, X8, Y8, dz8
+        del adj5, H5, dO5, gb
         torch.cuda.empty_cache()
         # the d = 512 stress variant SURVEY 8d asks for next to the reference-faithful d = 100: 18.94 MB and 1.63 GFLOP per
         # dialogue-layer = 86 flop/B, above the fp32 ridge (157 TFLOP/s / 8 TB/s = 20 flop/B): MFMA-bound, priced against
         # the dense fp32 matrix peak (the kernel carries the fp32 product on bf16 pieces, 6 MFMA products per fp32 product)
-        l8 = [512] * 8
+        if "d512" in legs5:
+            l8 = [512] * 8
 
-        def mk512(i):
-            g = torch.Generator(device=dev).manual_seed(900 + i)
-            adj = ops.build_adjacency(torch.randn(6, sum(l8), 200, device=dev, generator=g), l8)
-            return adj, torch.randn(6 * sum(l8), 512, device=dev, generator=g)
+            def mk512(i):
+                g = torch.Generator(device=dev).manual_seed(900 + i)
+                adj = ops.build_adjacency(torch.randn(6, sum(l8), 200, device=dev, generator=g), l8)
+                return adj, torch.randn(6 * sum(l8), 512, device=dev, generator=g)
 
-        ms512 = time_propagate(mk512, nsets=3, iters=12, warm_replays=8, timed_replays=4)
-        lay8 = ops.DialogueLayout.get(l8, 6, dev)
-        fl = lay8.propagate_flops(512)
-        out["roofline_cfg5_d512"] = {"workload": "cfg5 stress variant: B=8, L=512, M=6, d=512 (K6 fwd)", "bound": "mfma",
-                                     "note": "MFMA-bound, 86 flop/B", "achieved": fl / (ms512 * 1e-3) / 1e12,
-                                     "peak": 157.3, "unit": "TFLOP/s", "frac": fl / (ms512 * 1e-3) / 1e12 / 157.3,
-                                     "algorithmic_bytes": lay8.propagate_bytes(512), "avg_launch_us": ms512 * 1e3,
-                                     "hbm_frac": lay8.propagate_bytes(512) / (ms512 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            ms512 = time_propagate(mk512, nsets=3, iters=12, warm_replays=8, timed_replays=4)
+            lay8 = ops.DialogueLayout.get(l8, 6, dev)
+            fl = lay8.propagate_flops(512)
+            out["roofline_cfg5_d512"] = {"workload": "cfg5 stress variant: B=8, L=512, M=6, d=512 (K6 fwd)", "bound": "mfma",
+                                         "note": "MFMA-bound, 86 flop/B", "achieved": fl / (ms512 * 1e-3) / 1e12,
+                                         "peak": 157.3, "unit": "TFLOP/s", "frac": fl / (ms512 * 1e-3) / 1e12 / 157.3,
+                                         "algorithmic_bytes": lay8.propagate_bytes(512), "avg_launch_us": ms512 * 1e3,
+                                         "hbm_frac": lay8.propagate_bytes(512) / (ms512 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     except Exception as exc:
         print("[bench] cfg5 roofline leg skipped: %s" % exc, file=sys.stderr)
 

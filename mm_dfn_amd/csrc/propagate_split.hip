@@ -45,7 +45,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// ABLC (profiling aid, compile time): 1 = no cutting stages, 2 = no MFMAs
+// ABLC (profiling aid, compile time): 1 = no cutting stages, 2 = no MFMAs, 4 = no MFMAs of the fourth column tile (the
+// upper bound of what a tail tile for columns 96.. can buy at d = 100; results wrong)
 template <int ABLC>
 __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
                 coff[j] = 4 * (c4 < cw4 ? c4 : cw4 - 1);
                 v[j] = *reinterpret_cast<const float4*>(&Os[erow * LDO + coff[j]]);
             }
-            const int nq = (abl & 1) ? 0 : M - 1;
+            const int nq = (abl & 1) ? 0 : (abl & 2) ? 1 : M - 1;   // (2: one cross-modal row instead of M - 1, timing only)
 #pragma unroll 2
             for (int q = 0; q < nq; ++q) {
                 const int n = q + (q >= m ? 1 : 0);
@@ -246,10 +247,11 @@ int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const f
     hipLaunchKernelGGL((propagate_split_kernel<A>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
                        row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation())
 #ifdef MMDFN_TUNING
-    const char* ac = getenv("MMDFN_SPLIT_ABLC");  // compile-time ablations (1: no cutting, 2: no MFMA)
+    const char* ac = getenv("MMDFN_SPLIT_ABLC");  // compile-time ablations (1: no cutting, 2: no MFMA, 4: no fourth-tile MFMAs)
     const int ablc = ac ? atoi(ac) : 0;
     if (ablc == 1) SPLIT_LAUNCH(1);
     else if (ablc == 2) SPLIT_LAUNCH(2);
+    else if (ablc == 4) SPLIT_LAUNCH(4);
     else
 #endif
     SPLIT_LAUNCH(0);

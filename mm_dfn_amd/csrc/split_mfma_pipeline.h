@@ -79,7 +79,7 @@
             const u32x4 av_ = (pc_ == 0) ? ap3[P][KH] : (pc_ == 1 || pc_ == 3) ? ap2[P][KH] : ap1[P][KH];  \
             const int bi_ = (pc_ < 3) ? 0 : (pc_ < 5) ? 1 : 2;                                             \
             _Pragma("unroll") for (int ct_ = 0; ct_ < NCT; ++ct_) {                                        \
-                if (!(ABLC & 2)) acc[ct_] = mfma_bf16(av_, bf_[ct_][bi_], acc[ct_]);                       \
+                if (!(ABLC & 2) && !((ABLC & 4) && ct_ == 3)) acc[ct_] = mfma_bf16(av_, bf_[ct_][bi_], acc[ct_]);                       \
                 if (!(ABLC & 1)) SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 24 * (KH) + 4 * pc_ + ct_, SAFE);       \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
             }                                                                                              \
