@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 12: 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 13: 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -217,6 +217,9 @@ int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* 
 int mmdfn_keep_flags(float* out, int64_t n, float keep, void* state, void* stream);
 int64_t mmdfn_colsum_workspace(int H);
 int mmdfn_colsum(const float* A, int64_t R, int H, int lda, float* out, float* workspace, void* stream);
+/* The first launch of mmdfn_colsum alone (ABI 13): returns the number (> 0) of [H] slabs left in `workspace` for
+ * mmdfn_gemm_tn_batch_ext to sum (ext_N = 0, ext_M = H), negative = rejected. */
+int mmdfn_colsum_partial(const float* A, int64_t R, int H, int lda, float* workspace, void* stream);
 int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const int32_t* rank,
                         const int64_t* flat_idx, float* out, const float* weights,
                         int L, int B, int P, int N, int H, void* stream);
@@ -394,6 +397,19 @@ int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float* const* B, 
                         const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
                         float* const* colsum, float* const* colsum2, const int* M, const int* N, const int* ldc,
                         const int* accumulate, float* workspace, void* stream);
+/* The same batch whose reduction launch ALSO sums `next` slab stacks written by other kernels (ABI 13): stack e holds
+ * ext_splits[e] slabs of ext_M[e] x ext_N[e] floats (ext_part[e], summed into ext_C[e] of row stride ext_ldc[e]; ext_N[e] = 0:
+ * none) and / or of ext_M[e] floats (ext_colpart[e], summed into ext_colsum[e]; NULL: none), in slab order (bit-reproducible);
+ * ext_accumulate[e] != 0 adds to the destination.  Producers: mmdfn_head_bwd_partial (the classifier's dW / db, reference
+ * model.py:1337), mmdfn_colsum_partial (the bias gradient of the project-then-gather node, model.py:1082).  nseg = nout = 0 with
+ * next > 0 runs the reduction alone; nout + next <= 40. */
+int mmdfn_gemm_tn_batch_ext(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                            const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                            float* const* colsum, float* const* colsum2, const int* M, const int* N, const int* ldc,
+                            const int* accumulate, float* workspace, int next, const float* const* ext_part,
+                            const float* const* ext_colpart, float* const* ext_C, float* const* ext_colsum, const int* ext_M,
+                            const int* ext_N, const int* ext_ldc, const int* ext_splits, const int* ext_accumulate,
+                            void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused Adam step over flat fp32 buffers (replaces torch.optim.Adam(lr, weight_decay=l2).step(),
@@ -419,6 +435,12 @@ int64_t mmdfn_head_bwd_workspace(int Wd, int C);
 int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
                    float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split,
                    float mscale, void* stream);
+/* mmdfn_head_bwd without its slab reduction (ABI 13): dF is complete, `workspace` holds mmdfn_head_bwd_groups() slabs of dW
+ * ([groups][C][Wd]) followed by as many of db ([groups][C]) for mmdfn_gemm_tn_batch_ext. */
+int mmdfn_head_bwd_groups(void);
+int mmdfn_head_bwd_partial(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
+                           float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split, float mscale,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------
  * K10  FocalLoss (reference loss.py:14-34) as one launch each way:

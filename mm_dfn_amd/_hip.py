@@ -57,6 +57,11 @@ SIGNATURES = {
     "mmdfn_gemm_tn_grouped": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_gemm_tn_batch_workspace": [_I, _P, _P, _I, _P, _P],
     "mmdfn_gemm_tn_batch": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_gemm_tn_batch_ext": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P,
+                                _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_head_bwd_groups": [],
+    "mmdfn_head_bwd_partial": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "mmdfn_colsum_partial": [_P, _L, _I, _I, _P, _P],
     "mmdfn_head_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P],
     "mmdfn_head_bwd_workspace": [_I, _I],
     "mmdfn_head_bwd": [_P] * 9 + [_L, _I, _I, _I, _I, _I, _F, _P],
@@ -76,7 +81,7 @@ SIGNATURES = {
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class HipLibraryError(RuntimeError):

@@ -422,6 +422,19 @@ extern "C" int mmdfn_colsum(const float* A, int64_t R, int H, int lda, float* ou
     return 0;
 }
 
+// The first launch of mmdfn_colsum alone: workspace then holds the returned number (> 0) of [H] slabs for
+// mmdfn_gemm_tn_batch_ext to sum; negative = rejected.
+extern "C" int mmdfn_colsum_partial(const float* A, int64_t R, int H, int lda, float* workspace, void* stream) {
+    if (R <= 0 || H <= 0 || (H & 3) || lda < H || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) return -1;
+    const int ncb = (H + 63) / 64;
+    if (ncb > 64) return -1;
+    int nsl = COLSUM_SLABS;
+    if ((int64_t)nsl * 64 > R) nsl = (int)((R + 63) / 64);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ncb, nsl), dim3(256), 0, (hipStream_t)stream, A, R, H, lda, workspace);
+    if (hipGetLastError() != hipSuccess) return -2;
+    return nsl;
+}
+
 extern "C" int mmdfn_keep_flags(float* out, int64_t n, float keep, void* state, void* stream) {
     if (n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || state == nullptr || !(keep >= 0.f) || keep > 1.f) return -1;
     const int64_t n4 = n >> 2, n8 = (((n4 + 1) >> 1) + 63) & ~(int64_t)63;      // Philox counters consumed: whole waves

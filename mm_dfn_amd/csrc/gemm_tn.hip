@@ -464,6 +464,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tall_kernel(const TnSegs sq) {
                             sq.rows_per_split[p], sq.bshift[p], tile, split);
 }
 
+constexpr int TN_REDUCE_WIDE = 40;      // stacks taller than this get 8 lanes per output element
+
 __global__ void gemm_tn_batch_reduce_kernel(const TnOuts oq) {
     int p = 0;
     while (p + 1 < oq.n && (int)blockIdx.x >= oq.blk_prefix[p + 1]) ++p;
@@ -477,6 +479,46 @@ __global__ void gemm_tn_batch_reduce_kernel(const TnOuts oq) {
     float* cs2 = oq.colsum2[p];
     const int64_t total = (int64_t)M * N;
     const int64_t stride = (int64_t)nblk * blockDim.x;
+    if (splits > TN_REDUCE_WIDE) {
+        // tall stacks (foreign ones: 256 slabs of the head's backward, 48 of the column-sum kernel): 8 lanes per output element,
+        // each adds its share of the slabs in a fixed order with all its loads in flight, the partial sums meet in a fixed
+        // shuffle tree (bit-reproducible; the order of head.hip's own reduction)
+        const int sub = threadIdx.x & 7;
+        for (int64_t t = (blockIdx.x - oq.blk_prefix[p]) * (int64_t)blockDim.x + threadIdx.x; t < ((total + M + 31) & ~31ll) * 8;
+             t += stride) {
+            const int64_t idx = t >> 3;
+            const bool live = idx < total + M && (idx < total || cs != nullptr);
+            const float* src = idx < total ? part + idx : colpart + (idx - total);
+            const int64_t sstride = idx < total ? total : M;
+            float s = 0.f;
+            if (live) {
+                int k = sub;
+                for (; k + 56 < splits; k += 64) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = src[(int64_t)(k + 8 * e) * sstride];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s += v[e];
+                }
+                for (; k < splits; k += 8) s += src[(int64_t)k * sstride];
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            if (live && sub == 0) {
+                if (idx < total) {
+                    const int m = (int)(idx / N);
+                    float* dst = C + (int64_t)m * ldc + (idx - (int64_t)m * N);
+                    *dst = acc ? *dst + s : s;
+                } else {
+                    const int m = (int)(idx - total);
+                    cs[m] = acc ? cs[m] + s : s;
+                    if (cs2 != nullptr) cs2[m] = acc ? cs2[m] + s : s;
+                }
+            }
+        }
+        return;
+    }
     for (int64_t idx = (blockIdx.x - oq.blk_prefix[p]) * (int64_t)blockDim.x + threadIdx.x; idx < total + M; idx += stride) {
         if (idx < total) {
             // fixed summation order, 8 independent loads in flight per thread (a plain loop pays the latency per slab)
@@ -713,9 +755,21 @@ static bool tns_enabled() { const char* e = getenv("MMDFN_TN_SPLIT"); return !e 
 #else
 constexpr bool tns_enabled() { return true; }
 #endif
-static int tns_tiles(int M, int N, int* nblocks) {
-    const int nb = (N + MMDFN_TNS_TN - 1) / MMDFN_TNS_TN;
+// Column blocks of an output: 112 wide, or -- when that needs fewer of them by enough (a 224-column block costs about 1.5 of
+// the narrow ones: the A planes are cut once for its two halves) -- 224 wide (N = 200, 400, 512, 600: yes; 100, 300: no).
+static bool tns_wide(int N) {
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_TNS_WIDE")) { if (atoi(e) == 0) return false; }
+#endif
+    const int nn = (N + MMDFN_TNS_TN - 1) / MMDFN_TNS_TN, nw = (N + 2 * MMDFN_TNS_TN - 1) / (2 * MMDFN_TNS_TN);
+    return 3 * nw < 2 * nn;
+}
+static int tns_tiles(int M, int N, int* nblocks, int* wide = nullptr) {
+    const bool w = tns_wide(N);
+    const int bw = w ? 2 * MMDFN_TNS_TN : MMDFN_TNS_TN;
+    const int nb = (N + bw - 1) / bw;
     if (nblocks) *nblocks = nb;
+    if (wide) *wide = w ? 1 : 0;
     return ((M + MMDFN_TNS_TM - 1) / MMDFN_TNS_TM) * nb;
 }
 static int tns_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
@@ -723,9 +777,11 @@ static int tns_rows_target(int nseg, const int* R, const int* out, int nout, con
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout) continue;
-        units += (double)tns_tiles(M[o], N[o], nullptr) * R[s];
+        int wd = 0;
+        const int tiles = tns_tiles(M[o], N[o], nullptr, &wd);
+        units += (wd ? 1.5 : 1.0) * tiles * R[s];              // (a 224-column tile holds about 1.5 narrow tiles of work)
     }
-    double wgs = 512.0;
+    double wgs = 384.0;          // (round 5, with the 224-column tiles: 256 .. 768 swept on the cfg2-cfg5 batches)
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_TNS_WGS")) wgs = atof(e);
 #endif
@@ -762,11 +818,26 @@ extern "C" int64_t mmdfn_gemm_tn_batch_workspace(int nseg, const int* R, const i
     return total;
 }
 
-extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
-                                   const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
-                                   float* const* colsum, float* const* colsum2, const int* M, const int* N,
-                                   const int* ldc, const int* accumulate, float* workspace, void* stream) {
-    if (nseg < 1 || nseg > TN_MAXSEG || nout < 1 || nout > TN_MAXOUT) return -1;
+// Slab stacks produced by OTHER kernels (the head's backward, the column-sum kernel of the project-then-gather node) that the
+// batch's reduction launch sums as well -- the last launch of a backward pass, so handing them over costs no launch of their own.
+struct TnExt {
+    int n;
+    const float* const* part;       // [splits][M][N] (may be null when N = 0)
+    const float* const* colpart;    // [splits][M] or null
+    float* const* C;
+    float* const* colsum;
+    const int *M, *N, *ldc, *splits, *accumulate;
+};
+
+static int tn_batch_impl(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                         const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                         float* const* colsum, float* const* colsum2, const int* M, const int* N,
+                         const int* ldc, const int* accumulate, float* workspace, const TnExt& ext, void* stream) {
+    if (nseg < 0 || nseg > TN_MAXSEG || nout < 0 || nout + ext.n > TN_MAXOUT || (nseg == 0) != (nout == 0) ||
+        (nseg == 0 && ext.n == 0)) return -1;
+    for (int e = 0; e < ext.n; ++e)
+        if (ext.M[e] <= 0 || ext.N[e] < 0 || ext.splits[e] <= 0 || (ext.N[e] > 0 && (ext.part[e] == nullptr || ext.C[e] == nullptr ||
+            ext.ldc[e] < ext.N[e])) || (ext.colsum[e] != nullptr && ext.colpart[e] == nullptr)) return -1;
     TnSegs sq;
     TnOuts oq;
     // pass 1: splits per output (its segments stack their slabs)
@@ -814,30 +885,50 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
         oq.colsum2[o] = colsum2 ? colsum2[o] : nullptr;
         oq.M[o] = M[o]; oq.N[o] = N[o]; oq.ldc[o] = ldc[o]; oq.splits[o] = out_splits[o];
         oq.accumulate[o] = accumulate ? accumulate[o] : 0;
-        int nblk = (int)(((int64_t)M[o] * N[o] + M[o] + 255) / 256);
+        int nblk = (int)((((int64_t)M[o] * N[o] + M[o]) * (out_splits[o] > TN_REDUCE_WIDE ? 8 : 1) + 255) / 256);
         if (nblk > 256) nblk = 256;
         oq.blk_prefix[o + 1] = oq.blk_prefix[o] + nblk;
     }
-    for (int o = nout; o < TN_MAXOUT; ++o) {
+    const int ntot = nout + ext.n;
+    oq.n = ntot;
+    for (int e = 0; e < ext.n; ++e) {
+        const int o = nout + e;
+        oq.part[o] = ext.part[e]; oq.colpart[o] = ext.colpart[e];
+        oq.C[o] = ext.C[e]; oq.colsum[o] = ext.colsum[e]; oq.colsum2[o] = nullptr;
+        oq.M[o] = ext.M[e]; oq.N[o] = ext.N[e]; oq.ldc[o] = ext.ldc[e]; oq.splits[o] = ext.splits[e];
+        oq.accumulate[o] = ext.accumulate ? ext.accumulate[e] : 0;
+        const int lanes = ext.splits[e] > TN_REDUCE_WIDE ? 8 : 1;
+        int nblk = (int)((((int64_t)ext.M[e] * ext.N[e] + ext.M[e]) * lanes + 255) / 256);
+        if (nblk > 256) nblk = 256;
+        oq.blk_prefix[o + 1] = oq.blk_prefix[o] + nblk;
+    }
+    for (int o = ntot; o < TN_MAXOUT; ++o) {
         oq.part[o] = oq.colpart[o] = nullptr; oq.C[o] = oq.colsum[o] = oq.colsum2[o] = nullptr;
         oq.M[o] = oq.N[o] = oq.ldc[o] = oq.splits[o] = oq.accumulate[o] = 0;
-        oq.blk_prefix[o + 1] = oq.blk_prefix[nout];
+        oq.blk_prefix[o + 1] = oq.blk_prefix[ntot];
     }
     int used[TN_MAXOUT];
     for (int o = 0; o < nout; ++o) used[o] = 0;
     hipStream_t st = (hipStream_t)stream;
+    if (nseg == 0) {       // nothing but foreign slab stacks
+        hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[ntot]), dim3(256), 0, st, oq);
+        MMDFN_CHECK_LAUNCH();
+        return 0;
+    }
     if (split_form) {
         // longest workgroups first
         int ord[TN_MAXSEG];
         for (int s = 0; s < nseg; ++s) ord[s] = s;
-        std::stable_sort(ord, ord + nseg, [&](int a, int b) { return seg_rps[a] > seg_rps[b]; });
+        auto wg_len = [&](int q) { return seg_rps[q] * (tns_wide(N[out[q]]) ? 3 : 2); };
+        std::stable_sort(ord, ord + nseg, [&](int a, int b) { return wg_len(a) > wg_len(b); });
         TnSplitSegs tq;
         tq.n = nseg;
         tq.wg_prefix[0] = 0;
         for (int k = 0; k < nseg; ++k) {
             const int s = ord[k], o = out[s];
-            int nb = 1;
-            const int tiles = tns_tiles(M[o], N[o], &nb);
+            int nb = 1, wd = 0;
+            const int tiles = tns_tiles(M[o], N[o], &nb, &wd);
+            tq.wide[k] = wd;
             tq.A[k] = A[s]; tq.B[k] = B[s];
             tq.part[k] = part_base[o] + (int64_t)used[o] * M[o] * N[o];
             tq.colpart[k] = (oq.colsum[o] != nullptr) ? col_base[o] + (int64_t)used[o] * M[o] : nullptr;
@@ -850,11 +941,11 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
         for (int k = nseg; k < MMDFN_TNS_MAXSEG; ++k) {
             tq.A[k] = tq.B[k] = nullptr; tq.part[k] = tq.colpart[k] = nullptr;
             tq.R[k] = tq.lda[k] = tq.ldb[k] = tq.bshift[k] = tq.rows_per_split[k] = tq.splits[k] = tq.tiles[k] = tq.nblocks[k] = 0;
-            tq.M[k] = tq.N[k] = 0;
+            tq.M[k] = tq.N[k] = 0; tq.wide[k] = 0;
             tq.wg_prefix[k + 1] = tq.wg_prefix[nseg];
         }
         if (int e = mmdfn_launch_gemm_tn_split(tq, st)) return e;
-        hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[nout]), dim3(256), 0, st, oq);
+        hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[ntot]), dim3(256), 0, st, oq);
         MMDFN_CHECK_LAUNCH();
         return 0;
     }
@@ -919,7 +1010,29 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
         hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(sq.wg_prefix[nseg]), dim3(256), 0, st, sq);
     }
     MMDFN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[nout]), dim3(256), 0, st, oq);
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[ntot]), dim3(256), 0, st, oq);
     MMDFN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                                   const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                                   float* const* colsum, float* const* colsum2, const int* M, const int* N,
+                                   const int* ldc, const int* accumulate, float* workspace, void* stream) {
+    if (nseg < 1 || nout < 1) return -1;
+    const TnExt none = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return tn_batch_impl(nseg, A, B, R, lda, ldb, bshift, out, nout, C, colsum, colsum2, M, N, ldc, accumulate, workspace, none, stream);
+}
+
+extern "C" int mmdfn_gemm_tn_batch_ext(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                                       const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                                       float* const* colsum, float* const* colsum2, const int* M, const int* N,
+                                       const int* ldc, const int* accumulate, float* workspace, int next,
+                                       const float* const* ext_part, const float* const* ext_colpart, float* const* ext_C,
+                                       float* const* ext_colsum, const int* ext_M, const int* ext_N, const int* ext_ldc,
+                                       const int* ext_splits, const int* ext_accumulate, void* stream) {
+    if (next < 0 || (next > 0 && (!ext_part || !ext_colpart || !ext_C || !ext_colsum || !ext_M || !ext_N || !ext_ldc || !ext_splits)))
+        return -1;
+    const TnExt ext = {next, ext_part, ext_colpart, ext_C, ext_colsum, ext_M, ext_N, ext_ldc, ext_splits, ext_accumulate};
+    return tn_batch_impl(nseg, A, B, R, lda, ldb, bshift, out, nout, C, colsum, colsum2, M, N, ldc, accumulate, workspace, ext, stream);
 }

@@ -290,9 +290,9 @@ extern "C" int mmdfn_head_fwd(const float* F, const float* mask, const float* W,
 
 extern "C" int64_t mmdfn_head_bwd_workspace(int Wd, int C) { return (int64_t)HB_GROUPS * ((int64_t)C * Wd + C); }
 
-extern "C" int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
-                              float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split,
-                              float mscale, void* stream) {
+static int head_bwd_impl(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
+                         float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split,
+                         float mscale, bool reduce, void* stream) {
     if (N <= 0 || Wd < 4 || (Wd & 3) || C < 1 || C > HC_MAX || bad_split(Wd, ldf, split) || bad_split(Wd, lddf, split)) return -1;
     hipStream_t s = (hipStream_t)stream;
     float* part = workspace;
@@ -304,8 +304,24 @@ extern "C" int mmdfn_head_bwd(const float* dlogp, const float* logp, const float
     hipLaunchKernelGGL(head_bwd_kernel, dim3(HB_GROUPS, nblk), dim3(256), lds, s, dlogp, logp, F, mask, W, dF, part, bpart, N, Wd, C,
                        ldf, lddf, split, mscale);
     MMDFN_CHECK_LAUNCH();
+    if (!reduce) return 0;
     const int total = (C * Wd + C) * 8;               // 8 lanes per output element
     hipLaunchKernelGGL(head_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, bpart, dW, db, HB_GROUPS, C * Wd, C);
     MMDFN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mmdfn_head_bwd(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W, float* dF,
+                              float* dW, float* db, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split,
+                              float mscale, void* stream) {
+    return head_bwd_impl(dlogp, logp, F, mask, W, dF, dW, db, workspace, N, Wd, C, ldf, lddf, split, mscale, true, stream);
+}
+
+// The same launch without the slab reduction: workspace then holds mmdfn_head_bwd_groups() slabs of dW ([groups][C][Wd]) followed
+// by as many of db ([groups][C]) for mmdfn_gemm_tn_batch_ext to sum with the step's other weight gradients.
+extern "C" int mmdfn_head_bwd_groups(void) { return HB_GROUPS; }
+extern "C" int mmdfn_head_bwd_partial(const float* dlogp, const float* logp, const float* F, const float* mask, const float* W,
+                                      float* dF, float* workspace, int64_t N, int Wd, int C, int ldf, int lddf, int split,
+                                      float mscale, void* stream) {
+    return head_bwd_impl(dlogp, logp, F, mask, W, dF, nullptr, nullptr, workspace, N, Wd, C, ldf, lddf, split, mscale, false, stream);
 }

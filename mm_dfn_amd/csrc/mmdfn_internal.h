@@ -100,6 +100,7 @@ struct TnSplitSegs {
     int R[MMDFN_TNS_MAXSEG], lda[MMDFN_TNS_MAXSEG], ldb[MMDFN_TNS_MAXSEG], bshift[MMDFN_TNS_MAXSEG];
     int rows_per_split[MMDFN_TNS_MAXSEG], splits[MMDFN_TNS_MAXSEG], tiles[MMDFN_TNS_MAXSEG], nblocks[MMDFN_TNS_MAXSEG];
     int M[MMDFN_TNS_MAXSEG], N[MMDFN_TNS_MAXSEG];
+    int wide[MMDFN_TNS_MAXSEG];          // != 0: 128 x (2 MMDFN_TNS_TN) tiles, nblocks counts 224-column blocks (gemm_tn_split.hip)
     int wg_prefix[MMDFN_TNS_MAXSEG + 1];
     int n;
 };

@@ -496,6 +496,35 @@ def colsum(A):
     return out
 
 
+class _HalvesGrad:
+    """Stand-in 'parameter' of queue_slab_reduce for two biases that share one column-sum stack: its .grad is the (N,) buffer
+    whose halves were handed to the two biases."""
+
+    def __init__(self, buf):
+        self.grad = buf
+
+
+def _queue_bias_halves(A, b1, b2, n1):
+    """b1.grad, b2.grad = halves of the column sums of A (R, N): the slab kernel runs now, the sum over slabs rides on the
+    backward pass's last reduction launch."""
+    _hip.require_cuda(A)
+    _hip.require_f32(A)
+    if A.stride(1) != 1:
+        A = A.contiguous()
+    R, N = A.shape
+    lib = _hip.lib()
+    ws = torch.empty(int(lib.mmdfn_colsum_workspace(N)), dtype=torch.float32, device=A.device)
+    nsl = lib.mmdfn_colsum_partial(_hip.ptr(A), R, N, A.stride(0), _hip.ptr(ws), _hip.stream())
+    if nsl <= 0:
+        raise _hip.HipLibraryError("mmdfn_colsum_partial rejected the operand (%d)" % nsl)
+    buf = torch.empty(N, dtype=torch.float32, device=A.device)
+    b1.grad, b2.grad = buf[:n1], buf[n1:]
+    _WGQ["ext"].append(dict(part=None, colpart=ws, splits=int(nsl), M=int(N), N=0, weight=None, bias=_HalvesGrad(buf), acc=0))
+    if not _WGQ["armed"]:
+        _WGQ["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_queued_wgrads)
+
+
 class _ProjectGather(torch.autograd.Function):
     """First party-GRU layer without projecting padded party rows: gi_p = party_gather(X_m [W1; W2]^T) + [b1; b2] for every
     speaker-encoded modality m, as ONE node: a grouped launch of the few-row kernel for the projections (each modality its
@@ -544,8 +573,14 @@ class _ProjectGather(torch.autograd.Function):
         _hip.check(rc, "mmdfn_party_gather_bwd")
         db1 = db2 = None
         if b1 is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
-            db = colsum(dS.view(-1, N))
-            db1, db2 = db[:n1], db[n1:]
+            if (ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and slab_reduce_queueable(None, [b1, b2])
+                    and b1.grad is None and b2.grad is None):
+                # the column sums stay slab stacks; the step's last reduction launch sums them into ONE (N,) buffer of which the two
+                # biases' .grad are the halves (views handed over here, filled at the end of the backward pass)
+                _queue_bias_halves(dS.view(-1, N), b1, b2, n1)
+            else:
+                db = colsum(dS.view(-1, N))
+                db1, db2 = db[:n1], db[n1:]
         # input gradients: dX_m = dG_m [W1; W2] (+ the gradient that reached X_m's alias), one grouped launch
         dXs = [None] * Mn
         need = [m for m in range(Mn) if ctx.needs_input_grad[7 + m]]
@@ -859,7 +894,7 @@ def gemm_tn_grouped(problems):
 # The queue belongs to one backward pass: entering the outermost scope drops anything a failed backward left behind, and
 # leaving it flushes what the engine callback did not (or clears the queue when the backward raised).
 # ---------------------------------------------------------------------------------------------------
-_WGQ = {"segs": [], "outs": {}, "armed": False, "scope": 0, "side": None, "held": [], "pending_join": False}
+_WGQ = {"segs": [], "outs": {}, "ext": [], "armed": False, "scope": 0, "side": None, "held": [], "pending_join": False}
 # MMDFN_EARLY_WGRAD=1: issue the graph-side weight gradients (GCN stack, LSTM gate) on a second stream as soon as the graph
 # part of the backward pass is done, concurrently with the GRU backward recurrence.  OFF by default: measured slower at
 # cfg2 (1.133 vs 1.107 ms per step; the split batches cost 47.6 + 111.5 us against 140.3 us for one, and the concurrent
@@ -874,8 +909,8 @@ class wgrad_batch:
     and written to ``.grad`` directly (see the comment above).  Re-entrant; exception-safe."""
 
     def __enter__(self):
-        if _WGQ["scope"] == 0 and (_WGQ["outs"] or _WGQ["armed"]):
-            _WGQ["outs"], _WGQ["armed"] = {}, False        # stale entries of a backward that raised
+        if _WGQ["scope"] == 0 and (_WGQ["outs"] or _WGQ["ext"] or _WGQ["armed"]):
+            _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False        # stale entries of a backward that raised
         _WGQ["scope"] += 1
         return self
 
@@ -883,10 +918,10 @@ class wgrad_batch:
         _WGQ["scope"] -= 1
         if _WGQ["scope"] == 0:
             if exc_type is None:
-                if _WGQ["outs"]:
+                if _WGQ["outs"] or _WGQ["ext"]:
                     flush_queued_wgrads()                  # a backward driven without the engine callback
             else:
-                _WGQ["outs"], _WGQ["armed"] = {}, False    # the callback never ran: drop the half-built batch
+                _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False    # the callback never ran: drop the half-built batch
             _join_side()
         return False
 
@@ -936,6 +971,31 @@ def queue_wgrad(A, B, weight, biases=(), shift=0, rows=None):
         torch.autograd.Variable._execution_engine.queue_callback(flush_queued_wgrads)
 
 
+SLAB_RIDE = __import__("os").environ.get("MMDFN_SLAB_RIDE", "1") == "1"      # (0: A/B aid, the stacks get their own launches)
+
+
+def slab_reduce_queueable(weight, biases):
+    """May the slab stacks of ``weight`` / ``biases`` (partial sums another kernel wrote) be summed by the end-of-backward
+    reduction launch instead of a launch of their own?  Same rules as queue_wgrad."""
+    ps = ([weight] if weight is not None else []) + list(biases)
+    return SLAB_RIDE and _WGQ["scope"] > 0 and bool(ps) and all(_leaf(p) and not _hooked(p) for p in ps)
+
+
+def queue_slab_reduce(part, colpart, splits, M, N, weight=None, biases=()):
+    """weight.grad (M, N) += sum of the ``splits`` slabs of ``part`` ([splits][M][N]); b.grad (M) += sum of the slabs of
+    ``colpart`` ([splits][M]) for the ONE bias in ``biases`` -- summed by the reduction launch of the backward pass's
+    weight-gradient batch (mmdfn_gemm_tn_batch_ext).  Only inside a backward pass under ``wgrad_batch()``."""
+    if _WGQ["scope"] <= 0:
+        raise RuntimeError("queue_slab_reduce outside a wgrad_batch() scope")
+    if len(biases) > 1 or (weight is None) != (part is None) or (colpart is None) != (len(biases) == 0):
+        raise RuntimeError("queue_slab_reduce: one weight and / or one bias per slab stack")
+    _WGQ["ext"].append(dict(part=part, colpart=colpart, splits=int(splits), M=int(M), N=int(N) if weight is not None else 0,
+                            weight=weight, bias=biases[0] if biases else None))
+    if not _WGQ["armed"]:
+        _WGQ["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(flush_queued_wgrads)
+
+
 def _join_side():
     """The main stream waits for the side-stream batch (if one is in flight); its operands may be released afterwards."""
     if _WGQ["pending_join"]:
@@ -956,10 +1016,10 @@ def set_graph_backward_done_hook(fn):
 
 def flush_queued_wgrads_now():
     """Issue the weight gradients queued so far on the current stream (the end-of-backward callback flushes the rest)."""
-    if _WGQ["outs"]:
-        outs = list(_WGQ["outs"].values())
-        _WGQ["outs"] = {}                    # 'armed' stays set: the end-of-backward callback still runs for the rest
-        _flush_outs(outs, None)
+    if _WGQ["outs"] or _WGQ["ext"]:
+        outs, ext = list(_WGQ["outs"].values()), _WGQ["ext"]
+        _WGQ["outs"], _WGQ["ext"] = {}, []   # 'armed' stays set: the end-of-backward callback still runs for the rest
+        _flush_outs(outs, None, ext)
 
 
 def flush_queued_wgrads_early():
@@ -1022,14 +1082,40 @@ def apply_grad_addends():
 
 def flush_queued_wgrads():
     """Issue every queued weight-gradient contraction (one launch pair per <= 40 segments) into the .grad fields."""
-    outs = list(_WGQ["outs"].values())
-    _WGQ["outs"], _WGQ["armed"] = {}, False
+    outs, ext = list(_WGQ["outs"].values()), _WGQ["ext"]
+    _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False
     _join_side()             # first: a parameter may collect contributions from both batches (the later one accumulates)
-    if outs:
-        _flush_outs(outs, None)
+    if outs or ext:
+        _flush_outs(outs, None, ext)
 
 
-def _flush_outs(outs, side):
+def _ext_destinations(ext):
+    """.grad destinations of foreign slab stacks: fresh buffers (written) or the existing .grad (accumulated)."""
+    items = []
+    for e in ext:
+        w, b = e["weight"], e["bias"]
+        have = [p.grad is not None for p in (w, b) if p is not None]
+        acc = e["acc"] if e.get("acc") is not None else (1 if any(have) else 0)
+        C = cs = None
+        if w is not None:
+            if w.grad is None:
+                w.grad = (torch.zeros if acc else torch.empty)(e["M"], e["N"], dtype=torch.float32, device=e["part"].device)
+            elif not w.grad.is_contiguous():
+                w.grad = w.grad.contiguous()
+            C = w.grad.view(e["M"], e["N"])
+        if b is not None:
+            if b.grad is None:
+                b.grad = (torch.zeros if acc else torch.empty)(e["M"], dtype=torch.float32, device=e["colpart"].device)
+            cs = b.grad
+        items.append((e, C, cs, acc))
+    return items
+
+
+def _flush_outs(outs, side, ext=()):
+    ext_items = _ext_destinations(ext) if ext else []
+    if not outs:
+        _prepare_wgrad_batch([], ext_items)(_hip.stream())
+        return
     dev = outs[0]["weight"].device
     # gradient destinations: fresh buffers handed to .grad (the usual case: backward runs with .grad = None), or the
     # existing .grad accumulated in place
@@ -1086,7 +1172,12 @@ def _flush_outs(outs, side):
         nseg += len(item[4])
     if batch:
         batches.append(batch)
-    prepared = [_prepare_wgrad_batch(b) for b in batches]          # allocations (workspace) on the current stream
+    # foreign slab stacks ride on the last batch's reduction launch (a launch of their own when it has no room left, or when
+    # the batch leaves on the side stream)
+    ride = bool(ext_items) and side is None and len(batches[-1]) + len(ext_items) <= _WG_MAX
+    prepared = [_prepare_wgrad_batch(b, ext_items if (ride and b is batches[-1]) else None) for b in batches]          # allocations (workspace) on the current stream
+    if ext_items and not ride:
+        _prepare_wgrad_batch([], ext_items)(_hip.stream())
     if side is not None:
         side.wait_stream(torch.cuda.current_stream())             # operands, zero fills and allocations are ordered before
         _WGQ["held"].append((outs, prepared))
@@ -1100,9 +1191,31 @@ def _launch_wgrad_batch(batch):
     _prepare_wgrad_batch(batch)(_hip.stream())
 
 
-def _prepare_wgrad_batch(batch):
+def _prepare_wgrad_batch(batch, ext_items=None):
     lib = _hip.lib()
     ia = _hip.int_array
+    pa = lambda ts: (ctypes.c_void_p * max(1, len(ts)))(*[None if t is None else t.data_ptr() for t in ts])
+    ext_items = ext_items or []
+    ext_args = None
+    if ext_items:
+        ep = [e["part"] for e, _, _, _ in ext_items]
+        ec = [e["colpart"] for e, _, _, _ in ext_items]
+        eC = [C for _, C, _, _ in ext_items]
+        es = [cs for _, _, cs, _ in ext_items]
+        _hip.require_f32(*[t for t in ep + ec + eC + es if t is not None])
+        ext_args = (len(ext_items), pa(ep), pa(ec), pa(eC), pa(es), ia([e["M"] for e, _, _, _ in ext_items]),
+                    ia([e["N"] for e, _, _, _ in ext_items]), ia([0 if C is None else C.stride(0) for _, C, _, _ in ext_items]),
+                    ia([e["splits"] for e, _, _, _ in ext_items]), ia([a for _, _, _, a in ext_items]))
+        ext_keep = (ep, ec, eC, es)
+    if not batch:
+        if not ext_items:
+            return lambda stream: None
+
+        def call_ext(stream, _keep=ext_keep):
+            rc = lib.mmdfn_gemm_tn_batch_ext(0, None, None, None, None, None, None, None, 0, None, None, None, None, None, None,
+                                             None, None, *ext_args, stream)
+            _hip.check(rc, "mmdfn_gemm_tn_batch_ext")
+        return call_ext
     A, B, R, lda, ldb, sh, oi = [], [], [], [], [], [], []
     C, cs1, cs2, M, N, ldc, acc = [], [], [], [], [], [], []
     for k, (o, Ct, cs, a, segs) in enumerate(batch):
@@ -1119,9 +1232,13 @@ def _prepare_wgrad_batch(batch):
     if nws < 0:
         raise _hip.HipLibraryError("mmdfn_gemm_tn_batch_workspace rejected the batch")
     ws = torch.empty(int(nws), dtype=torch.float32, device=A[0].device)
-    pa = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
 
-    def call(stream, _keep=(A, B, C, cs1, cs2, ws)):
+    def call(stream, _keep=(A, B, C, cs1, cs2, ws, ext_items)):
+        if ext_args is not None:
+            rc = lib.mmdfn_gemm_tn_batch_ext(len(A), pa(A), pa(B), ia(R), ia(lda), ia(ldb), ia(sh), ia(oi), len(C), pa(C), pa(cs1),
+                                             pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), *ext_args, stream)
+            _hip.check(rc, "mmdfn_gemm_tn_batch_ext")
+            return
         rc = lib.mmdfn_gemm_tn_batch(len(A), pa(A), pa(B), ia(R), ia(lda), ia(ldb), ia(sh), ia(oi), len(C), pa(C), pa(cs1),
                                      pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), stream)
         _hip.check(rc, "mmdfn_gemm_tn_batch")
@@ -1730,6 +1847,7 @@ class _Head(torch.autograd.Function):
                 Fm = Fm.contiguous()
             (N, Wd), split, ldf = Fm.shape, 0, Fm.stride(0)
         C = weight.shape[0]
+        ctx.refs = (weight, bias)          # the parameters themselves (slab_reduce_queueable looks at .is_leaf / hooks)
         weight, bias = weight.contiguous(), bias.contiguous()
         mask = mask.contiguous() if mask is not None else None
         logp = torch.empty(N, C, dtype=torch.float32, device=Fm.device)
@@ -1749,9 +1867,20 @@ class _Head(torch.autograd.Function):
         dlogp = dlogp.contiguous()
         lib = _hip.lib()
         dF = torch.empty(Fm.shape, dtype=torch.float32, device=Fm.device)
+        ws = torch.empty(int(lib.mmdfn_head_bwd_workspace(Wd, C)), dtype=torch.float32, device=Fm.device)
+        pw, pb = ctx.refs
+        if (ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and tuple(pw.shape) == (C, Wd) and pw.is_contiguous()
+                and slab_reduce_queueable(pw, [pb])):
+            # dW / db stay slab stacks: the reduction launch of the step's weight-gradient batch sums them (no launch of their own)
+            rc = lib.mmdfn_head_bwd_partial(_hip.ptr(dlogp), _hip.ptr(logp), _hip.ptr(Fm), _hip.ptr(mask), _hip.ptr(weight),
+                                            _hip.ptr(dF), _hip.ptr(ws), N, Wd, C, ldf, split if split else Wd, split, ctx.mscale,
+                                            _hip.stream())
+            _hip.check(rc, "mmdfn_head_bwd_partial")
+            G = int(lib.mmdfn_head_bwd_groups())
+            queue_slab_reduce(ws[:G * C * Wd], ws[G * C * Wd:], G, C, Wd, weight=pw, biases=[pb])
+            return dF, None, None, None, None
         dW = torch.empty(C, Wd, dtype=torch.float32, device=Fm.device)
         db = torch.empty(C, dtype=torch.float32, device=Fm.device)
-        ws = torch.empty(int(lib.mmdfn_head_bwd_workspace(Wd, C)), dtype=torch.float32, device=Fm.device)
         rc = lib.mmdfn_head_bwd(_hip.ptr(dlogp), _hip.ptr(logp), _hip.ptr(Fm), _hip.ptr(mask), _hip.ptr(weight), _hip.ptr(dF),
                                 _hip.ptr(dW), _hip.ptr(db), _hip.ptr(ws), N, Wd, C, ldf, split if split else Wd, split,
                                 ctx.mscale, _hip.stream())

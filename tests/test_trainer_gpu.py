@@ -407,6 +407,49 @@ def test_weight_gradient_batch_is_opt_in_and_matches_plain_autograd():
     assert not ops._WGQ["outs"] and not ops._WGQ["armed"]
 
 
+def test_slab_stacks_of_the_head_and_the_gather_bias_ride_on_the_batch_reduction():
+    """Round 5: the classifier's dW / db slabs (mmdfn_head_bwd_partial) and the column-sum slabs of the project-then-gather
+    node's bias gradient (mmdfn_colsum_partial) are summed by the reduction launch of the step's weight-gradient batch
+    (mmdfn_gemm_tn_batch_ext): no head_reduce / colsum_final launch in the trace, same gradients as plain autograd (checked by
+    the test above), and a second backward without zero_grad accumulates (the bias halves then take the autograd path)."""
+    from torch.profiler import ProfilerActivity, profile
+    from mm_dfn_amd import ops
+    m = _model().train()
+    b, flat = _step_inputs()
+    seen = []
+    orig = ops._prepare_wgrad_batch
+
+    def spy(batch, ext_items=None):
+        seen.append((len(batch), len(ext_items or [])))
+        return orig(batch, ext_items)
+    ops._prepare_wgrad_batch = spy
+    try:
+        torch.manual_seed(3)
+        T.backward(_loss(m, b, flat))
+    finally:
+        ops._prepare_wgrad_batch = orig
+    assert seen and sum(e for _, e in seen) == 2 and seen[-1][0] > 0, seen        # both stacks ride on the last batch
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert "smax_fc.weight" in g1 and "smax_fc.bias" in g1
+    torch.manual_seed(3)
+    T.backward(_loss(m, b, flat))                       # no zero_grad: every gradient doubles
+    for n, p in m.named_parameters():
+        if n in g1:
+            scale = float(g1[n].abs().max()) + 1e-12
+            assert float((p.grad - 2 * g1[n]).abs().max()) / scale < 2e-5, n
+    m.zero_grad(set_to_none=True)
+    T.backward(_loss(m, b, flat))
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        m.zero_grad(set_to_none=True)
+        T.backward(_loss(m, b, flat))
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert any("head_bwd_kernel" in n for n in names) and any("gemm_tn_batch_reduce" in n for n in names), names
+    assert not [n for n in names if "head_reduce" in n or "colsum_final" in n], names
+    assert not ops._WGQ["outs"] and not ops._WGQ["ext"] and not ops._WGQ["armed"]
+
+
 def test_parameter_hooks_fire_under_the_weight_gradient_batch():
     m = _model().train()
     b, flat = _step_inputs()

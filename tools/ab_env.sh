@@ -1,0 +1,11 @@
+# Same-box A/B of one environment switch on the bench workloads:  bash tools/ab_env.sh VAR A_VALUE B_VALUE [cfg ...]
+var=$1; a=$2; b=$3; shift 3
+cfgs=${@:-cfg2}
+for cfg in $cfgs; do
+  for rep in 1 2 3; do
+    for v in $a $b; do
+      ms=$(env $var=$v python bench.py --config $cfg --no-extra --no-roofline --no-cpu-baseline --steps 300 --warmup 40 2>/dev/null | python -c "import json,sys; print('%.4f' % json.loads(sys.stdin.read())['ms_per_step'])")
+      echo "$cfg $var=$v rep$rep $ms ms"
+    done
+  done
+done
