@@ -1612,6 +1612,15 @@ int seg_slots(SegInfo& S, int ngroups, const int* rows, const int* T, const int3
     return start;
 }
 
+// Launches with more sequence-directions than this run the MFMA form (gru_mfma.hip: 16 sequences per workgroup, ~1.2 us per
+// step whatever the batch): beyond two rounds of the one-sequence-per-workgroup kernels (512 slots each) it is the shorter launch.
+int mfma_min_chains() {
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_GRU_MFMA_MIN")) return atoi(e);      // tests / A-B: 0 forces the form, a huge value disables it
+#endif
+    return 1024;
+}
+
 bool kpart_any_size() {
 #ifdef MMDFN_TUNING
     const char* e = getenv("MMDFN_GRU_KPART_BWD");
@@ -1673,6 +1682,11 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
+    {
+        int chains = 0;
+        for (int g = 0; g < ngroups; ++g) chains += 2 * rows[g];
+        if (chains > mfma_min_chains() && G.abl == 0) return mmdfn_launch_gru_fwd_mfma(ngroups, gi, w_hh, b_hh, y, gates, rows, T, s);
+    }
     // the 5-wave kernel runs one workgroup per CU (its fifth wave shares a SIMD with a recurrence wave at ~210 VGPRs each):
     // it wins while every sequence gets a CU of its own in one round (cfg2: 160 workgroups); beyond that the 4-wave kernel,
     // two workgroups per CU, needs fewer rounds (cfg3 / cfg4: +4-5 % step time with the 5-wave kernel, measured)
@@ -1716,6 +1730,11 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     G.slice0[ngroups] = sl;
     dim3 grid(sl, 2), block(NT);
     hipStream_t s = (hipStream_t)stream;
+    {
+        int chains = 0;
+        for (int g = 0; g < ngroups; ++g) chains += 2 * rows[g];
+        if (chains > mfma_min_chains()) return mmdfn_launch_gru_bwd_mfma(ngroups, dy, y, gates, w_hh, dgi, dgh, rows, T, s);
+    }
     // (the 8-wave kernel runs one workgroup per CU: it wins while all sequences fit in one round; beyond that the lane-pair
     // kernel, two workgroups per CU, keeps the batch in one round -- cfg4: 320 workgroups, 1.75 vs 1.69 ms per step)
     if (R == 1 && (2 * sl <= 256 || kpart_any_size()) && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 0>), grid, dim3(512), 0, s, G);

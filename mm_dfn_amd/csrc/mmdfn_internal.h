@@ -105,3 +105,11 @@ struct TnSplitSegs {
     int n;
 };
 int mmdfn_launch_gemm_tn_split(const TnSplitSegs& sq, hipStream_t s);
+
+// MFMA form of the GRU recurrence for launches with very many sequences (gru_mfma.hip): 16 sequences per workgroup, the
+// recurrent products on bf16 pieces.  Same operands and layouts as mmdfn_gru_seq_fwd / _bwd; -2 = not covered.
+int mmdfn_launch_gru_fwd_mfma(int ngroups, const float* const* gi, const float* const* w_hh, const float* const* b_hh,
+                              float* const* y, float* const* gates, const int* rows, const int* T, hipStream_t s);
+int mmdfn_launch_gru_bwd_mfma(int ngroups, const float* const* dy, const float* const* y, const float* const* gates,
+                              const float* const* w_hh, float* const* dgi, float* const* dgh, const int* rows, const int* T,
+                              hipStream_t s);

@@ -31,9 +31,15 @@ USE_TABLE = __import__("os").environ.get("MMDFN_GRU_TABLE", "0") == "1"
 L1_SKIPS_SILENT = __import__("os").environ.get("MMDFN_GRU_L1_SEG", "0") == "1"
 
 
+MFMA_MIN_CHAINS = int(__import__("os").environ.get("MMDFN_GRU_MFMA_MIN", "1024"))    # (csrc/gru.hip: mfma_min_chains)
+
+
 def wants_truncation(n_rows_total):
+    """Valid-length launches pay when the chains they remove change the number of rounds of the one-sequence-per-workgroup
+    kernels; launches with more than MFMA_MIN_CHAINS sequence-directions run the MFMA form (csrc/gru_mfma.hip: 16 sequences per
+    workgroup, launch time independent of the batch) at full length instead."""
     if TRUNCATE == "auto":
-        return 2 * n_rows_total > CUS
+        return CUS < 2 * n_rows_total <= MFMA_MIN_CHAINS
     return bool(TRUNCATE)
 
 

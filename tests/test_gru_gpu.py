@@ -95,6 +95,34 @@ def test_rows_per_workgroup_variants_agree(R, kernel_variants):
             assert rel_err(a[2][i][k], b[2][i][k]) < 5e-5, k
 
 
+@pytest.mark.parametrize("shapes", [[(7, 3)], [(1, 5)], [(33, 40), (33, 100)], [(12, 1), (5, 2), (9, 130)], [(110, 17)]])
+def test_mfma_form_agrees_with_the_one_sequence_per_workgroup_kernels(shapes, kernel_variants):
+    """Round 5: launches with more than 1 024 sequence-directions (BASELINE cfg3) run 16 sequences per workgroup with the
+    recurrent products on bf16-piece MFMAs (csrc/gru_mfma.hip).  Forced here at small sizes (rows that are not multiples of 16,
+    one step, several groups, 110 steps) against the scalar kernels: outputs, input gradients and every parameter gradient to
+    fp32 summation-order noise -- and really a different kernel."""
+    rs = np.random.RandomState(77)
+    xs = [torch.from_numpy(rs.randn(T, R, 200).astype(np.float32)).to(DEV) for T, R in shapes]
+    ws = [torch.from_numpy(rs.randn(T, R, 200).astype(np.float32)).to(DEV) for T, R in shapes]
+    res = {}
+    for mode in ("0", "100000000"):
+        kernel_variants.setenv("MMDFN_GRU_MFMA_MIN", mode)
+        grus = [make_gru(90 + i).to(DEV) for i in range(len(shapes))]
+        xg = [x.clone().requires_grad_(True) for x in xs]
+        ys = fused.bigru2(xg, grus, 0.0, True)
+        sum((y * w).sum() for y, w in zip(ys, ws)).backward()
+        res[mode] = ([y.detach() for y in ys], [x.grad for x in xg], [dict((k, p.grad) for k, p in g.named_parameters()) for g in grus])
+    a, b = res["0"], res["100000000"]
+    differs = False
+    for i in range(len(shapes)):
+        assert abs_err(a[0][i], b[0][i]) < 2e-6
+        assert rel_err(a[1][i], b[1][i]) < 2e-5
+        differs = differs or float((a[1][i] - b[1][i]).abs().max()) > 0.0
+        for k in a[2][i]:
+            assert rel_err(a[2][i][k], b[2][i][k]) < 5e-5, k
+    assert differs
+
+
 def test_matches_torch_gru_module_eval():
     g = make_gru(3)
     x = torch.randn(40, 9, 200)
