@@ -895,6 +895,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
 //   tile per wave, K = 4H.  Staging a row block IS the pointwise gate backward (every column block recomputes it, block
 //   0 writes dG / dc to memory).
 constexpr int CBW = 64;
+constexpr int GATE_BWD_WIDE_NKC = 26;     // K-chunks of 16 a consumer wave's register tile covers (lstm_gate_bwd_ws_kernel<., true>)
 
 __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                             const float* __restrict__ c_new, const float* __restrict__ dh_a,
@@ -1014,8 +1015,13 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
 // waves 0-3 are consumers (contraction of A(i) against the weight slice, results stored straight from the accumulators);
 // one barrier per block hands the buffers over.  Every SIMD then holds one wave of each kind, so the consumer's MFMAs
 // run under the producer's loads, VALU work and stores.
+// WIDE (round 5, 64 < H <= 104): ONE column block per product (dq | dh) instead of two -- the producer side (operand loads, gate
+// math, dG / dc stores: 2/3 of the launch at 98 304 rows) is done twice per row instead of four times.  The 128-column weight
+// slice does not fit the LDS (206 KB), so consumer wave w contracts its SECOND tile (columns 64 + 16 w ..) against weight
+// fragments held in REGISTERS (<= 26 float4 per lane: K = 4 H <= 416, loaded once per workgroup straight from the parameter); the first tile
+// comes from the LDS slice as before, both share the A fragments.
 // ------------------------------------------------------------------------------------------------------------------
-template <int ABL>
+template <int ABL, bool WIDE = false>
 __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                                const float* __restrict__ c_new, const float* __restrict__ dh_a,
                                                                const float* __restrict__ dh_b, const float* __restrict__ dc_next,
@@ -1029,10 +1035,10 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
     const int ldw = lds_stride(K);
     float* sW = smem;                                  // [CBW][ldw]
     float* sA = sW + CBW * ldw;                        // [2][16][ldw]   rows dG
-    const int nb = (H + CBW - 1) / CBW;
+    const int nb = WIDE ? 1 : (H + CBW - 1) / CBW;
     const bool is_dh = (int)blockIdx.y >= nb;
-    const int n0 = (is_dh ? blockIdx.y - nb : blockIdx.y) * CBW;
-    const int ncols = min(CBW, H - n0);
+    const int n0 = WIDE ? 0 : (is_dh ? blockIdx.y - nb : blockIdx.y) * CBW;
+    const int ncols = min(CBW, H - n0);                // columns of the LDS slice (WIDE: + the register tiles behind them)
     const int nrb = (R + RB - 1) / RB;
     const int tid = threadIdx.x & 255;                 // index inside the half (consumer / producer) of the workgroup
     const bool producer = threadIdx.x >= 256;
@@ -1149,17 +1155,43 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
     const int ecol = n0 + 16 * w + frag_row(fi);        // (output column / rows of this lane's accumulator elements: frag_row)
     const bool ecol_ok = (16 * w + frag_row(fi)) < ncols;
     float* const outp = is_dh ? dh_prev : dq;
+    // WIDE: the second tile's weight fragments, lane (fi, g): column ecol2, k = 16 kc + 4 frag_unit(g) .. + 3 (K = 4 H <= 512)
+    constexpr int NKC = WIDE ? GATE_BWD_WIDE_NKC : 1;
+    const int ecol2 = CBW + 16 * w + frag_row(fi);
+    const bool ecol2_ok = WIDE && ecol2 < H;
+    const bool tile2 = WIDE && (CBW + 16 * w) < H;      // (wave-uniform: the whole tile lies past H)
+    float4 wreg[NKC];
+    if (WIDE && !producer) {
+        const float* Wsrc = is_dh ? Whh : Wih;
+        const int cc = ecol2_ok ? ecol2 : 0;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int k0 = 16 * kc + 4 * frag_unit(g);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (ecol2_ok && k0 + j < K) ? Wsrc[(int64_t)(k0 + j) * H + cc] : 0.f;
+            wreg[kc] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
     int buf = 0;
-    for (int rb = first; rb < nrb; rb += stride) {
-        const int nxt = rb + stride;
-        if (producer) {
+    // (one loop per role: inside a common loop the register allocation is the SUM of the producers' operand sets and the
+    // consumers' weight fragments; the barrier count is the same on both sides)
+    if (producer) {
+        for (int rb = first; rb < nrb; rb += stride) {
+            const int nxt = rb + stride;
             // block nxt's operands were requested one iteration ago: gate math, park, then request block nxt + stride
             if (nxt < nrb) {
                 park(sA + (buf ^ 1) * RB * ldw);
                 if (nxt + stride < nrb) issue(nxt + stride);
                 flush(nxt);
             }
-        } else {
+            __syncthreads();                           // A(nxt) is parked; A(rb)'s buffer is free
+            buf ^= 1;
+        }
+        return;
+    }
+    for (int rb = first; rb < nrb; rb += stride) {
+        {
             float rv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1167,8 +1199,45 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
                 rv[r] = (!is_dh && dres && ecol_ok && erow < R) ? dres[(int64_t)erow * lddres + ecol] : 0.f;
             }
             f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-            if (!(ABL & 1)) contract<1>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, K);
-            else acc[0][0] = sA[buf * RB * ldw + fi * ldw + g];
+            if constexpr (WIDE) {
+                float rv2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int erow = rb * RB + frag_row(4 * g + r);
+                    rv2[r] = (!is_dh && dres && ecol2_ok && erow < R) ? dres[(int64_t)erow * lddres + ecol2] : 0.f;
+                }
+                f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+                // both tiles against the same A fragments; K walked in whole chunks of 16 (the LDS rows are zero-padded, the
+                // register fragments past K hold zeros); fragments of chunk kc + 1 are fetched before the MFMAs of chunk kc
+                const float* ap = sA + buf * RB * ldw + frag_row(fi) * ldw + 4 * frag_unit(g);
+                const float* bp = sW + (wrow0[0] + frag_row(fi)) * ldw + 4 * frag_unit(g);
+                const int nk = (K + 15) >> 4;
+                float4 a_n = ld4(ap), b_n = ld4(bp);
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+                    if (kc < nk) {                                  // uniform
+                        const float4 a_c = a_n, b_c = b_n;
+                        if (kc + 1 < nk) { a_n = ld4(ap + 16 * (kc + 1)); b_n = ld4(bp + 16 * (kc + 1)); }
+                        const float av[4] = {a_c.x, a_c.y, a_c.z, a_c.w}, bv[4] = {b_c.x, b_c.y, b_c.z, b_c.w};
+                        const float cv[4] = {wreg[kc].x, wreg[kc].y, wreg[kc].z, wreg[kc].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[0], 0, 0, 0);
+                            if (tile2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cv[j], acc2, 0, 0, 0);
+                        }
+                    }
+                }
+                if (ecol2_ok && !(ABL & 8)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int erow = rb * RB + frag_row(4 * g + r);
+                        if (erow < R) outp[(int64_t)erow * H + ecol2] = acc2[r] + rv2[r];
+                    }
+                }
+            } else {
+                if (!(ABL & 1)) contract<1>(acc, wrow0, sA + buf * RB * ldw, ldw, sW, ldw, K);
+                else acc[0][0] = sA[buf * RB * ldw + fi * ldw + g];
+            }
             if (ecol_ok && !(ABL & 8)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1349,6 +1418,8 @@ inline bool layer_ws(int R) {
 
 // bf16-piece form of the K8 forward (lstm_gate_split.hip) from GATE_SPLIT_ROWS rows on (tuning build: MMDFN_GATE_SPLIT=0|1 forces)
 constexpr int GATE_SPLIT_ROWS = 16384;
+// two-tile consumers of the K8 backward (one column block per product) from this many rows on (tuning build: MMDFN_GATE_BWD_WIDE)
+constexpr int GATE_BWD_WIDE_ROWS = 16384;
 inline bool gate_split(int R, int H) {
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_GATE_SPLIT")) return atoi(e) != 0;
@@ -1456,6 +1527,20 @@ extern "C" int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, cons
         }
 #undef GBWS_ABL
 #endif
+        // WIDE: one column block per product while the register tiles reach H (64 < H <= 128) and the launch is long enough for
+        // the halved producer side to matter (the extra weight-fragment loads are a fixed cost per workgroup)
+        bool wide = H > CBW && 4 * H <= 16 * GATE_BWD_WIDE_NKC && R >= GATE_BWD_WIDE_ROWS;
+#ifdef MMDFN_TUNING
+        if (const char* e = getenv("MMDFN_GATE_BWD_WIDE")) wide = H > CBW && 4 * H <= 16 * GATE_BWD_WIDE_NKC && atoi(e) != 0;
+#endif
+        if (wide) {
+            const int ncw = has_h ? 2 : 1;
+            if (int e_ = mmdfn_allow_big_lds(lstm_gate_bwd_ws_kernel<0, true>)) return e_;
+            hipLaunchKernelGGL((lstm_gate_bwd_ws_kernel<0, true>), dim3(row_groups(R, ncw), ncw), dim3(512), ldsw, (hipStream_t)stream,
+                               gates, c_prev, c_new, dh_a, dh_b, dc_next, Wih, Whh, dres, dG, dc_prev, dq, dh_prev, R, H, has_h, lddres);
+            MMDFN_CHECK_LAUNCH();
+            return 0;
+        }
         if (int e_ = mmdfn_allow_big_lds(lstm_gate_bwd_ws_kernel<0>)) return e_;
         hipLaunchKernelGGL(lstm_gate_bwd_ws_kernel<0>, dim3(row_groups(R, ncb), ncb), dim3(512), ldsw, (hipStream_t)stream, gates,
                            c_prev, c_new, dh_a, dh_b, dc_next, Wih, Whh, dres, dG, dc_prev, dq, dh_prev, R, H, has_h, lddres);
