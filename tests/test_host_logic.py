@@ -272,3 +272,42 @@ def test_only_feature_tensors_are_row_padded():
     assert not ops.is_odd_feature_tensor(torch.zeros(5, 3, 342, dtype=torch.int64), True)
     # the role is the slot in the reference's batch tuple (textf, visuf, acouf, qmask, umask, label)
     assert ops.FEATURE_SLOTS == (0, 1, 2)
+
+
+def test_gru_launch_form_thresholds():
+    """Which form a GRU launch takes is decided from the row count alone (no device data): up to one workgroup slot per
+    sequence-direction the plain launches, above that the valid-length (merged-chain) launches, and beyond
+    MFMA_MIN_CHAINS sequence-directions the MFMA form at full length (csrc/gru_mfma.hip: its launch time does not depend on
+    the chain count, so truncation has nothing to remove there)."""
+    from mm_dfn_amd import gru
+    if gru.TRUNCATE != "auto":
+        pytest.skip("MMDFN_GRU_TRUNCATE overrides the rule")
+    assert not gru.wants_truncation(80)                     # cfg2: 160 chains on 256 CUs
+    assert gru.wants_truncation(288)                        # cfg4: 576 chains
+    assert gru.wants_truncation(gru.MFMA_MIN_CHAINS // 2)   # the last size the scalar kernels keep
+    assert not gru.wants_truncation(gru.MFMA_MIN_CHAINS // 2 + 1)
+    assert not gru.wants_truncation(960)                    # cfg3: 1 920 chains -> MFMA form
+
+
+def test_foreign_slab_stacks_get_gradient_destinations():
+    """ops._ext_destinations: slab stacks of other kernels that ride on the weight-gradient batch's reduction launch get a fresh
+    .grad (written) or accumulate into the existing one; a stack with its own buffer (the two bias halves of the
+    project-then-gather node) is written even though its stand-in already holds a buffer."""
+    from mm_dfn_amd import ops
+    w = torch.nn.Parameter(torch.zeros(6, 8))
+    b = torch.nn.Parameter(torch.zeros(6))
+    e = dict(part=torch.zeros(4, 6, 8), colpart=torch.zeros(4, 6), splits=4, M=6, N=8, weight=w, bias=b)
+    (_, C, cs, acc), = ops._ext_destinations([e])
+    assert acc == 0 and C.data_ptr() == w.grad.data_ptr() and cs.data_ptr() == b.grad.data_ptr() and tuple(C.shape) == (6, 8)
+    (_, C2, cs2, acc2), = ops._ext_destinations([e])                       # second backward without zero_grad: accumulate
+    assert acc2 == 1 and C2.data_ptr() == C.data_ptr()
+    w3 = torch.nn.Parameter(torch.zeros(6, 8))                             # one of the two exists: the missing one starts at zero
+    w3.grad = torch.ones(6, 8)
+    b3 = torch.nn.Parameter(torch.zeros(6))
+    (_, C4, cs4, acc4), = ops._ext_destinations([dict(e, weight=w3, bias=b3)])
+    assert acc4 == 1 and float(cs4.abs().sum()) == 0.0                     # the fresh bias buffer is zero-filled, then added to
+    buf = torch.empty(10)
+    half = ops._HalvesGrad(buf)
+    (_, C5, cs5, acc5), = ops._ext_destinations([dict(part=None, colpart=torch.zeros(3, 10), splits=3, M=10, N=0, weight=None,
+                                                      bias=half, acc=0)])
+    assert C5 is None and cs5 is buf and acc5 == 0
