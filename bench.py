@@ -724,7 +724,7 @@ def roofline_legs(out, a, dev, n_utt, lengths):
         b5 = lay5.propagate_bytes(d)
         t5, src5 = measured_traffic("cfg5_b32", "propagate_split_kernel")
         out["roofline_cfg5"] = {"workload": "cfg5: B=32, L=512, M=6, d=100", "bound": "hbm",
-                                "kernel": "propagate_split_kernel (K6 fwd, bf16-piece MFMA, fp32-level error)",
+                                "kernel": "propagate_split_kernel<0, true> (K6 fwd, bf16-piece MFMA, three 32-column tiles + a 16-column tail tile, fp32-level error)",
                                 "traffic": t5, "traffic_source": src5,
                                 "achieved": b5 / (ms5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": b5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b5,
@@ -739,9 +739,9 @@ def roofline_legs(out, a, dev, n_utt, lengths):
             "bound": "mfma_f32", "achieved": fl5 / (ms5 * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
             "frac": fl5 / (ms5 * 1e-3) / 1e12 / 157.3, "flop_per_algorithmic_byte": fl5 / b5,
             "ridge_flop_per_byte": 157.3e12 / (HBM_PEAK_GBS * 1e9),
-            "note": "useful fp32 flop (2 d nnz) per launch / launch time; the kernel's issue-side accounting (MFMA 23 us + "
+            "note": "useful fp32 flop (2 d nnz) per launch / launch time; the kernel's issue-side accounting (MFMA ~20 us + "
                     "piece cutting and other issue 25 us + epilogue per workgroup pair, no overlap between them on a SIMD) "
-                    "is in DESIGN.md 4g / profiles/r03_k6_memory_path.md"}
+                    "is in DESIGN.md 4g / 4k, profiles/r03_k6_memory_path.md, profiles/r05_k6_levers_upper_bounds.md"}
         # K6 backward at the same workload, reported separately: dH = A^T dO (the forward kernel, A is
         # symmetric) + dA = dO . H^T on the tile pattern (tile_dot + cross_dot); bytes_bwd = 8 nnz + 16 M N d
         legs5 = set(a.roofline_legs.split(","))

@@ -30,6 +30,9 @@ __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(ui
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_bf16_16(u32x4 a, u32x4 b, f32x4 c) {     // (the pipeline's tail tile)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // One 128 x 128 output block:  Yb[r][c] = act( sum_k Xb[r][k] Wb[c][k] + bias[c] ) (+ Yb[r][c])  for r < Rv, c < Nstore;
 // columns Nv <= c < Nstore are written as exact zeros (row padding of the block-tile layout).
@@ -98,6 +101,10 @@ __device__ __forceinline__ void split_gemm_block(const float* __restrict__ Xb, c
         }                                                                                                  \
     } while (0)
 
+constexpr bool SPLIT_TAIL = false;     // (four full 32-column tiles)
+    f32x4 acct[1];
+    const int tboff = 0;
+    (void)acct; (void)tboff;
 #include "split_mfma_pipeline.h"
 
     // ---- epilogue.  Vector path (16-byte aligned rows): accumulators -> LDS (64 rows per pass) -> four threads per

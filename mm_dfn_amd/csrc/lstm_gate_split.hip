@@ -32,6 +32,9 @@ __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(ui
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_bf16_16(u32x4 a, u32x4 b, f32x4 c) {     // (the pipeline's tail tile)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // the gate non-linearities of gcn_stack.hip (hardware exp / rcp forms, |err| < 3e-7)
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -110,6 +113,10 @@ __global__ __launch_bounds__(256, 2) void lstm_gate_fwd_split_kernel(
         }                                                                                                  \
     } while (0)
 
+constexpr bool SPLIT_TAIL = false;     // (four full 32-column tiles)
+    f32x4 acct[1];
+    const int tboff = 0;
+    (void)acct; (void)tboff;
 #include "split_mfma_pipeline.h"
 
     // ---- cell math straight from the accumulators.  C/D layout of a tile: column = lane & 31 (the unit), row = (r & 3) +

@@ -44,10 +44,14 @@ __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(ui
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma_bf16_16(u32x4 a, u32x4 b, f32x4 c) {     // (the pipeline's tail tile)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // ABLC (profiling aid, compile time): 1 = no cutting stages, 2 = no MFMAs, 4 = no MFMAs of the fourth column tile (the
 // upper bound of what a tail tile for columns 96.. can buy at d = 100; results wrong)
-template <int ABLC>
+// TAIL: 96 < d <= 112 (the reference's d = 100): three 32-column tiles + a 16-column tail tile, see split_mfma_pipeline.h
+template <int ABLC, bool TAIL = false>
 __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
@@ -58,10 +62,11 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
 #else
     const int abl = abl_arg;
 #endif
-    constexpr int NCT = 4;                 // 32-column MFMA tiles
+    constexpr int NCT = TAIL ? 3 : 4;      // 32-column MFMA tiles
+    constexpr bool SPLIT_TAIL = TAIL;
     constexpr int WROWS = 32;              // tile rows per wave
     constexpr int BM = 4 * WROWS;          // 128 tile rows per workgroup
-    constexpr int CB = 32 * NCT;
+    constexpr int CB = 128;                // feature columns staged per workgroup
     constexpr int LDO = CB + 8;            // epilogue row stride (floats): 4 rows apart -> 32 banks apart
     constexpr int OROWS = 64;              // output rows staged per epilogue pass
     constexpr int split_stride = 128 * SROW;   // dwords per bf16 piece array: one row per column (rows >= d hold zeros)
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    f32x4 acct[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // (TAIL) rows 16 half + 4 (lane >> 4) + r, column 96 + (lane & 15)
+    const int tboff = (96 + (lane & 15)) * SROW + ((lane >> 4) == 0 ? 0 : (lane >> 4) == 1 ? 8 : (lane >> 4) == 2 ? 4 : 12);
 
     // ---- k permutation inside a chunk: MFMA step kh (0,1), lane group kg (0,1), element e (0..7)  <->
     //      k = 16 kh + 8 (e >> 2) + 4 kg + (e & 3)
@@ -184,6 +191,13 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     Os[(lrow0 + (r & 3) + 8 * (r >> 2)) * LDO + 32 * ct + l32] = acc[ct][r];
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Os[(WROWS * (w & 1) + 16 * hf + 4 * (lane >> 4) + r) * LDO + 96 + (lane & 15)] = acct[hf][r];
+            }
         }
         __syncthreads();
         const int row = r0 + pass * OROWS + erow;
@@ -243,9 +257,19 @@ int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const f
     const int ncb = (d + 127) / 128;
     const int lds_bytes = 2 * 3 * 128 * SROW * 4;   // 61440 B (>= the 64 x 136 float epilogue staging)
     dim3 grid(((B + 7) / 8) * 8 * M * max_rb * ncb);
+    bool tail = d > 96 && d <= 112;        // three 32-column tiles + the 16-column tail tile
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_SPLIT_TAIL")) tail = tail && atoi(e) != 0;      // A/B aid
+#endif
 #define SPLIT_LAUNCH(A)                                                                                          \
-    hipLaunchKernelGGL((propagate_split_kernel<A>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
-                       row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation())
+    do {                                                                                                         \
+        if (tail && (A) == 0)                                                                                    \
+            hipLaunchKernelGGL((propagate_split_kernel<0, true>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
+                               row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation());        \
+        else                                                                                                     \
+            hipLaunchKernelGGL((propagate_split_kernel<A>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
+                               row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation());        \
+    } while (0)
 #ifdef MMDFN_TUNING
     const char* ac = getenv("MMDFN_SPLIT_ABLC");  // compile-time ablations (1: no cutting, 2: no MFMA, 4: no fourth-tile MFMAs)
     const int ablc = ac ? atoi(ac) : 0;

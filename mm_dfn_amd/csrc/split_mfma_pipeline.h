@@ -13,8 +13,13 @@
 //        araw[SET][f]     f = 0..3: float4 of this lane's A row at k = K0 + 8 f + 4 kg .. +3
 //        braw[SET][e][j]  e = 0,1 (kh), j = 0..7: B[k = K0 + 16 e + 4 bkg + (j&3) + 8 (j>>2)][column bcol]
 //        SAFE = 1: the chunk may reach past K (clamped addresses); SAFE = 0: fully inside
-//   variables: smem, stage_stride, split_stride, blds, boff[NCT], acc[NCT], NCT (= 4), ABLC,
+//   variables: smem, stage_stride, split_stride, blds, boff[NCT], acc[NCT], NCT (= 4; 3 with the tail tile), ABLC,
 //        nchunks, klast = (nchunks-1)*32, nfull = K / 32, limA = K - 4 kg, limB = (column staged ? K - 4 bkg : -inf)
+//   SPLIT_TAIL (constexpr bool): false = four 32-column tiles; true (propagate_split.hip, 96 < d <= 112) = three of them + a
+//        16-column TAIL tile (columns 96 .. 111) on v_mfma_f32_16x16x32_bf16: the fourth 32-column tile of a d = 100 launch
+//        carries 4 useful columns in 12 of the chunk's 48 MFMAs; the tail tile replaces them by 12 half-length ones (6 piece
+//        products x two 16-row halves, K = 32 each).  The includer then also provides  acct[2] (f32x4, rows 16 half + 4 (lane
+//        >> 4) + r, column 96 + (lane & 15))  and  tboff  (dword offset of this lane's tail fragment inside a piece array).
 // and declares nothing with the names used below.  After the fragment every LDS read has been issued; the includer
 // must __syncthreads() before reusing smem.
     float4 araw[2][4];
@@ -73,6 +78,25 @@
     // one K=16 step: 6 piece products x 4 column tiles = 24 MFMAs, the four accumulators round-robin (a
     // 32x32x16 MFMA's result is needed again only 4 MFMAs = 128 cycles later).  Product order
     // a3b1 a2b1 a1b1 | a2b2 a1b2 | a1b3  frees b1, then b2, then b3 for the reload of step (NSTG, NKH).
+// Cutting stages per MFMA slot.  Four tiles: 24 slots per step, one stage each (stage = 24 KH + slot).  Tail mode: 18 slots per
+// step + 12 tail slots behind step 1; the 24 B-side stages must retire before the mid-chunk barrier, so the first six slots of
+// step 0 carry two CONSECUTIVE stages (a pair flows through three consecutive stages), step 1 carries stages 24 .. 41 and the
+// first six tail slots the rest.
+#define SPLIT_SLOT_STAGES(P, KH, SLOT, K1, SAFE)                                                           \
+    do {                                                                                                   \
+        if constexpr (!SPLIT_TAIL) {                                                                       \
+            SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 24 * (KH) + (SLOT), SAFE);                                   \
+        } else if ((KH) == 0) {                                                                            \
+            if ((SLOT) < 6) {                                                                              \
+                SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 2 * (SLOT), SAFE);                                       \
+                SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 2 * (SLOT) + 1, SAFE);                                   \
+            } else {                                                                                       \
+                SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, (SLOT) + 6, SAFE);                                       \
+            }                                                                                              \
+        } else {                                                                                           \
+            SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 24 + (SLOT), SAFE);                                          \
+        }                                                                                                  \
+    } while (0)
 #define SPLIT_STEP(P, KH, NSTG, NKH, K1, SAFE)                                                             \
     do {                                                                                                   \
         _Pragma("unroll") for (int pc_ = 0; pc_ < 6; ++pc_) {                                              \
@@ -80,7 +104,7 @@
             const int bi_ = (pc_ < 3) ? 0 : (pc_ < 5) ? 1 : 2;                                             \
             _Pragma("unroll") for (int ct_ = 0; ct_ < NCT; ++ct_) {                                        \
                 if (!(ABLC & 2) && !((ABLC & 4) && ct_ == 3)) acc[ct_] = mfma_bf16(av_, bf_[ct_][bi_], acc[ct_]);                       \
-                if (!(ABLC & 1)) SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 24 * (KH) + 4 * pc_ + ct_, SAFE);       \
+                if (!(ABLC & 1)) SPLIT_SLOT_STAGES(P, KH, NCT * pc_ + ct_, K1, SAFE);                      \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
             }                                                                                              \
             if (pc_ == 2) SPLIT_LOADB(0, NSTG, NKH);                                                       \
@@ -94,6 +118,36 @@
     // stages 0..23) and has issued its last fragment read of chunk C (step 1's fragments are reloaded during
     // step 0), so after it LDS stage P^1 may be read (fragments of chunk C+1, step 0) and stage P may be
     // overwritten (chunk C+2, during the first half of the next period).
+// The tail tile of chunk C, behind its step 1 (the A pieces of set P are dead then): v_permlane16_swap turns the two K = 16
+// operands of a piece (lane rows: [rows 0-15 | rows 16-31] x lane group kg, for kh = 0 and kh = 1) into two K = 32 operands of 16
+// rows each (lane group j of rows 0-15: k slots {kh0 kg0, kh1 kg0, kh0 kg1, kh1 kg1}; tboff reads the B side in that order), six
+// piece products per half, then the tail fragments of chunk C + 1 are requested from stage P ^ 1 (complete since the mid-chunk
+// barrier, overwritten only behind the next one).
+#define SPLIT_TAIL_SWAP(X)                                                                                 \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int d_ = 0; d_ < 4; ++d_) {                                                 \
+            const auto r_ = __builtin_amdgcn_permlane16_swap(X[P_][0][d_], X[P_][1][d_], false, false);    \
+            X[P_][0][d_] = r_[0];                                                                          \
+            X[P_][1][d_] = r_[1];                                                                          \
+        }                                                                                                  \
+    } while (0)
+#define SPLIT_TAIL_BLOCK(P, K1, SAFE)                                                                      \
+    do {                                                                                                   \
+        constexpr int P_ = (P);                                                                            \
+        SPLIT_TAIL_SWAP(ap1); SPLIT_TAIL_SWAP(ap2); SPLIT_TAIL_SWAP(ap3);                                  \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < 6; ++pc_) {                                              \
+            const int bi_ = (pc_ < 3) ? 0 : (pc_ < 5) ? 1 : 2;                                             \
+            _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {                                          \
+                const u32x4 av_ = (pc_ == 0) ? ap3[P][hf_] : (pc_ == 1 || pc_ == 3) ? ap2[P][hf_] : ap1[P][hf_]; \
+                if (!(ABLC & 2)) acct[hf_] = mfma_bf16_16(av_, bft_[bi_], acct[hf_]);                      \
+                if (!(ABLC & 1) && 2 * pc_ + hf_ < 6) SPLIT_STAGE((P) ^ 1, K1, (P) ^ 1, 42 + 2 * pc_ + hf_, SAFE); \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+        }                                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                                   \
+            bft_[q_] = *reinterpret_cast<const u32x4*>(smem + ((P) ^ 1) * stage_stride + q_ * split_stride + tboff); \
+    } while (0)
+
 #define SPLIT_BODY(P, C, SAFE)                                                                             \
     do {                                                                                                   \
         const int kn1_ = ((C) + 1) * SBK < klast ? ((C) + 1) * SBK : klast;                                \
@@ -107,12 +161,14 @@
         SPLIT_STEP(P, 0, P, 1, kn1_, SAFE);                                                                \
         __syncthreads();                                                                                   \
         SPLIT_STEP(P, 1, (P) ^ 1, 0, kn1_, SAFE);                                                          \
+        if constexpr (SPLIT_TAIL) SPLIT_TAIL_BLOCK(P, kn1_, SAFE);                                         \
     } while (0)
 
     // chunks C+1 and C+2 (cut / loaded during chunk C) lie entirely inside the tile <=> C + 2 < nfull.
     // (The fast body stages column 0 again in the LDS rows of columns >= d: those only feed accumulator
     // columns >= d, which are never stored.)
     u32x4 bf_[NCT][3];
+    u32x4 bft_[3];                         // (tail mode) the tail tile's B fragments of one chunk, one per piece
     {   // prologue: chunk 0 -> pieces set 0 / LDS stage 0; chunk 1 raw -> set 1
         SPLIT_ISSUE(1, 0, 1);
         u32x4 bp1[2], bp2[2], bp3[2];
@@ -125,6 +181,10 @@
         SPLIT_LOADB(0, 0, 0);
         SPLIT_LOADB(1, 0, 0);
         SPLIT_LOADB(2, 0, 0);
+        if constexpr (SPLIT_TAIL) {
+#pragma unroll
+            for (int q_ = 0; q_ < 3; ++q_) bft_[q_] = *reinterpret_cast<const u32x4*>(smem + q_ * split_stride + tboff);
+        }
     }
     {
         // Period C loads chunk min(C+2, last) and cuts chunk min(C+1, last); only the PARTIAL last chunk (K % 32 != 0)
@@ -143,7 +203,10 @@
         if (nchunks & 1) SPLIT_BODY(0, c, 1);
     }
 #undef SPLIT_BODY
+#undef SPLIT_TAIL_BLOCK
+#undef SPLIT_TAIL_SWAP
 #undef SPLIT_STEP
+#undef SPLIT_SLOT_STAGES
 #undef SPLIT_LOADB
 #undef SPLIT_STAGE
 #undef SPLIT_ISSUE

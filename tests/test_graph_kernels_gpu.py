@@ -53,6 +53,10 @@ SPLIT_CASES = [
     ([140, 77], 3, 200),
     ([70], 6, 512),
     ([33, 200], 2, 132),
+    # 96 < d <= 112: three 32-column tiles + the 16-column tail tile (round 5), every width of that range
+    ([130, 45], 3, 104),
+    ([64, 300], 6, 108),
+    ([200], 2, 112),
 ]
 
 
@@ -99,6 +103,25 @@ def test_propagate_bf16_piece_kernel_is_the_large_launch_default(kernel_variants
     ref = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
     assert float((out - ref).abs().max()) < 2e-6
     assert float((out - ref).abs().max()) > 0.0   # it really was a different kernel
+
+
+@pytest.mark.parametrize("lengths,M,d", [([513, 140], 3, 100), ([77, 129], 6, 112)])
+def test_propagate_tail_tile_against_four_full_tiles(lengths, M, d, kernel_variants):
+    """The tail-tile form of the bf16-piece kernel (columns 96 .. on v_mfma_f32_16x16x32_bf16 with the A pieces regrouped by
+    v_permlane16_swap) against the four-tile form it replaces for 96 < d <= 112: same products, fp32 summation-order noise only."""
+    adj, dense, _, _ = random_block_adjacency(17, lengths, M, DEV)
+    rs = np.random.RandomState(9)
+    H = torch.from_numpy(rs.randn(M * sum(lengths), d).astype(np.float32)).to(DEV)
+    kernel_variants.setenv("MMDFN_PROP_CFG", "8")
+    outs = {}
+    for tail in ("1", "0"):
+        kernel_variants.setenv("MMDFN_SPLIT_TAIL", tail)
+        outs[tail] = ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout)
+    want = dense.double() @ H.double().cpu()
+    assert rel_err(outs["1"], want) < 1e-5
+    assert rel_err(outs["1"], outs["0"]) < 1e-6
+    assert float((outs["1"][:, 96:] - outs["0"][:, 96:]).abs().max()) > 0.0   # (really a different instruction stream there)
+    assert bool((outs["1"][:, :96] == outs["0"][:, :96]).all())        # the three full tiles are the same instructions
 
 
 @pytest.mark.parametrize("lengths,M,d", CASES)

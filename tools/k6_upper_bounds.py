@@ -25,9 +25,10 @@ lay = sets[0][0].layout
 alg = lay.propagate_bytes(d)
 
 
-def run(ablc, abl):
+def run(ablc, abl, tail=0):
     os.environ["MMDFN_SPLIT_ABLC"] = str(ablc)
     os.environ["MMDFN_PROP_ABL"] = str(abl)
+    os.environ["MMDFN_SPLIT_TAIL"] = str(tail)
     for adj, H, o in sets:
         ops.propagate_raw(adj.tiles, adj.cross, H, adj.layout, out=o)
     torch.cuda.synchronize()
@@ -48,10 +49,10 @@ def run(ablc, abl):
     return e0.elapsed_time(e1) / 105 * 1e3
 
 
-rows = [("full kernel", 0, 0), ("(a) no fourth-tile MFMAs", 4, 0), ("(b) one cross-modal row instead of five", 0, 2),
-        ("(a) + (b)", 4, 2), ("no cross-modal rows", 0, 1), ("(a) + no cross-modal rows", 4, 1), ("no MFMA at all", 2, 0),
-        ("no cutting", 1, 0)]
+rows = [("full kernel, four 32-column tiles", 0, 0, 0), ("BUILT: three tiles + the 16-column tail tile", 0, 0, 1),
+        ("(a) no fourth-tile MFMAs", 4, 0, 0), ("(b) one cross-modal row instead of five", 0, 2, 0),
+        ("(a) + (b)", 4, 2, 0), ("tail tile + (b)", 0, 2, 1), ("no cross-modal rows", 0, 1, 0), ("tail tile + no cross-modal rows", 0, 1, 1)]
 for rep in range(2):
-    for name, ablc, abl in rows:
-        us = run(ablc, abl)
+    for name, ablc, abl, tail in rows:
+        us = run(ablc, abl, tail)
         print("%-44s %6.1f us   %.3f of 8 TB/s" % (name, us, alg / (us * 1e-6) / 8e12), flush=True)
