@@ -116,8 +116,8 @@ class IndexScope:
     def _stage(self, slot, name, arr, dev):
         host = slot["bufs"].get(name)
         if host is None or tuple(host.shape) != arr.shape or host.dtype != dev.dtype:
-            host = torch.empty(arr.shape, dtype=dev.dtype)
-            host = host.pin_memory() if dev.is_cuda else host
+            # (the caching pinned allocator; `.pin_memory()` of an existing tensor registers its pages: milliseconds per call)
+            host = torch.empty(arr.shape, dtype=dev.dtype, pin_memory=bool(dev.is_cuda))
             slot["bufs"][name] = host
         host.numpy()[...] = arr
         dev.copy_(host, non_blocking=True)
