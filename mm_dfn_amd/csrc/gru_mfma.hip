@@ -7,7 +7,7 @@
 // as ceil(sequences / 512) rounds of T steps.  At cfg3 that is 3-4 rounds.  Here a workgroup owns 16 rows of one (group,
 // direction):   gh^T (300 x 16) = W_hh (300 x 100) . h_{t-1}^T (100 x 16)   per step as v_mfma_f32_16x16x32_bf16 with every
 // fp32 operand cut exactly into three bf16 pieces and the six piece products of weight >= 2^-16 (fp32-level error, see
-// propagate_split.hip): the launch lasts T steps of ~1.2 us for up to 16 x 256 sequences.
+// propagate_split.hip): the launch lasts T steps of ~2.4 us for up to 16 x 256 sequences.
 //   forward : wave w (7 waves) owns hidden units 16 w .. 16 w + 15: its three gate tiles (r, z, n) x 4 K-steps of W_hh pieces
 //             stay in registers (144 VGPRs) as the MFMA's A operand (rows = units); the B operand (k x 16 sequences) is
 //             h_{t-1} as three bf16 planes [sequence][unit] in LDS, written by the lanes that produce h_t: a lane's D fragment
@@ -17,9 +17,10 @@
 //   backward: dh_{t+1}'s recurrent term  rec^T (100 x 16) = W_hh^T (100 x 300) . dgh^T (300 x 16): wave w owns units 16 w ..,
 //             one tile x 10 K-steps of W_hh^T pieces (120 VGPRs); dgh (r, z, n pre-activation gradients) of the step just done
 //             lives in LDS as three bf16 planes [sequence][gate row].  Same lane ownership, same barrier.
-// The operands of a step (gi; dy, the saved gates, h_prev) are fetched one step ahead straight into the registers of the lane
-// that consumes them.  Used by mmdfn_gru_seq_fwd / _bwd when a launch holds more than MMDFN_GRU_MFMA_MIN_CHAINS
-// sequence-directions (gru.hip); H = 100 like every kernel of this path.
+// The operands of a step (gi; dy, the saved gates, h_prev) reach the recurrence waves through LDS slots filled by an eighth
+// wave that does nothing but load (see the kernels).  Used by mmdfn_gru_seq_fwd / _bwd when a launch holds more than
+// mfma_min_chains() = 1 024 sequence-directions (gru.hip); H = 100 like every kernel of this path.  Measurements and the tuning
+// log: profiles/r05_gru_mfma_form.md.
 #include "mmdfn_internal.h"
 #include <stdlib.h>
 

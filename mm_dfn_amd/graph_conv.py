@@ -36,7 +36,7 @@ class GraphConvolution(nn.Module):
         if isinstance(adj, BlockTileAdjacency):
             hi = ops.propagate(adj, input)           # HIP K6
         else:
-            hi = torch.mm(adj, input)                # caller supplied a dense matrix
+            hi = ops.matmul_kn(adj, input)           # caller supplied a dense matrix: the package's MFMA product, no library GEMM
         if self.variant:
             support = torch.cat([hi, h0], 1)
             r = (1 - alpha) * hi + alpha * h0
@@ -75,8 +75,8 @@ class GCNII_lyc(nn.Module):
 
     def _gate(self, q, h, c):
         """One LSTM-cell step (gate order i, f, g, o), state carried layer to layer."""
-        g = F.linear(q, self.rnn.weight_ih_l0, self.rnn.bias_ih_l0) + F.linear(h, self.rnn.weight_hh_l0,
-                                                                              self.rnn.bias_hh_l0)
+        g = ops.linear(q, self.rnn.weight_ih_l0, self.rnn.bias_ih_l0) + ops.linear(h, self.rnn.weight_hh_l0,
+                                                                                  self.rnn.bias_hh_l0)
         i, f, gg, o = g.chunk(4, 1)
         c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
         h = torch.sigmoid(o) * torch.tanh(c)
@@ -127,7 +127,7 @@ class GCNII_lyc(nn.Module):
         cur = gcn_stack.gcn_stack(x, adj, masks, mscale, self.lamda, self.alpha, self.reason_flag, self.use_residue,
                                   self.fcs[0].weight, self.fcs[0].bias, self.rnn, [c.weight for c in self.convs])
         if not self.return_feature:
-            cur = F.log_softmax(self.fcs[-1](cur), dim=1)
+            cur = F.log_softmax(ops.linear(cur, self.fcs[-1].weight, self.fcs[-1].bias), dim=1)
         return cur
 
     def _stack_params(self):
@@ -174,13 +174,13 @@ class GCNII_lyc(nn.Module):
         if self.use_residue:
             cur = torch.cat([x, cur], dim=-1)
         if not self.return_feature:
-            cur = F.log_softmax(self.fcs[-1](cur), dim=1)
+            cur = F.log_softmax(ops.linear(cur, self.fcs[-1].weight, self.fcs[-1].bias), dim=1)
         return cur
 
     def _forward_generic(self, x, adj, dump=None):
         """Literal op-by-op composition (dense adjacency tensors, non-variant / residual layers)."""
         x = F.dropout(x, self.dropout, training=self.training)
-        h0 = self.act_fn(self.fcs[0](x))
+        h0 = ops.linear(x, self.fcs[0].weight, self.fcs[0].bias, act=1)      # Linear + ReLU (hand-written kernels here too)
         cur = F.dropout(h0, self.dropout, training=self.training)
         h = torch.zeros_like(cur)
         c = torch.zeros_like(cur)
@@ -201,7 +201,7 @@ class GCNII_lyc(nn.Module):
         if self.use_residue:
             cur = torch.cat([x, cur], dim=-1)
         if not self.return_feature:
-            cur = F.log_softmax(self.fcs[-1](cur), dim=1)
+            cur = F.log_softmax(ops.linear(cur, self.fcs[-1].weight, self.fcs[-1].bias), dim=1)
         return cur
 
 

@@ -113,8 +113,18 @@ def test_gcnii_module_against_golden():
         assert rel_err(x.grad, torch.from_numpy(g["dx%d" % ci])) < 1e-4
         assert rel_err(net.convs[0].weight.grad, torch.from_numpy(g["dW0_%d" % ci])) < 1e-4
         # a dense adjacency tensor is accepted too (drop-in signature)
-        y2 = net(x.detach(), lengths, None, adj.to_dense())
+        from torch.profiler import ProfilerActivity, profile
+        dense = adj.to_dense()
+        xd = x.detach().clone().requires_grad_(True)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            y2 = net(xd, lengths, None, dense)
+            (y2 * R).sum().backward()
+            torch.cuda.synchronize()
         assert abs_err(y2, y) < 2e-5
+        assert rel_err(xd.grad, torch.from_numpy(g["dx%d" % ci])) < 1e-4
+        # ... and it stays on this package's MFMA kernels (round 5: the op-by-op composition no longer calls torch.mm / F.linear)
+        names = [e.key for e in prof.key_averages()]
+        assert not [n for n in names if n.startswith("Cijk_")], names
 
 
 def test_adjacency_against_golden():
