@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     float* Os = reinterpret_cast<float*>(smem);
     if (abl & 32) return;
     __syncthreads();   // the last step's (unused) fragment reloads have retired
-    constexpr int NJ = CB / 16;
+    constexpr int NJ = TAIL ? 7 : CB / 16;   // float4 slots per thread and row (d <= 112: at most 28 float4 per row)
     const int cw4 = dloc / 4;
     const int erow = tid >> 2;
     const int eq = tid & 3;
