@@ -744,6 +744,34 @@ def test_gcn_input_stage_kernels(R, F, H, masked, residue):
     assert rel_err(dpre, dpre_w) < 1e-6 and rel_err(dx, dx_w) < 2e-6
 
 
+@pytest.mark.parametrize("R,H,first", [(4100, 100, False), (333, 100, True), (2000, 96, False), (530, 68, False), (700, 84, True)])
+def test_lstm_gate_backward_wide_form_is_bit_identical(R, H, first, kernel_variants):
+    """Round 5: from 16 384 rows on the K8 backward runs ONE column block per product (dq | dh), every consumer wave contracting
+    its second 16-column tile against weight fragments held in registers.  Forced here at small sizes (ragged last block, first
+    layer, several H of its range 64 < H <= 100) against the two-column-block form: the same MFMA order per output column, so
+    the results are bit-identical."""
+    from mm_dfn_amd import _hip
+    P, st = _hip.ptr, _hip.stream
+    rs = np.random.RandomState(91)
+    gates = torch.rand(R, 4 * H, device=DEV)
+    c, cn, dha, dhb, dcn = (_rnd(rs, R, H) for _ in range(5))
+    dres = _rnd(rs, R, H)
+    Wih, Whh = _rnd(rs, 4 * H, H, scale=0.2), _rnd(rs, 4 * H, H, scale=0.2)
+    outs = {}
+    for mode in ("0", "1"):
+        kernel_variants.setenv("MMDFN_GATE_BWD_WIDE", mode)
+        kernel_variants.setenv("MMDFN_GATE_WS", "1")
+        dG, dq = torch.empty(R, 4 * H, device=DEV), torch.empty(R, H, device=DEV)
+        dcp = None if first else torch.empty(R, H, device=DEV)
+        dhp = None if first else torch.empty(R, H, device=DEV)
+        assert _hip.lib().mmdfn_lstm_gate_bwd(P(gates), None if first else P(c), P(cn), P(dha), P(dhb), P(dcn), P(Wih), P(Whh),
+                                               P(dres), P(dG), P(dcp), P(dq), P(dhp), R, H, 0 if first else 1, H, st()) == 0
+        outs[mode] = [t.clone() for t in (dG, dq, dcp, dhp) if t is not None]
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
+    assert float(outs["1"][1].abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("R,H,first", [(37, 100, False), (37, 100, True), (600, 36, False), (3, 4, True), (2000, 96, False),
                                        (5280, 100, False),
                                        # larger launches (ragged last block, first layer, narrow H, BASELINE cfg5 rows)
