@@ -683,7 +683,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads, a.dropout, a.cpu_budget)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
-        torch.distributed.destroy_process_group()
+        # No destroy_process_group(): tearing an RCCL group down while captured graphs with collective nodes are alive aborts
+        # once in a few runs (seen at world size 1 in the GPU tests of round 5: a helper thread inside the teardown) -- and an
+        # aborted rank would fail the launcher AFTER the result line has been written.  Every rank is past its last collective
+        # here; synchronise, meet once more, leave.
+        torch.cuda.synchronize()
+        try:
+            torch.distributed.barrier()
+        except Exception:
+            pass
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def roofline_legs(out, a, dev, n_utt, lengths):
