@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 13: 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 14: 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -365,6 +365,17 @@ int mmdfn_lstm_gate_fwd(const float* q, const float* h, const float* c, const fl
 int mmdfn_lstm_gate_fwd_ld(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
                            const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
                            int ldh, void* stream);
+/* The cell's weights as bf16 piece planes for the many-row form of the forward launch (ABI 14).  The LSTM cell of the reasoning
+ * module is shared by all layers of a stack and constant inside a step (model_GCN.py:466), so a caller whose launches take the
+ * many-row form (mmdfn_lstm_gate_takes_planes(R, H) != 0) cuts it ONCE per forward pass -- mmdfn_lstm_gate_cut_weights into
+ * mmdfn_lstm_gate_planes_workspace(H) floats -- and hands the planes to every layer's mmdfn_lstm_gate_fwd_pre (same operands
+ * as mmdfn_lstm_gate_fwd_ld; planes = NULL, h = NULL or a launch of another form: identical to mmdfn_lstm_gate_fwd_ld). */
+int64_t mmdfn_lstm_gate_planes_workspace(int H);
+int mmdfn_lstm_gate_cut_weights(const float* Wih, const float* Whh, float* planes, int H, void* stream);
+int mmdfn_lstm_gate_takes_planes(int R, int H);
+int mmdfn_lstm_gate_fwd_pre(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                            const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                            int ldh, const float* planes, void* stream);
 int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh_a, const float* dh_b,
                         const float* dc_next, const float* Wih, const float* Whh, const float* dres, float* dG,
                         float* dc_prev, float* dq, float* dh_prev, int R, int H, int has_h, int lddres, void* stream);

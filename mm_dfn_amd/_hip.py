@@ -35,6 +35,10 @@ SIGNATURES = {
     "mmdfn_gcn_input_bwd": [_P] * 9 + [_I] * 4 + [_F, _P],
     "mmdfn_lstm_gate_fwd": [_P] * 10 + [_I] * 2 + [_P],
     "mmdfn_lstm_gate_fwd_ld": [_P] * 10 + [_I] * 3 + [_P],
+    "mmdfn_lstm_gate_fwd_pre": [_P] * 10 + [_I] * 3 + [_P, _P],
+    "mmdfn_lstm_gate_planes_workspace": [_I],
+    "mmdfn_lstm_gate_cut_weights": [_P, _P, _P, _I, _P],
+    "mmdfn_lstm_gate_takes_planes": [_I, _I],
     "mmdfn_lstm_gate_bwd": [_P] * 13 + [_I] * 4 + [_P],
     "mmdfn_gcnii_layer_fwd": [_P] * 7 + [_F, _F, _I, _I, _I, _F, _P],
     "mmdfn_gcnii_layer_bwd": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _P],
@@ -81,7 +85,7 @@ SIGNATURES = {
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class HipLibraryError(RuntimeError):

@@ -1467,14 +1467,38 @@ extern "C" int mmdfn_gcn_input_bwd(const float* dcur0, const float* m0, const fl
     return 0;
 }
 
+static int lstm_gate_fwd_impl(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                              const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                              int ldh, const void* planes, void* stream);
+
 extern "C" int mmdfn_lstm_gate_fwd_ld(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
                                       const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
                                       int ldh, void* stream) {
+    return lstm_gate_fwd_impl(q, h, c, Wih, Whh, bsum, bsum2, gates, h_out, c_out, R, H, ldh, nullptr, stream);
+}
+
+// The cell's weights as bf16 piece planes for the many-row form (ABI 14): the cell is shared by all layers of a stack and
+// constant inside a step, so the caller cuts it ONCE (mmdfn_lstm_gate_cut_weights into mmdfn_lstm_gate_planes_workspace(H)
+// floats) and hands the planes to every layer's launch; launches that do not take the many-row form ignore them.
+extern "C" int64_t mmdfn_lstm_gate_planes_workspace(int H) { return (H < 8 || (H & 3)) ? -1 : mmdfn_lstm_gate_planes_floats(H); }
+extern "C" int mmdfn_lstm_gate_cut_weights(const float* Wih, const float* Whh, float* planes, int H, void* stream) {
+    return mmdfn_launch_lstm_gate_cut(Wih, Whh, planes, H, (hipStream_t)stream);
+}
+extern "C" int mmdfn_lstm_gate_fwd_pre(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                                       const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R,
+                                       int H, int ldh, const float* planes, void* stream) {
+    return lstm_gate_fwd_impl(q, h, c, Wih, Whh, bsum, bsum2, gates, h_out, c_out, R, H, ldh, planes, stream);
+}
+extern "C" int mmdfn_lstm_gate_takes_planes(int R, int H) { return (!bad_dims(R, H) && gate_split(R, H)) ? 1 : 0; }
+
+static int lstm_gate_fwd_impl(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
+                              const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R, int H,
+                              int ldh, const void* planes, void* stream) {
     if (bad_dims(R, H) || (h == nullptr) != (c == nullptr) || ldh < H || (ldh & 3)) return -1;
     if (gate_split(R, H)) {
         // many rows: the contraction on the bf16 matrix path, cell math from the accumulators (lstm_gate_split.hip)
         const int rc = mmdfn_launch_lstm_gate_fwd_split(q, h, c, Wih, Whh, bsum, bsum2, gates, h_out, c_out, R, H,
-                                                        ldh, (hipStream_t)stream);
+                                                        ldh, planes, (hipStream_t)stream);
         if (rc != -2) return rc;
     }
     const int ncb = (H + UB - 1) / UB;

@@ -105,6 +105,7 @@ constexpr bool SPLIT_TAIL = false;     // (four full 32-column tiles)
     f32x4 acct[1];
     const int tboff = 0;
     (void)acct; (void)tboff;
+constexpr bool SPLIT_BPRE = false;
 #include "split_mfma_pipeline.h"
 
     // ---- epilogue.  Vector path (16-byte aligned rows): accumulators -> LDS (64 rows per pass) -> four threads per

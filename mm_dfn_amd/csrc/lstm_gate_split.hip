@@ -40,10 +40,53 @@ __device__ __forceinline__ f32x4 mfma_bf16_16(u32x4 a, u32x4 b, f32x4 c) {     /
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+// Piece planes of [W_ih | W_hh] for the BPRE form (the cell is shared by all layers of the stack and constant inside a step,
+// model_GCN.py:466: cut ONCE per step by lstm_gate_cut_kernel instead of by every workgroup of every layer's launch).  Layout =
+// what a staging thread stores to LDS: [unit block][chunk of 32 k][piece][k-slot 2 kh + kg][accumulator column (gate, unit)] x
+// 16 bytes (the 8 k of the slot in the pipeline's order k = 32 c + 16 kh + 4 kg + (j & 3) + 8 (j >> 2)).
+constexpr int GPL_SLOT = 128;                      // u32x4 per (chunk, piece, k-slot)
+constexpr int GPL_CHUNK = 3 * 4 * GPL_SLOT;        // u32x4 per chunk
+
+__global__ __launch_bounds__(256) void lstm_gate_cut_kernel(const float* __restrict__ Wih, const float* __restrict__ Whh,
+                                                            u32x4* __restrict__ planes, int H, int nchunks, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int bcol = idx & 127;
+    const int slot = (idx >> 7) & 3;
+    const int cc = (idx >> 9) % nchunks;
+    const int ub = (idx >> 9) / nchunks;
+    const int gate = bcol >> 5, unit = 32 * ub + (bcol & 31);
+    const int e = slot >> 1, bkg = slot & 1;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * cc + 16 * e + 4 * bkg + (j & 3) + 8 * (j >> 2);
+        const int64_t row = (int64_t)(gate * H + unit) * H;
+        v[j] = (unit < H && k < 2 * H) ? (k < H ? Wih[row + k] : Whh[row + k - H]) : 0.f;
+    }
+    uint32_t pc[3][4];
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = v[j];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) pc[q][p2] = __builtin_amdgcn_perm(as_u(x[2 * p2 + 1]), as_u(x[2 * p2]), 0x07060302u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] -= as_f(as_u(x[j]) & 0xffff0000u);
+    }
+    u32x4* dst = planes + ((int64_t)(ub * nchunks + cc) * 3 * 4 + slot) * GPL_SLOT + bcol;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[q * 4 * GPL_SLOT] = u32x4{pc[q][0], pc[q][1], pc[q][2], pc[q][3]};
+}
+
+// BPRE: the weight pieces come from the planes above (h != null only: K = 2 H)
+template <bool BPRE>
 __global__ __launch_bounds__(256, 2) void lstm_gate_fwd_split_kernel(
     const float* __restrict__ q, const float* __restrict__ h, const float* __restrict__ c, const float* __restrict__ Wih,
     const float* __restrict__ Whh, const float* __restrict__ bsum, const float* __restrict__ bsum2, float* __restrict__ gates,
-    float* __restrict__ h_out, float* __restrict__ c_out, int R, int H, int ldh) {
+    float* __restrict__ h_out, float* __restrict__ c_out, int R, int H, int ldh, const u32x4* __restrict__ planes) {
+    constexpr bool SPLIT_BPRE = BPRE;
     constexpr int NCT = 4;
     constexpr int ABLC = 0;
     constexpr int WROWS = 32;
@@ -96,8 +139,15 @@ __global__ __launch_bounds__(256, 2) void lstm_gate_fwd_split_kernel(
     const int limB = bok ? K - 4 * bkg : -(1 << 30);
 
     // a 16-byte group starting at k (a multiple of 4) lies in the first block (k < H) or in the second (H % 4 == 0)
+    const u32x4* planes_lane = BPRE ? planes + (int64_t)ub * ((2 * H + SBK - 1) / SBK) * GPL_CHUNK + bcol : nullptr;
 #define SPLIT_ISSUE(SET, K0, SAFE)                                                                         \
     do {                                                                                                   \
+        if constexpr (BPRE) {                                                                              \
+            const u32x4* pp_ = planes_lane + (int64_t)((K0) / SBK) * GPL_CHUNK + bkg * GPL_SLOT;           \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                  \
+                _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)                                           \
+                    bpre[SET][e][q_] = pp_[(q_ * 4 + 2 * e) * GPL_SLOT];                                   \
+        } else                                                                                             \
         _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                      \
             _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) {                                             \
                 const int kb_ = (K0) + 16 * e + 8 * h2 + 4 * bkg;                                          \
@@ -153,13 +203,32 @@ constexpr bool SPLIT_TAIL = false;     // (four full 32-column tiles)
 // -2: shape not covered (the caller keeps the exact-f32 kernels of gcn_stack.hip)
 int mmdfn_launch_lstm_gate_fwd_split(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
                                      const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R,
-                                     int H, int ldh, hipStream_t s) {
+                                     int H, int ldh, const void* planes, hipStream_t s) {
     if (H < 8 || (H & 3) || R <= 0) return -2;
     const int nub = (H + 31) / 32;
     const int lds_bytes = 2 * 3 * 128 * SROW * 4;
     dim3 grid(((R + 127) / 128) * nub);
-    hipLaunchKernelGGL(lstm_gate_fwd_split_kernel, grid, dim3(256), lds_bytes, s, q, h, c, Wih, Whh, bsum, bsum2, gates, h_out,
-                       c_out, R, H, ldh);
+    if (planes != nullptr && h != nullptr)
+        hipLaunchKernelGGL((lstm_gate_fwd_split_kernel<true>), grid, dim3(256), lds_bytes, s, q, h, c, Wih, Whh, bsum, bsum2, gates,
+                           h_out, c_out, R, H, ldh, reinterpret_cast<const u32x4*>(planes));
+    else
+        hipLaunchKernelGGL((lstm_gate_fwd_split_kernel<false>), grid, dim3(256), lds_bytes, s, q, h, c, Wih, Whh, bsum, bsum2, gates,
+                           h_out, c_out, R, H, ldh, static_cast<const u32x4*>(nullptr));
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+// floats of the piece planes of one cell (K = 2 H)
+int64_t mmdfn_lstm_gate_planes_floats(int H) {
+    return (int64_t)((H + 31) / 32) * ((2 * H + SBK - 1) / SBK) * GPL_CHUNK * 4;
+}
+
+int mmdfn_launch_lstm_gate_cut(const float* Wih, const float* Whh, void* planes, int H, hipStream_t s) {
+    if (H < 8 || (H & 3) || Wih == nullptr || Whh == nullptr || planes == nullptr) return -1;
+    const int nchunks = (2 * H + SBK - 1) / SBK;
+    const int total = ((H + 31) / 32) * nchunks * 4 * 128;
+    hipLaunchKernelGGL(lstm_gate_cut_kernel, dim3((total + 255) / 256), dim3(256), 0, s, Wih, Whh, reinterpret_cast<u32x4*>(planes), H,
+                       nchunks, total);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

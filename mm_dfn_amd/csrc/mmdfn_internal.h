@@ -71,7 +71,10 @@ int mmdfn_launch_linear_split(const float* X, const float* W, const float* W2, i
 // bf16-piece form of the GCN stack's LSTM cell for many-row launches (lstm_gate_split.hip); -2 = shape not covered
 int mmdfn_launch_lstm_gate_fwd_split(const float* q, const float* h, const float* c, const float* Wih, const float* Whh,
                                      const float* bsum, const float* bsum2, float* gates, float* h_out, float* c_out, int R,
-                                     int H, int ldh, hipStream_t s);
+                                     int H, int ldh, const void* planes, hipStream_t s);
+// piece planes of the cell's weights for the form above (cut once per step; `planes` = null: every workgroup cuts its own)
+int64_t mmdfn_lstm_gate_planes_floats(int H);
+int mmdfn_launch_lstm_gate_cut(const float* Wih, const float* Whh, void* planes, int H, hipStream_t s);
 
 int mmdfn_launch_tile_dot_split(const float* X, const float* Y, float* out_tiles, const int32_t* dia_len,
                                 const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx,

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
         }                                                                                                  \
     } while (0)
 
+constexpr bool SPLIT_BPRE = false;
 #include "split_mfma_pipeline.h"   // araw / braw / piece sets, cutting stages, MFMA steps, the chunk loops
 
     // ---- epilogue through LDS, OROWS rows per pass (the loop's last barrier has retired every fragment read).

@@ -15,6 +15,9 @@
 //        SAFE = 1: the chunk may reach past K (clamped addresses); SAFE = 0: fully inside
 //   variables: smem, stage_stride, split_stride, blds, boff[NCT], acc[NCT], NCT (= 4; 3 with the tail tile), ABLC,
 //        nchunks, klast = (nchunks-1)*32, nfull = K / 32, limA = K - 4 kg, limB = (column staged ? K - 4 bkg : -inf)
+//   SPLIT_BPRE (constexpr bool): true = the B operand arrives as bf16 pieces (SPLIT_ISSUE fills bpre[SET][kh][piece] with the
+//        three u32x4 of this thread's k-slot instead of braw): a WEIGHT operand is cut once per step by a small kernel, the 24
+//        B-side cutting stages of every chunk vanish (lstm_gate_split.hip with its piece planes).
 //   SPLIT_TAIL (constexpr bool): false = four 32-column tiles; true (propagate_split.hip, 96 < d <= 112) = three of them + a
 //        16-column TAIL tile (columns 96 .. 111) on v_mfma_f32_16x16x32_bf16: the fourth 32-column tile of a d = 100 launch
 //        carries 4 useful columns in 12 of the chunk's 48 MFMAs; the tail tile replaces them by 12 half-length ones (6 piece
@@ -24,6 +27,7 @@
 // must __syncthreads() before reusing smem.
     float4 araw[2][4];
     float braw[2][2][8];
+    u32x4 bpre[2][2][3];                       // (SPLIT_BPRE) [set][kh][piece]: B pieces that arrive cut (a weight cut once per step)
     u32x4 ap1[2][2], ap2[2][2], ap3[2][2];     // [set][kh]
 
 
@@ -37,6 +41,16 @@
     do {                                                                                                   \
         const int u_ = (T) / 3, st_ = (T) % 3, p_ = u_ & 3, h_ = (u_ >> 2) & 1;                            \
         const int kp_ = (K0) + 16 * h_ + 8 * (p_ >> 1) + 2 * (p_ & 1);   /* + 4 kg (folded into lim) */    \
+        if (SPLIT_BPRE && u_ < 8) {                                                                        \
+            /* B pieces arrive cut (SPLIT_ISSUE filled bpre): no VALU on this side, only the LDS stores */ \
+            if (p_ == 3 && st_ == 2) {                                                                     \
+                uint32_t* dst_ = smem + (STG) * stage_stride + blds + 8 * h_;                              \
+                *reinterpret_cast<u32x4*>(dst_) = bpre[SET][h_][0];                                        \
+                *reinterpret_cast<u32x4*>(dst_ + split_stride) = bpre[SET][h_][1];                         \
+                *reinterpret_cast<u32x4*>(dst_ + 2 * split_stride) = bpre[SET][h_][2];                     \
+            }                                                                                              \
+            break;                                                                                         \
+        }                                                                                                  \
         if (st_ == 0) {                                                                                    \
             if (u_ < 8) {                                                                                  \
                 cx0 = (!(SAFE) || kp_ < limB) ? braw[SET][h_][2 * p_] : 0.f;                               \

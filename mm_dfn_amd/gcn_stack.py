@@ -14,6 +14,8 @@ than ROW_LIMIT rows (beyond anything measured: the fused node is ahead of the op
 """
 import math
 
+PRECUT = __import__("os").environ.get("MMDFN_GATE_PRECUT", "1") == "1"     # (0: A/B aid, every workgroup cuts the cell's weights itself)
+
 import torch
 
 from . import _hip, ops
@@ -62,13 +64,18 @@ class _GcnStack(torch.autograd.Function):
         # Y operand of a single adjacency-gradient contraction of width nl H in the backward pass (the adjacency is shared by
         # the layers, model_GCN.py:461-472), instead of nl read-modify-write passes over the tile array
         zin_all = new(R, nl * H) if reason else None
+        planes = None
+        if PRECUT and reason and nl > 1 and lib.mmdfn_lstm_gate_takes_planes(R, H):
+            # many-row launches (bf16-piece form): the cell's weights are cut ONCE for all layers of this forward pass
+            planes = new(int(lib.mmdfn_lstm_gate_planes_workspace(H)))
+            _hip.check(lib.mmdfn_lstm_gate_cut_weights(P(w_ih), P(w_hh), P(planes), H, st), "mmdfn_lstm_gate_cut_weights")
         for i in range(nl):
             q = cur
             rec = dict(q=q, h_prev=h, c_prev=c)
             if reason:
                 gates, h_new, c_new = new(R, 4 * H), zin_all[:, i * H:(i + 1) * H], new(R, H)
-                _hip.check(lib.mmdfn_lstm_gate_fwd_ld(P(q), P(h), P(c), P(w_ih), P(w_hh), P(b_ih), P(b_hh), P(gates), P(h_new),
-                                                      P(c_new), R, H, nl * H, st), "mmdfn_lstm_gate_fwd_ld")
+                _hip.check(lib.mmdfn_lstm_gate_fwd_pre(P(q), P(h), P(c), P(w_ih), P(w_hh), P(b_ih), P(b_hh), P(gates), P(h_new),
+                                                       P(c_new), R, H, nl * H, P(planes), st), "mmdfn_lstm_gate_fwd_pre")
                 rec.update(gates=gates, c_new=c_new)
                 h, c = h_new, c_new
                 zin = h_new

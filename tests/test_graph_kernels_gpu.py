@@ -805,6 +805,14 @@ def test_lstm_gate_kernels(R, H, first):
     # exp / rcp of the gate non-linearities: worst element of 2 M at the 1e-5 level, mean error ~1e-7
     assert rel_err(h_out, h_w) < 1e-5 and rel_err(c_out, c_w) < 1e-5
     assert rel_err(gates, torch.cat([i, f, g, o], 1)) < 1e-5
+    if not first and lib.mmdfn_lstm_gate_takes_planes(R, H):
+        # round 5: the many-row form with the cell's weights cut once into piece planes -- the same pieces, the same products
+        planes = torch.empty(int(lib.mmdfn_lstm_gate_planes_workspace(H)), device=DEV)
+        assert lib.mmdfn_lstm_gate_cut_weights(P(Wih), P(Whh), P(planes), H, st()) == 0
+        g2, h2, c2 = (torch.empty_like(t) for t in (gates, h_out, c_out))
+        assert lib.mmdfn_lstm_gate_fwd_pre(P(q), P(h), P(c), P(Wih), P(Whh), P(b_ih), P(b_hh), P(g2), P(h2), P(c2), R, H, H,
+                                           P(planes), st()) == 0
+        assert torch.equal(g2, gates) and torch.equal(h2, h_out) and torch.equal(c2, c_out)
     # backward: upstream gradients on h' (two addends), on c', and the residual addend of dq
     dh_a, dh_b, dc_n, dres_w = _rnd(rs, R, H), _rnd(rs, R, H), _rnd(rs, R, H), _rnd(rs, R, H + 12)
     dres = dres_w[:, 4:4 + H]                                       # strided residual gradient
