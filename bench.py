@@ -169,6 +169,72 @@ def time_propagate(make_set, nsets, iters, warm_replays=10, timed_replays=3):
     return e0.elapsed_time(e1) / (iters * timed_replays)
 
 
+def dependent_launch_us(n=256, replays=20):
+    """Cost of ONE MORE dependent launch inside a replayed hipGraph, measured live: a captured chain of `n` one-workgroup
+    kernels (the package's smallest launch: a 4-element Adam step on its own buffers), each depending on its predecessor
+    through the stream; HIP events around the replays.  This is the per-launch term of the step floor (tools/step_floor.py);
+    MI355X_MICROARCH.md's price list has 1.45 us for it between trivial kernels."""
+    import torch
+    from mm_dfn_amd import _hip
+    dev = torch.device("cuda", torch.cuda.current_device())
+    p = torch.zeros(4, device=dev)
+    g = torch.zeros(4, device=dev)
+    m = torch.zeros(4, device=dev)
+    v = torch.zeros(4, device=dev)
+
+    def one():
+        _hip.check(_hip.lib().mmdfn_adam_step(_hip.ptr(p), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), 4, 1e-3, 0.9, 0.999, 1e-8,
+                                              0.0, 1, _hip.stream()), "mmdfn_adam_step")
+    one()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(n):
+            one()
+    for _ in range(5):
+        gr.replay()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(replays):
+        gr.replay()
+    e1.record(s)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (n * replays)
+
+
+def attach_step_floor(dominant, config, lengths, t_launch_us):
+    """`dominant.families[*].bound` for EVERY family + `step_floor_ms`: tools/step_floor.py's analytic
+    inventory of the step's launch classes, priced per class at max(algorithmic bytes / 8 TB/s, flops / matrix peak, serial
+    chain, the dependent-launch cost measured above); the family times they are compared with are the committed rocprof
+    summary's (`dominant.source`)."""
+    if not dominant or config not in ("cfg2", "cfg3", "cfg4"):
+        return dominant
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import step_floor
+    finally:
+        sys.path.pop(0)
+    r = step_floor.for_config(config, lengths=lengths, t_launch_us=t_launch_us, measured=dominant.get("families"))
+    for k, ent in r["families"].items():
+        fam = dominant["families"].get(k)
+        if fam is None:
+            continue
+        prev = fam.get("bound")
+        fam["bound"] = {"floor_us_per_step": ent["floor_us"], "floor_f32_mfma_us_per_step": ent["floor_f32_mfma_us"],
+                        "frac": ent.get("frac"), "launches_modelled": ent["launches_modelled"], "classes": ent["classes"]}
+        if prev is not None:
+            fam["bound"]["detail"] = prev                      # (the GRU family's chain model of tools/step_breakdown.py)
+    dominant["step_floor_ms"] = r["step_floor_us"] / 1e3
+    dominant["step_floor_f32_mfma_ms"] = r["step_floor_f32_mfma_us"] / 1e3
+    dominant["step_floor_method"] = r["method"]
+    dominant["dependent_launch_us"] = t_launch_us
+    if dominant.get("kernel_us_per_step"):
+        dominant["step_floor_frac_of_kernel_time"] = round(r["step_floor_us"] / dominant["kernel_us_per_step"], 3)
+    return dominant
+
+
 def timed_replays(cap, steps, warmup, post=None):
     import torch
     for _ in range(warmup):
@@ -601,7 +667,8 @@ def main():
                 loss = loss_f(logp, label) * scale
                 train.backward(loss)
                 return loss
-            local_ms = timed_replays(CapturedStep(model, fwd_bwd_local, warmup=2), max(10, a.steps // 4), 3) * 1e3
+            cap_local = CapturedStep(model, fwd_bwd_local, warmup=2)
+            local_ms = timed_replays(cap_local, max(10, a.steps // 4), 3) * 1e3
             every = [None] * world
             torch.distributed.all_gather_object(every, local_ms)
             bucket_bytes = dp.flat.numel() * 4 if (dp is not None and dp.flat is not None) else 0
@@ -665,8 +732,12 @@ def main():
             out["gradient_bucket"] = {"floats": dp.flat.numel(), "bytes": dp.flat.numel() * 4, "backend": a.backend}
         if not a.no_roofline:
             roofline_legs(out, a, dev, n_utt, lengths)
-        out["dominant"] = (profile_json("r05_step_breakdown_%s.json" % a.config) or profile_json("r04_step_breakdown_%s.json" % a.config) or profile_json("r03_step_breakdown_%s.json" % a.config)
-                           or profile_json("r02_step_breakdown_%s.json" % a.config))
+        out["dominant"] = (profile_json("r06_step_breakdown_%s.json" % a.config) or profile_json("r05_step_breakdown_%s.json" % a.config)
+                           or profile_json("r04_step_breakdown_%s.json" % a.config))
+        try:
+            out["dominant"] = attach_step_floor(out["dominant"], a.config, [int(x) for x in lengths], dependent_launch_us())
+        except Exception as exc:
+            print("[bench] step floor not attached: %s: %s" % (type(exc).__name__, exc), file=sys.stderr)
         if world == 1 and not a.no_extra and not use_dp:
             out["other_workloads"] = []
             legs = [lambda c=c, r=r: quick_leg(c, r, a.dropout) for c, r in
@@ -683,18 +754,25 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, batch, model.state_dict(), a.cpu_threads, a.dropout, a.cpu_budget)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dp:
-        # No destroy_process_group(): tearing an RCCL group down while captured graphs with collective nodes are alive aborts
-        # once in a few runs (seen at world size 1 in the GPU tests of round 5: a helper thread inside the teardown) -- and an
-        # aborted rank would fail the launcher AFTER the result line has been written.  Every rank is past its last collective
-        # here; synchronise, meet once more, leave.
+        # Normal teardown (round 6): the captured steps that hold a collective node are released FIRST (CapturedStep.close():
+        # hipGraphExec + pool gone, device idle), then the ranks meet and the group is destroyed; an exception here -- or a
+        # teardown that does not return within two minutes -- ends this rank with a non-zero exit code, so a rank that dies
+        # after the result line is visible to the launcher (round 5 left through os._exit(0), which hid exactly that).
+        import gc
+        import threading
+        guard = threading.Timer(120.0, lambda: os._exit(3))
+        guard.daemon = True
+        guard.start()
+        for name in ("captured", "cap_local"):
+            cap = locals().get(name)
+            if cap is not None and hasattr(cap, "close"):
+                cap.close()
+        cap = None
+        gc.collect()
         torch.cuda.synchronize()
-        try:
-            torch.distributed.barrier()
-        except Exception:
-            pass
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        guard.cancel()
 
 
 def roofline_legs(out, a, dev, n_utt, lengths):

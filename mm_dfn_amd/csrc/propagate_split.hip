@@ -55,12 +55,28 @@ template <int ABLC, bool TAIL = false>
 __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     const float* __restrict__ tiles, const float* __restrict__ cross, const float* __restrict__ H,
     float* __restrict__ out, const int32_t* __restrict__ dia_len, const int32_t* __restrict__ row_start,
-    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl_arg) {
+    const int64_t* __restrict__ tile_base, int B, int M, int N, int d, int ldh, int ldo, int max_rb, int ncb, int abl_arg,
+    unsigned long long* trace_arg) {
 #ifndef MMDFN_TUNING
     constexpr int abl = 0;                 // production build: no ablation paths
     (void)abl_arg;
+    (void)trace_arg;
+#define SPLIT_STAMP(K) do { } while (0)
 #else
     const int abl = abl_arg;
+    unsigned long long* trace = trace_arg;
+    // per-workgroup timeline (tools/k6_trace.py): slots 0..5 = s_memtime stamps, 7 = (XCC_ID << 32) | HW_ID
+#define SPLIT_STAMP(K)                                                                                     \
+    do {                                                                                                   \
+        if (trace && threadIdx.x == 0) trace[(int64_t)blockIdx.x * 8 + (K)] = __builtin_readcyclecounter(); \
+    } while (0)
+    SPLIT_STAMP(0);
+    if (trace && threadIdx.x == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[(int64_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    }
 #endif
     constexpr int NCT = TAIL ? 3 : 4;      // 32-column MFMA tiles
     constexpr bool SPLIT_TAIL = TAIL;
@@ -78,13 +94,26 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
     const int Rt = max_rb * ncb;
     const int Rd = M * Rt;
     const int bid = blockIdx.x;
-    const int yq = bid >> 3;
+    int yq = bid >> 3;
+#ifdef MMDFN_TUNING
+    // (experiment) co-residency pairing: if workgroups yq and yq + 32 of an XCD share a CU, make them neighbours v = 2a, 2a + 1
+    const int dec = (abl >> 8) & 3;
+    if (dec) {
+        const int tot = (int)(gridDim.x >> 3);
+        const int blk = yq >> 6, j = yq & 63;
+        if ((blk + 1) * 64 <= tot) yq = blk * 64 + 2 * (j & 31) + (j >> 5);
+    }
+#else
+    constexpr int dec = 0;
+#endif
     const int i = (yq / Rd) * 8 + (bid & 7);
     if (i >= B) return;
     const int rho = yq % Rd;
-    const int m = rho / Rt;
-    const int rb = (rho - m * Rt) / ncb;
-    const int c0 = ((rho - m * Rt) - rb * ncb) * CB;
+    // dec 2: modality fastest (neighbours = two modalities of one row block: they share four of their five cross-modal rows);
+    // dec 0 / 1: row block fastest (neighbours = two row blocks of one modality: they share the B operand stream)
+    const int m = dec == 2 ? rho % M : rho / Rt;
+    const int rb = dec == 2 ? (rho / M) / ncb : (rho - m * Rt) / ncb;
+    const int c0 = dec == 2 ? ((rho / M) % ncb) * CB : ((rho - m * Rt) - rb * ncb) * CB;
     const int dloc = (d - c0 < CB) ? d - c0 : CB;      // columns of this block that exist
     const int L = dia_len[i];
     const int r0 = rb * BM;
@@ -169,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void propagate_split_kernel(
         }                                                                                                  \
     } while (0)
 
+    SPLIT_STAMP(1);
 constexpr bool SPLIT_BPRE = false;
 #include "split_mfma_pipeline.h"   // araw / braw / piece sets, cutting stages, MFMA steps, the chunk loops
 
@@ -176,6 +206,7 @@ constexpr bool SPLIT_BPRE = false;
     // Four threads per output row, each owning every 4th float4 of it: the M-1 cross-modal weights of the
     // row are loaded once per thread and all its H loads of one modality are in flight together.
     float* Os = reinterpret_cast<float*>(smem);
+    SPLIT_STAMP(2);
     if (abl & 32) return;
     __syncthreads();   // the last step's (unused) fragment reloads have retired
     constexpr int NJ = TAIL ? 7 : CB / 16;   // float4 slots per thread and row (d <= 112: at most 28 float4 per row)
@@ -218,7 +249,8 @@ constexpr bool SPLIT_BPRE = false;
                 const int n = q + (q >= m ? 1 : 0);
                 const int pk = (m < n) ? mmdfn_pair_index(m, n, M) : mmdfn_pair_index(n, m, M);
                 const float cwt = cross[(int64_t)pk * N + grow];
-                const float* hrow = H + ((int64_t)n * N + grow) * ldh + c0;
+                // (abl & 8, timing only: the cross-modal rows of a workgroup alias 8 rows -> L1 hits)
+                const float* hrow = H + ((int64_t)n * N + ((abl & 8) ? rs + (row & 7) : grow)) * ldh + c0;
                 float4 h[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) h[j] = *reinterpret_cast<const float4*>(hrow + coff[j]);
@@ -235,7 +267,9 @@ constexpr bool SPLIT_BPRE = false;
             for (int j = 0; j < NJ; ++j)
                 if (eq + 4 * j < cw4) *reinterpret_cast<float4*>(orow + coff[j]) = v[j];
         }
+        SPLIT_STAMP(3 + pass);
     }
+#undef SPLIT_STAMP
 }
 
 #ifdef MMDFN_TUNING
@@ -243,8 +277,13 @@ int split_ablation() {
     const char* e = getenv("MMDFN_PROP_ABL");
     return e ? atoi(e) : 0;
 }
+unsigned long long* split_trace() {       // device address of a (workgroups x 8) uint64 buffer (tools/k6_trace.py)
+    const char* e = getenv("MMDFN_TRACE_PTR");
+    return e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 10)) : nullptr;
+}
 #else
 constexpr int split_ablation() { return 0; }
+constexpr unsigned long long* split_trace() { return nullptr; }
 #endif
 
 }  // namespace
@@ -266,10 +305,10 @@ int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const f
     do {                                                                                                         \
         if (tail && (A) == 0)                                                                                    \
             hipLaunchKernelGGL((propagate_split_kernel<0, true>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
-                               row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation());        \
+                               row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation(), split_trace()); \
         else                                                                                                     \
             hipLaunchKernelGGL((propagate_split_kernel<A>), grid, dim3(256), lds_bytes, s, tiles, cross, H, out, dia_len, \
-                               row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation());        \
+                               row_start, tile_base, B, M, N, d, ldh, ldo, max_rb, ncb, split_ablation(), split_trace()); \
     } while (0)
 #ifdef MMDFN_TUNING
     const char* ac = getenv("MMDFN_SPLIT_ABLC");  // compile-time ablations (1: no cutting, 2: no MFMA, 4: no fourth-tile MFMAs)

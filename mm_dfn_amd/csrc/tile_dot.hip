@@ -448,7 +448,7 @@ extern "C" int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, f
         if (rc) return rc;
         if (M > 1 && dc) {              // (NULL by now if the tile launch took the cross diagonals along)
             for (int c0 = 0; c0 < d; c0 += CUT) {
-                const int kc = d - c0 < CUT + 8 ? d - c0 : CUT;          // (no sliver at the end: 208 stays one piece)
+                const int kc = d - c0 <= CUT + 8 ? d - c0 : CUT;          // (no sliver at the end: 208 stays one piece)
                 cross_piece(X + c0, Y + c0, dc, M, N, kc, ldx, ldy, (accumulate || c0 > 0) ? 1 : 0, s);
                 if (kc != CUT) break;
             }
@@ -457,7 +457,7 @@ extern "C" int mmdfn_tile_outer(const float* X, const float* Y, float* dtiles, f
         return 0;
     }
     for (int c0 = 0; c0 < d; c0 += CUT) {
-        const int kc = d - c0 < CUT + 8 ? d - c0 : CUT;
+        const int kc = d - c0 <= CUT + 8 ? d - c0 : CUT;
         const int acc = (accumulate || c0 > 0) ? 1 : 0;
         float* dc = dcross;
         int rc = launch_tile_dot(X + c0, Y + c0, dtiles, nullptr, nullptr, dia_len, row_start, tile_base, B, M, N, kc, ldx, ldy,

@@ -68,7 +68,22 @@ class CapturedStep:
         # load_state_dict(assign=True)) would make the graph update stale memory -- checked on every replay
         self._param_ptrs = [(p, p.data_ptr()) for p in model.parameters()]
 
+    def close(self):
+        """Release the captured graph NOW (hipGraphExec + its private memory pool) instead of whenever the last reference to this
+        object dies.  A graph that holds a collective node keeps the RCCL communicator's work objects alive: it has to be gone
+        before ``torch.distributed.destroy_process_group()`` (bench.py, the RCCL tests).  The object is unusable afterwards."""
+        graph, self.graph = self.graph, None
+        self.loss = None
+        self.grads = {}
+        self._pinned = []
+        self._step_fn = None
+        if graph is not None:
+            torch.cuda.synchronize()
+            graph.reset()
+
     def replay(self):
+        if self.graph is None:
+            raise RuntimeError("CapturedStep: replay() after close()")
         for p, ptr in self._param_ptrs:
             if p.data_ptr() != ptr:
                 raise RuntimeError("CapturedStep: a parameter's storage moved after the capture (optimizer "

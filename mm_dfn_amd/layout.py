@@ -124,6 +124,14 @@ class IndexScope:
 
     def retarget(self, lengths):
         lengths = [int(x) for x in lengths]
+        # validate EVERYTHING first: a batch that does not fit must leave host state and device arrays as they were
+        for lay in self.layouts.values():
+            lay.check_retarget(lengths)
+        made = {}
+        for key, (dev, maker) in self.tensors.items():
+            arr = made[key] = maker(lengths)
+            if arr.shape != tuple(dev.shape):
+                raise RuntimeError("IndexScope.retarget: the batch does not fit this step's bucket")
         slot = self._slots[self._turn % len(self._slots)]
         self._turn += 1
         if slot["event"] is not None:
@@ -135,10 +143,7 @@ class IndexScope:
             self._stage(slot, ("tb",) + key, tile_base, lay.tile_base)
             cuda = cuda or lay._i32.is_cuda
         for key, (dev, maker) in self.tensors.items():
-            arr = maker(lengths)
-            if arr.shape != tuple(dev.shape):
-                raise RuntimeError("IndexScope.retarget: the batch does not fit this step's bucket")
-            self._stage(slot, ("t",) + tuple(key), arr, dev)
+            self._stage(slot, ("t",) + tuple(key), made[key], dev)
             cuda = cuda or dev.is_cuda
         if cuda:
             slot["event"] = torch.cuda.Event()
@@ -195,12 +200,20 @@ class DialogueLayout:
         over the device arrays in place (a captured step keeps reading those)."""
         if not self._capacity:
             raise RuntimeError("only layouts owned by an IndexScope can be retargeted (shared ones live in an LRU)")
-        B, N, mx = self.B, self.N, self.max_len
-        i32, tile_base = self._host_arrays(lengths)
-        if (self.B, self.N, self.max_len) != (B, N, mx) or int(tile_base[-1]) > self.tile_elems:
+        self.check_retarget(lengths)
+        return self._host_arrays(lengths)
+
+    def check_retarget(self, lengths):
+        """Raise unless ``lengths`` fits this layout's (B, N, max_len) and tile capacity -- WITHOUT touching the host state, so a
+        rejected batch leaves the layout describing the batch its device arrays still hold."""
+        lens = np.asarray([int(x) for x in lengths], dtype=np.int64)
+        if lens.ndim != 1 or lens.size == 0 or (lens <= 0).any():
+            raise ValueError("dialogue lengths must be a non-empty list of positive ints")
+        new = (int(lens.size), int(lens.sum()), int(lens.max()))
+        tiles = int((self.M * lens * ((lens + 3) & ~3)).sum())
+        if new != (self.B, self.N, self.max_len) or tiles > self.tile_elems:
             raise RuntimeError("DialogueLayout.retarget: (B, N, max_len) = %s does not match this layout's %s"
-                               % ((self.B, self.N, self.max_len), (B, N, mx)))
-        return i32, tile_base
+                               % (new, (self.B, self.N, self.max_len)))
 
     @staticmethod
     def get(lengths, M, device):

@@ -3,9 +3,16 @@ import torch
 import torch.nn as nn
 
 
-# data pointers of the cached scalar 1 that train.backward seeds loss.backward() with: an upstream gradient that IS one of
-# them is exactly 1, and the gradient the forward launch already wrote is the answer
-UNIT_SEED_PTRS = set()
+# Set by train.backward() (and only there) around ``loss.backward(one)`` when ``loss`` IS the output of the fused node below and
+# ``one`` is its cached scalar 1: the node's upstream gradient is then exactly 1 and the gradient the forward launch already wrote
+# is the answer.  An explicit flag, not a comparison of data pointers (an address can be reused, a seed overwritten).
+UNIT_SEED_ACTIVE = [False]
+
+
+def is_fused_loss_output(loss):
+    """True when ``loss`` comes straight out of _FocalLossHip (so a backward seeded at ``loss`` hands the node its seed unchanged)."""
+    fn = getattr(loss, "grad_fn", None)
+    return fn is not None and type(fn).__name__ == "_FocalLossHipBackward"
 
 
 class _FocalLossHip(torch.autograd.Function):
@@ -35,7 +42,10 @@ class _FocalLossHip(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         from . import _hip
-        if ctx.dunit is not None and dloss.data_ptr() in UNIT_SEED_PTRS:
+        if ctx.dunit is not None and UNIT_SEED_ACTIVE[0]:
+            if getattr(ctx, "dunit_handed_out", False):
+                return ctx.dunit.clone(), None, None, None, None     # a second pass (retain_graph): never the same tensor twice
+            ctx.dunit_handed_out = True
             return ctx.dunit, None, None, None, None
         coef, target = ctx.saved_tensors
         N = coef.shape[0]

@@ -911,6 +911,8 @@ class wgrad_batch:
     def __enter__(self):
         if _WGQ["scope"] == 0 and (_WGQ["outs"] or _WGQ["ext"] or _WGQ["armed"]):
             _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False        # stale entries of a backward that raised
+        if _WGQ["scope"] == 0:
+            drop_grad_addends()                                             # (same: its callback never ran)
         _WGQ["scope"] += 1
         return self
 
@@ -922,6 +924,7 @@ class wgrad_batch:
                     flush_queued_wgrads()                  # a backward driven without the engine callback
             else:
                 _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False    # the callback never ran: drop the half-built batch
+                drop_grad_addends()
             _join_side()
         return False
 
@@ -1041,6 +1044,14 @@ def flush_queued_wgrads_early():
 
 
 _GRAD_ADDENDS = []      # (parameter, tensor, event recorded on the producing stream)
+_GRAD_ADDENDS_ARMED = [False]    # the end-of-backward callback of the RUNNING backward pass has been queued
+
+
+def drop_grad_addends():
+    """Forget addends (and the callback flag) left behind by a backward pass that raised before its end-of-backward callback
+    ran; without this every later pass would see a non-empty list, queue no callback and silently lose its addends."""
+    del _GRAD_ADDENDS[:]
+    _GRAD_ADDENDS_ARMED[0] = False
 
 
 def add_grad_addends(pairs):
@@ -1049,15 +1060,16 @@ def add_grad_addends(pairs):
     gradient pieces computed off the main stream that neither autograd nor the weight-gradient batch should wait for."""
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
-    first = not _GRAD_ADDENDS
     for prm, t in pairs:
         if prm.requires_grad:
             _GRAD_ADDENDS.append((prm, t, ev))
-    if first and _GRAD_ADDENDS:
+    if _GRAD_ADDENDS and not _GRAD_ADDENDS_ARMED[0]:
+        _GRAD_ADDENDS_ARMED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(apply_grad_addends)
 
 
 def apply_grad_addends():
+    _GRAD_ADDENDS_ARMED[0] = False
     if not _GRAD_ADDENDS:
         return
     items = list(_GRAD_ADDENDS)

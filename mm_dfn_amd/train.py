@@ -53,9 +53,15 @@ def backward(loss):
             if loss.is_cuda and torch.cuda.is_current_stream_capturing():
                 return loss.backward()           # a tensor created under capture belongs to that graph's pool
             one = _UNIT_SEED[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
-            from . import loss as _loss_mod
-            _loss_mod.UNIT_SEED_PTRS.add(one.data_ptr())       # (FocalLoss then knows the upstream gradient is exactly 1)
-        loss.backward(one)
+        from . import loss as _loss_mod
+        # the seed is exactly 1 and, when ``loss`` is the fused FocalLoss node's own output, reaches that node unchanged: tell it
+        # so (it then returns the gradient its forward launch wrote instead of launching a backward kernel)
+        prev = _loss_mod.UNIT_SEED_ACTIVE[0]
+        _loss_mod.UNIT_SEED_ACTIVE[0] = _loss_mod.is_fused_loss_output(loss)
+        try:
+            loss.backward(one)
+        finally:
+            _loss_mod.UNIT_SEED_ACTIVE[0] = prev
 
 
 class StepGraphCache:
@@ -124,7 +130,9 @@ class StepGraphCache:
         Nb = ((N + 1 + g - 1) // g) * g
         pad = Nb - N                                       # 1 .. g utterances of the padding dialogue
         lens2 = lengths + [pad]
-        key = ("bucket", bool(train_flag), B, L, Nb) + tuple(tuple(t.shape[2:]) for t in inputs[:4])
+        # (the padded widths of umask / label are baked into the captured label gather and the static buffers: part of the key)
+        key = (("bucket", bool(train_flag), B, L, Nb, int(inputs[4].shape[1]), int(inputs[5].shape[1]))
+               + tuple(tuple(t.shape[2:]) for t in inputs[:4]))
         ent = self.entries.get(key)
         dev = inputs[0].device
         Lp = int(inputs[5].shape[1])

@@ -311,3 +311,40 @@ def test_foreign_slab_stacks_get_gradient_destinations():
     (_, C5, cs5, acc5), = ops._ext_destinations([dict(part=None, colpart=torch.zeros(3, 10), splits=3, M=10, N=0, weight=None,
                                                       bias=half, acc=0)])
     assert C5 is None and cs5 is buf and acc5 == 0
+
+
+def test_rejected_retarget_leaves_layout_and_scope_untouched():
+    """a batch that does not fit a bucketed step's index scope must be refused BEFORE any host state or device array
+    is rewritten (the captured step keeps describing the batch its arrays hold)."""
+    from mm_dfn_amd.layout import IndexScope
+    scope = IndexScope()
+    with scope:
+        lay = DialogueLayout.get([4, 3, 3], 3, "cpu")
+        pos = scope.tensor(("pos", 0), [4, 3, 3], lambda lens: np.cumsum(np.asarray(lens, dtype=np.int64)), "cpu")
+    snap = (list(lay.lengths), lay.B, lay.N, lay.max_len, lay.row_start_host.copy(), lay._i32.clone(), lay.tile_base.clone(),
+            pos.clone())
+    for bad in ([5, 3, 2], [4, 3, 2], [4, 3, 2, 1], []):
+        with pytest.raises((RuntimeError, ValueError)):
+            scope.retarget(bad)
+        assert (list(lay.lengths), lay.B, lay.N, lay.max_len) == snap[:4]
+        assert np.array_equal(lay.row_start_host, snap[4])
+        assert torch.equal(lay._i32, snap[5]) and torch.equal(lay.tile_base, snap[6]) and torch.equal(pos, snap[7])
+    scope.retarget([3, 4, 3])                              # same (B, N, max_len): accepted, everything follows
+    assert lay.lengths == [3, 4, 3] and lay._i32[:3].tolist() == [3, 4, 3] and pos.tolist() == [3, 7, 10]
+
+
+def test_grad_addends_of_a_backward_that_raised_do_not_block_later_passes():
+    """addends queued by a backward pass that raised before its end-of-backward callback must not leave the
+    'callback queued' state behind (later passes would silently drop their addends)."""
+    from mm_dfn_amd import ops
+    p = torch.nn.Parameter(torch.zeros(3))
+    ops._GRAD_ADDENDS.append((p, torch.ones(3), None))      # what a failed pass leaves behind
+    ops._GRAD_ADDENDS_ARMED[0] = True
+    with ops.wgrad_batch():
+        assert not ops._GRAD_ADDENDS and not ops._GRAD_ADDENDS_ARMED[0]
+    with pytest.raises(ZeroDivisionError):
+        with ops.wgrad_batch():
+            ops._GRAD_ADDENDS.append((p, torch.ones(3), None))
+            ops._GRAD_ADDENDS_ARMED[0] = True
+            1 / 0
+    assert not ops._GRAD_ADDENDS and not ops._GRAD_ADDENDS_ARMED[0]

@@ -305,11 +305,15 @@ def test_captured_step_cache_with_flat_adam_recaptures_after_the_flat_layout(tmp
 
 
 def _run_rccl_case(name):
-    """The RCCL cases run in a process of their own.  Tearing an RCCL process group down in the process that still holds
-    captured graphs with collective nodes ABORTS once in a few runs (a ProcessGroupNCCL helper thread inside
-    destroy_process_group; 1 of 6 full GPU runs of round 5) -- in-process that takes the whole pytest session with it.  A case
-    prints its marker once every assertion has passed, BEFORE the teardown; only the marker counts here."""
+    """The RCCL cases run IN the pytest process (round 6).  Round 5 ran them in a child process because
+    destroy_process_group() aborted once in six full GPU runs while captured graphs with collective nodes were still referenced;
+    the cases now release those graphs explicitly (CapturedStep.close(): hipGraphExec + its pool gone, device idle) BEFORE the
+    group is destroyed, and tools/rccl_teardown_repro.py + test_rccl_teardown_thirty_rounds_in_process cover the order.
+    MMDFN_RCCL_SUBPROCESS=1 restores the isolation (a case prints its marker once every assertion has passed)."""
     import os
+    if os.environ.get("MMDFN_RCCL_SUBPROCESS", "0") != "1":
+        globals()[name]()
+        return
     import subprocess
     import sys
     tests = os.path.dirname(os.path.abspath(__file__))
@@ -318,6 +322,17 @@ def _run_rccl_case(name):
             % (root, os.path.join(root, "oracle"), tests, name))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert "RCCL-CASE-OK" in out.stdout, "rc %s\n%s\n%s" % (out.returncode, out.stdout[-2000:], out.stderr[-6000:])
+
+
+def _rccl_teardown(cap):
+    """Graphs first, then the group: a captured collective keeps RCCL work alive for as long as its hipGraphExec exists."""
+    import gc
+    import torch.distributed as dist
+    if cap is not None:
+        cap.close()
+    gc.collect()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
 
 
 def test_real_model_gradient_bucket_through_rccl_and_flat_adam():
@@ -340,6 +355,7 @@ def _rccl_case_bucket_and_flat_adam():
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     distributed.init(backend="nccl")
+    cap = None
     try:
         cfg = dict(B=3, L=12, **CFG)
         b = synthetic.make_batch(31, lengths=[12, 5, 9], device="cuda", **cfg)
@@ -384,9 +400,7 @@ def _rccl_case_bucket_and_flat_adam():
         torch.cuda.synchronize()
         print("RCCL-CASE-OK", flush=True)
     finally:
-        cap = None
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+        _rccl_teardown(cap)
 
 
 def _step_inputs(seed=11, lengths=(20, 13, 7)):
@@ -504,6 +518,7 @@ def _rccl_case_two_part_bucket():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
     s.close()
     dist.init_process_group(backend="nccl")
+    cap = None
     try:
         b, flat = _step_inputs(lengths=(20, 13, 7))
         grads = {}
@@ -541,9 +556,47 @@ def _rccl_case_two_part_bucket():
         torch.cuda.synchronize()
         print("RCCL-CASE-OK", flush=True)
     finally:
+        _rccl_teardown(cap)
+
+
+def test_rccl_teardown_thirty_rounds_in_process():
+    """thirty times in ONE process -- init_process_group("nccl"), a captured step whose graph holds the
+    gradient all-reduce, replays, CapturedStep.close(), destroy_process_group() -- without an abort, a hang or a changed loss."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from mm_dfn_amd import distributed
+    from mm_dfn_amd.graphs import CapturedStep
+    b, flat = _step_inputs(lengths=(12, 5, 9))
+    losses = []
+    for it in range(30):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+        s.close()
+        dist.init_process_group(backend="nccl")
         cap = None
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+        try:
+            m = _model(13).train()
+            bucket = distributed.GradientBucket(m, average=True)
+            m.zero_grad(set_to_none=True)
+            T.backward(_loss(m, b, flat))
+            bucket.flatten()
+
+            def fwd_bwd():
+                loss = _loss(m, b, flat)
+                T.backward(loss)
+                return loss
+            cap = CapturedStep(m, fwd_bwd, warmup=1, bucket=bucket, reduce_in_graph=True)
+            for _ in range(2):
+                loss = cap.replay()
+            losses.append(float(loss))
+        finally:
+            _rccl_teardown(cap)
+        with pytest.raises(RuntimeError):
+            cap.replay()                                   # closed
+        assert not dist.is_initialized()
+    assert len(losses) == 30 and max(losses) - min(losses) == 0.0
 
 
 def test_weight_gradient_queue_survives_a_backward_that_raises():
