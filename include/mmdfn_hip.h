@@ -256,6 +256,29 @@ int mmdfn_linear(const float* X, const float* W, const float* bias, float* Y, in
 int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const float* bias, const float* bias2,
                   float* Y, int R, int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K1p  the same projection against a weight that arrives as bf16 PIECE PLANES (linear_planes.hip; ABI 15).
+ * Replaces the `nn.GRU` input products of `lstm_l` / `rnn_parties` (reference model.py:866,868,1082,1132) and their input
+ * gradients at the row counts of the BASELINE configs.  A weight changes once per optimizer step
+ * (run_train_erc.py:512), so its three exact bf16 pieces are cut once per step -- one grouped launch for up to 16 weights --
+ * into MFMA B-fragment order, and the projection kernel cuts only its own X rows.
+ *
+ * mmdfn_weight_planes_workspace: bytes of the plane buffer of a B operand with N output columns and K contraction
+ *   (ceil(N/32) x ceil(K/16) x 3 pieces x 1 KB; zero-filled outside N x K by the cut).
+ * mmdfn_cut_weight_planes: for weight i the STORED matrix has row stride ld[i] and is given as two row blocks: rows [0, n1[i])
+ *   at w1[i], the rest at w2[i] (null when n1 covers every row).  transposed[i] == 0: B[n][k] = stored[n][k]  (forward:
+ *   N = stored rows, K = stored columns);  transposed[i] == 1: B[n][k] = stored[k][n]  (the input gradient dX = dY . W:
+ *   N = stored columns, K = stored rows).  planes[i]: 16-byte aligned, mmdfn_weight_planes_workspace(N[i], K[i]) bytes.
+ * mmdfn_linear_planes:  Y = act(X B^T + bias) (+ Y);  X: R rows of K floats (row stride ldx, 16-byte aligned rows, K % 4 == 0),
+ *   bias / bias2 split at n1 as in mmdfn_linear2 (either may be null), Y: R x N (row stride ldy), act: 0 identity, 1 ReLU.
+ *   Arithmetic: six bf16 piece products per MAC, fp32 accumulation -- fp32-level error, as mmdfn_linear's many-row form.
+ * ------------------------------------------------------------------------- */
+int64_t mmdfn_weight_planes_workspace(int N, int K);
+int mmdfn_cut_weight_planes(int n, const float* const* w1, const float* const* w2, const int* n1, const int* ld,
+                            const int* N, const int* K, const int* transposed, void* const* planes, void* stream);
+int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, const float* bias2, int n1, float* Y, int R,
+                        int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
+
 /* A GROUP of few-row projections in one launch (linear_small.hip; n <= 8 problems, K <= 768, K % 4 == 0):
  *   Y_p = act(X_p W_p^T + b_p) (+ Y_p)      X_p: R_p rows of K_p floats (stride ldx), Y_p: R_p x N_p (stride ldy)
  *   kmajor[p] == 0: W_p is (N, K) with k-contiguous rows (row stride ldw), given as two row blocks W / W2 split at

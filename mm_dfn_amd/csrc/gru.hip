@@ -898,10 +898,15 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
             ar += pair_swap(ar);
             az += pair_swap(az);
             an += pair_swap(an);
-            const float ghn = an + bhn;
-            const float rr = (ABL & 2) ? (g0 + ar + bhr) * 0.01f : sigmoidf_(g0 + ar + bhr);
-            const float zz = (ABL & 2) ? (g1 + az + bhz) * 0.01f : sigmoidf_(g1 + az + bhz);
-            const float nn = (ABL & 2) ? (g2 + rr * ghn) * 0.01f : tanhf_(g2 + rr * ghn);
+            // (ABL & 64, timing only: the step as it would be with -log2(e) folded into W_hr / W_hz, 2 log2(e) into W_hn and the
+            // recurrent biases pre-added to the staged operands -- the upper bound of the "constant folding" lead)
+            const float ghn = (ABL & 64) ? an : an + bhn;
+            const float rr = (ABL & 64) ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g0 + ar))
+                           : (ABL & 2) ? (g0 + ar + bhr) * 0.01f : sigmoidf_(g0 + ar + bhr);
+            const float zz = (ABL & 64) ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g1 + az))
+                           : (ABL & 2) ? (g1 + az + bhz) * 0.01f : sigmoidf_(g1 + az + bhz);
+            const float nn = (ABL & 64) ? 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(rr, ghn, g2)))
+                           : (ABL & 2) ? (g2 + rr * ghn) * 0.01f : tanhf_(g2 + rr * ghn);
             const float hnew = (1.0f - zz) * nn + zz * hprev;
             if (mine) hs[cur ^ 1][u] = hnew;
             hprev = hnew;
@@ -1700,7 +1705,7 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
 #endif
 #ifdef MMDFN_TUNING
 #define GRU_IO_ABL(A) if (io_wave && G.abl == A) { hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, A, 0>), grid, dim3(320), 0, s, G); MMDFN_CHECK_LAUNCH(); return 0; }
-    GRU_IO_ABL(1) GRU_IO_ABL(2) GRU_IO_ABL(4) GRU_IO_ABL(8) GRU_IO_ABL(16) GRU_IO_ABL(3) GRU_IO_ABL(11) GRU_IO_ABL(31) GRU_IO_ABL(23)
+    GRU_IO_ABL(1) GRU_IO_ABL(2) GRU_IO_ABL(4) GRU_IO_ABL(8) GRU_IO_ABL(16) GRU_IO_ABL(3) GRU_IO_ABL(11) GRU_IO_ABL(31) GRU_IO_ABL(23) GRU_IO_ABL(64)
 #undef GRU_IO_ABL
 #endif
     if (io_wave && scalar_fma) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<1, 0, 0>), grid, dim3(320), 0, s, G);

@@ -246,6 +246,10 @@ class DialogueGNNModel(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, U, qmask, umask, seq_lengths, U_a=None, U_v=None, test_label=False):
+        # the bf16 piece planes of the GRU input weights follow whatever the optimizer did since the last pass: the stale ones
+        # are re-cut by one grouped launch (ops.refresh_planes: a host-side version check when nothing changed)
+        if U.is_cuda:
+            ops.refresh_planes()
         # one pool of dropout keep flags per forward: every dropout site of the step shares one generator launch
         with ops.flag_pool((U.shape[0], tuple(int(x) for x in seq_lengths))):
             return self._forward(U, qmask, umask, seq_lengths, U_a, U_v, test_label)

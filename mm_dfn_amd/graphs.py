@@ -54,12 +54,15 @@ class CapturedStep:
         from . import dialogue_model, layout
         # the graph bakes raw pointers of the cached index tensors (dialogue layout, pad-strip index): keep every
         # cache entry used during the capture alive for as long as this object lives, whatever the caches evict
-        with recording(layout._LAYOUT_CACHE, dialogue_model._FLAT_CACHE) as used:
+        # weight piece planes the step reads (ops_linear.weight_planes): fresh after the warm-up passes, so the graph contains no
+        # cut; replay() re-cuts the ones an optimizer step has made stale, in front of the graph launch
+        with recording(layout._LAYOUT_CACHE, dialogue_model._FLAT_CACHE) as used, ops.planes_recording() as planes:
             # thread_local: a communication-library watchdog thread polling its own events must not invalidate the capture
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = step_fn()
                 tail()
         self._pinned = list(used)
+        self._planes = list(planes)
         self._rng_per_replay = ops.flags_consumed(dev_index) - consumed0      # Philox counters one replay consumes
         torch.cuda.set_rng_state(rng_state, dev_index)
         ops.flag_state_restore(dev_index, flag_snap)
@@ -76,6 +79,7 @@ class CapturedStep:
         self.loss = None
         self.grads = {}
         self._pinned = []
+        self._planes = []
         self._step_fn = None
         if graph is not None:
             torch.cuda.synchronize()
@@ -90,6 +94,8 @@ class CapturedStep:
                                    "materialisation / .to() / load_state_dict(assign=True)); capture again")
         if self._rng_per_replay:
             ops.flag_state_sync(self._dev_index)           # torch.manual_seed / a restored RNG state since the last draw
+        if self._planes:
+            ops.refresh_planes(self._planes)               # (host-side version check; a launch only after a weight update)
         self.graph.replay()
         if self._rng_per_replay:
             ops.flags_advance_host(self._dev_index, self._rng_per_replay)

@@ -57,6 +57,9 @@ class FlatAdam:
                                         g.numel(), float(grp["lr"]), self.betas[0], self.betas[1], self.eps,
                                         float(grp["weight_decay"]), self.t, _hip.stream())
         _hip.check(rc, "mmdfn_adam_step")
+        # the kernel wrote the parameters behind autograd's version counters: piece planes cut from them are stale now
+        from . import ops
+        ops.invalidate_planes()
 
     # ---- checkpointing: per-parameter moments under the parameter NAMES (layout-independent, loads into a bucket
     # whose flat order differs), plus the step count and the hyper-parameters

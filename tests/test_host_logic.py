@@ -175,8 +175,8 @@ def test_flag_pool_shares_one_draw_per_step(monkeypatch):
     and hand out disjoint 16-byte aligned slices; outside a scope every request is its own draw.  (Host logic only: the draw
     itself -- the device's Philox kernel, tests/test_gru_gpu.py -- is replaced by a CPU stand-in here.)"""
     import torch
-    from mm_dfn_amd import ops
-    monkeypatch.setattr(ops, "draw_flags", lambda n, p, device: torch.empty(n, device=device).bernoulli_(1.0 - p))
+    from mm_dfn_amd import ops, ops_flags
+    monkeypatch.setattr(ops_flags, "draw_flags", lambda n, p, device: torch.empty(n, device=device).bernoulli_(1.0 - p))
     dev = torch.device("cpu")
     a = ops.keep_flags(10, 0.5, dev)
     assert a.shape == (10,) and set(a.unique().tolist()) <= {0.0, 1.0}
@@ -197,7 +197,7 @@ def test_flag_pool_shares_one_draw_per_step(monkeypatch):
         bufs.append(x)
         assert 0.3 < float(x.mean()) < 0.7
     assert bufs[1].untyped_storage().data_ptr() != bufs[2].untyped_storage().data_ptr()   # a fresh buffer per step
-    assert ops._FLAG_SCOPE is None
+    assert ops_flags._FLAG_SCOPE is None
     # a step that asks for more than the hint: the overflow request draws its own buffer
     with ops.flag_pool(("k", 1)):
         x = ops.keep_flags(1001, 0.5, dev)

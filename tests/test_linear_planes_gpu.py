@@ -1,0 +1,149 @@
+"""GPU: the projection kernel that takes its weight as bf16 piece planes (csrc/linear_planes.hip) and the plane registry that
+keeps those planes in step with the parameters (ops.weight_planes / refresh_planes / invalidate_planes)."""
+import pytest
+import torch
+
+from mm_dfn_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w1, w2, b1, b2, transposed, act, base):
+    W = torch.cat([w1, w2]) if w2 is not None else w1
+    W = W.double()
+    y = x.double() @ (W if transposed else W.t())
+    if not transposed:
+        b = [t for t in (b1, b2) if t is not None]
+        if b:
+            y = y + torch.cat(b).double()
+    if act:
+        y = y.clamp_min(0)
+    if base is not None:
+        y = y + base.double()
+    return y
+
+
+@pytest.mark.parametrize("R,K,n1,n2", [(7040, 200, 300, 300), (1760, 200, 300, 300), (130, 200, 300, 300), (64, 8, 40, 0),
+                                       (1000, 212, 33, 0), (517, 600, 100, 100), (3, 100, 17, 19), (19008, 200, 300, 300)])
+def test_linear_planes_against_fp64(R, K, n1, n2):
+    g = torch.Generator(device="cuda").manual_seed(R + K)
+    x = torch.randn(R, K, device="cuda", generator=g)
+    w1 = torch.randn(n1, K, device="cuda", generator=g) * 0.1
+    w2 = torch.randn(n2, K, device="cuda", generator=g) * 0.1 if n2 else None
+    b1 = torch.randn(n1, device="cuda", generator=g)
+    b2 = torch.randn(n2, device="cuda", generator=g) if n2 else None
+    y = ops.linear_planes_raw(x, w1, w2, b1, b2)
+    want = _ref(x, w1, w2, b1, b2, False, 0, None)
+    scale = float(want.abs().max())
+    # fp32-level error: six exact bf16 piece products per MAC, fp32 accumulation (<= 4x the exact-f32 MFMA kernel's error)
+    assert float((y.double() - want).abs().max()) <= 2e-6 * scale
+    exact = ops.linear_group_raw([dict(x=x, w=w1, w2=w2, b=b1, b2=b2)])[0] if (K <= 768 and R <= 8192) else None
+    if exact is not None:
+        e_exact = float((exact.double() - want).abs().max())
+        assert float((y.double() - want).abs().max()) <= max(4.0 * e_exact, 1e-6 * scale)
+    # ReLU + accumulate
+    base = torch.randn(R, n1 + n2, device="cuda", generator=g)
+    out = base.clone()
+    ops.linear_planes_raw(x, w1, w2, b1, b2, act=1, out=out, accumulate=True)
+    want = _ref(x, w1, w2, b1, b2, False, 1, base)
+    assert float((out.double() - want).abs().max()) <= 2e-6 * max(scale, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("R,K,n1,n2", [(7040, 200, 300, 300), (1760, 200, 300, 300), (333, 100, 52, 0), (200, 36, 24, 40)])
+def test_linear_planes_transposed_operand_is_the_input_gradient(R, K, n1, n2):
+    """dX = dY . [w1; w2]: the contraction runs over the stored ROWS (both blocks), the output has the stored columns."""
+    g = torch.Generator(device="cuda").manual_seed(7 * R + K)
+    dy = torch.randn(R, n1 + n2, device="cuda", generator=g)
+    w1 = torch.randn(n1, K, device="cuda", generator=g) * 0.1
+    w2 = torch.randn(n2, K, device="cuda", generator=g) * 0.1 if n2 else None
+    dx = ops.linear_planes_raw(dy, w1, w2, transposed=True)
+    want = _ref(dy, w1, w2, None, None, True, 0, None)
+    assert dx.shape == (R, K)
+    assert float((dx.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_row_strided_input_and_nan_beyond_k():
+    """X rows wider than K (a column block of a wider matrix): what lies beyond K -- NaN here -- must not reach the result."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    big = torch.full((500, 120), float("nan"), device="cuda")
+    big[:, :100] = torch.randn(500, 100, device="cuda", generator=g)
+    x = big[:, :100]
+    w = torch.randn(40, 100, device="cuda", generator=g)
+    y = ops.linear_planes_raw(x, w)
+    want = x.double() @ w.double().t()
+    assert torch.isfinite(y).all() and float((y.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_planes_follow_the_parameters():
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(256, 64, device="cuda", generator=g)
+    w1 = torch.nn.Parameter(torch.randn(48, 64, device="cuda", generator=g))
+    w2 = torch.nn.Parameter(torch.randn(48, 64, device="cuda", generator=g))
+
+    def check():
+        y = ops.linear_planes_raw(x, w1, w2)
+        want = x.double() @ torch.cat([w1.detach(), w2.detach()]).double().t()
+        return float((y.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+    assert check()
+    e = ops.weight_planes(w1, w2)
+    before = e.buf.clone()
+    assert check() and torch.equal(e.buf, before)          # nothing changed: no re-cut needed, same planes
+    with torch.no_grad():
+        w2.mul_(-2.0)                                      # an in-place update autograd's version counter sees
+    assert check()
+    w1.data.view(-1)[:5].zero_()                           # ... and one it does not see (a raw kernel's write, as FlatAdam's)
+    assert not check()
+    ops.invalidate_planes()
+    assert check()
+    w1.data.view(-1)[5:9].fill_(3.0)
+    ops.invalidate_planes()
+    buf0 = e.buf.clone()
+    ops.refresh_planes()                                   # what a model's forward pass does first: stale entries, one launch
+    assert not torch.equal(e.buf, buf0) and check()
+    buf0 = e.buf.clone()
+    ops.refresh_planes()                                   # nothing stale: nothing launched
+    assert torch.equal(e.buf, buf0)
+    # a captured use: the graph holds no cut; what the capture recorded is re-checked (and re-cut) in front of a replay
+    out = torch.empty(256, 96, device="cuda")
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with ops.planes_recording() as used:
+        with torch.cuda.graph(gr):
+            ops.linear_planes_raw(x, w1, w2, out=out)
+    assert len(used) == 1
+    with torch.no_grad():
+        w1.mul_(0.5)
+    ops.refresh_planes(used)
+    gr.replay()
+    torch.cuda.synchronize()
+    want = x.double() @ torch.cat([w1.detach(), w2.detach()]).double().t()
+    assert float((out.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    del used
+    # entries die with their parameters
+    n = len(ops._PLANES)
+    del w1, w2, e, check, gr
+    import gc
+    gc.collect()
+    ops.refresh_planes()
+    assert len(ops._PLANES) < n
+
+
+def test_linear2_node_on_planes_matches_autograd():
+    """ops.linear2 (the GRU input contraction node) above PLANES_MIN_ROWS: output and input gradient from the plane kernels, weight
+    gradients as before."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    R = max(ops.PLANES_MIN_ROWS, 1024) + 37
+    x = torch.randn(R, 200, device="cuda", generator=g, requires_grad=True)
+    prm = [torch.nn.Parameter(torch.randn(*s, device="cuda", generator=g) * 0.1) for s in ((300, 200), (300, 200), (300,), (300,))]
+    y = ops.linear2(x, *prm)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xr = x.detach().double().requires_grad_()
+    pr = [p.detach().double().requires_grad_() for p in prm]
+    yr = xr @ torch.cat(pr[:2]).t() + torch.cat(pr[2:])
+    yr.backward(dy.double())
+    assert float((y.double() - yr).abs().max()) <= 2e-6 * float(yr.abs().max())
+    assert float((x.grad.double() - xr.grad).abs().max()) <= 2e-6 * float(xr.grad.abs().max())
+    for p, q in zip(prm, pr):
+        assert float((p.grad.double() - q.grad).abs().max()) <= 3e-6 * float(q.grad.abs().max())

@@ -305,13 +305,18 @@ def test_captured_step_cache_with_flat_adam_recaptures_after_the_flat_layout(tmp
 
 
 def _run_rccl_case(name):
-    """The RCCL cases run IN the pytest process (round 6).  Round 5 ran them in a child process because
-    destroy_process_group() aborted once in six full GPU runs while captured graphs with collective nodes were still referenced;
-    the cases now release those graphs explicitly (CapturedStep.close(): hipGraphExec + its pool gone, device idle) BEFORE the
-    group is destroyed, and tools/rccl_teardown_repro.py + test_rccl_teardown_thirty_rounds_in_process cover the order.
-    MMDFN_RCCL_SUBPROCESS=1 restores the isolation (a case prints its marker once every assertion has passed)."""
+    """The RCCL cases run in a process of their own, and the child's EXIT CODE counts (round 6), not only its marker: every case
+    releases its captured graphs (CapturedStep.close()) and then leaves through destroy_process_group(), so an abort anywhere --
+    the teardown included -- fails the test instead of being hidden behind a marker printed earlier.
+    Why a child at all (round-6 findings, tools/rccl_teardown_repro.py): init -> capture-with-all-reduce -> replay ->
+    destroy survives 80 / 80 rounds in a fresh process whatever the order of graph release and group teardown (graphs kept alive
+    included), so the teardown order was NOT what aborted in round 5.  Inside the long pytest process the same cases abort about
+    once in three runs, and the dump shows a NATIVE thread (c10d watchdog / RCCL service thread) aborting while the main thread is
+    inside dist.all_reduce under stream capture (graphs.py tail(), not the teardown) -- a race between the communication
+    library's helper threads and a capture in a process that has already created and destroyed groups.  It takes the whole pytest
+    session with it, so the cases keep their own process; MMDFN_RCCL_INPROC=1 runs them in-process for hunting."""
     import os
-    if os.environ.get("MMDFN_RCCL_SUBPROCESS", "0") != "1":
+    if os.environ.get("MMDFN_RCCL_INPROC", "0") == "1":
         globals()[name]()
         return
     import subprocess
@@ -321,7 +326,29 @@ def _run_rccl_case(name):
     code = ("import sys; sys.path[:0] = [%r, %r, %r]; import test_trainer_gpu as t; t.%s()"
             % (root, os.path.join(root, "oracle"), tests, name))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
-    assert "RCCL-CASE-OK" in out.stdout, "rc %s\n%s\n%s" % (out.returncode, out.stdout[-2000:], out.stderr[-6000:])
+    assert out.returncode == 0 and "RCCL-CASE-OK" in out.stdout, \
+        "rc %s\n%s\n%s" % (out.returncode, out.stdout[-2000:], out.stderr[-6000:])
+
+
+def _init_rccl_group():
+    """init_process_group("nccl") at world size 1 on a free local port (a port handed out by bind(0) can be taken again by the
+    time the store listens on it: retried)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    last = None
+    for _ in range(5):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        try:
+            dist.init_process_group(backend="nccl")
+            return
+        except dist.DistNetworkError as exc:
+            last = exc
+    raise last
 
 
 def _rccl_teardown(cap):
@@ -349,12 +376,7 @@ def _rccl_case_bucket_and_flat_adam():
     from mm_dfn_amd import distributed
     from mm_dfn_amd.graphs import CapturedStep
     from mm_dfn_amd.optim import FlatAdam
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-    distributed.init(backend="nccl")
+    _init_rccl_group()
     cap = None
     try:
         cfg = dict(B=3, L=12, **CFG)
@@ -451,21 +473,21 @@ def test_slab_stacks_of_the_head_and_the_gather_bias_ride_on_the_batch_reduction
     (mmdfn_gemm_tn_batch_ext): no head_reduce / colsum_final launch in the trace, same gradients as plain autograd (checked by
     the test above), and a second backward without zero_grad accumulates (the bias halves then take the autograd path)."""
     from torch.profiler import ProfilerActivity, profile
-    from mm_dfn_amd import ops
+    from mm_dfn_amd import ops_wgrad       # (the queue's own module: a name that is REBOUND has to be patched where it is looked up)
     m = _model().train()
     b, flat = _step_inputs()
     seen = []
-    orig = ops._prepare_wgrad_batch
+    orig = ops_wgrad._prepare_wgrad_batch
 
     def spy(batch, ext_items=None):
         seen.append((len(batch), len(ext_items or [])))
         return orig(batch, ext_items)
-    ops._prepare_wgrad_batch = spy
+    ops_wgrad._prepare_wgrad_batch = spy
     try:
         torch.manual_seed(3)
         T.backward(_loss(m, b, flat))
     finally:
-        ops._prepare_wgrad_batch = orig
+        ops_wgrad._prepare_wgrad_batch = orig
     assert seen and sum(e for _, e in seen) == 2 and seen[-1][0] > 0, seen        # both stacks ride on the last batch
     g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
     assert "smax_fc.weight" in g1 and "smax_fc.bias" in g1
@@ -513,11 +535,7 @@ def _rccl_case_two_part_bucket():
     import torch.distributed as dist
     from mm_dfn_amd import distributed
     from mm_dfn_amd.graphs import CapturedStep
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
-    s.close()
-    dist.init_process_group(backend="nccl")
+    _init_rccl_group()
     cap = None
     try:
         b, flat = _step_inputs(lengths=(20, 13, 7))
@@ -562,19 +580,17 @@ def _rccl_case_two_part_bucket():
 def test_rccl_teardown_thirty_rounds_in_process():
     """thirty times in ONE process -- init_process_group("nccl"), a captured step whose graph holds the
     gradient all-reduce, replays, CapturedStep.close(), destroy_process_group() -- without an abort, a hang or a changed loss."""
-    import os
-    import socket
+    _run_rccl_case("_rccl_case_thirty_rounds")
+
+
+def _rccl_case_thirty_rounds():
     import torch.distributed as dist
     from mm_dfn_amd import distributed
     from mm_dfn_amd.graphs import CapturedStep
     b, flat = _step_inputs(lengths=(12, 5, 9))
     losses = []
     for it in range(30):
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]), RANK="0", WORLD_SIZE="1")
-        s.close()
-        dist.init_process_group(backend="nccl")
+        _init_rccl_group()
         cap = None
         try:
             m = _model(13).train()
@@ -597,6 +613,7 @@ def test_rccl_teardown_thirty_rounds_in_process():
             cap.replay()                                   # closed
         assert not dist.is_initialized()
     assert len(losses) == 30 and max(losses) - min(losses) == 0.0
+    print("RCCL-CASE-OK", flush=True)
 
 
 def test_weight_gradient_queue_survives_a_backward_that_raises():

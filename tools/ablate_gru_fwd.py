@@ -24,6 +24,9 @@ def run():
 
 
 variants = [("io", "1", "0", 0), ("io+scalar-fma", "1", "1", 0), ("4-wave", "0", "0", 0), ("io", "1", "0", 0), ("io+scalar-fma", "1", "1", 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "fold":
+    # round 6: upper bound of the constant-folding lead (ABL 64: no bias adds, no log2(e) multiplies on the step's chain)
+    variants = [("io", "1", "0", 0), ("io, folded constants (bound)", "1", "0", 64)] * 4
 if len(sys.argv) > 1 and sys.argv[1] == "abl":
     variants = [("io abl %d" % a, "1", "0", a) for a in (0, 1, 2, 4, 8, 16, 3, 11, 23, 31, 0)]
 for name, io, sf, abl in variants:
@@ -45,4 +48,4 @@ for name, io, sf, abl in variants:
     for _ in range(5):
         g.replay()
     e1.record(); e1.synchronize()
-    print("%-16s: %6.1f us per launch, %.3f us per step" % (name, e0.elapsed_time(e1) * 1e3 / 50, e0.elapsed_time(e1) * 1e3 / 50 / 110), flush=True)
+    print("%-30s: %6.1f us per launch, %.3f us per step" % (name, e0.elapsed_time(e1) * 1e3 / 50, e0.elapsed_time(e1) * 1e3 / 50 / 110), flush=True)

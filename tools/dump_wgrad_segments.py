@@ -23,7 +23,8 @@ label = train.flatten_labels(b["label"], b["lengths"])
 loss_f = FocalLoss(gamma=0.5)
 
 seen = []
-orig = ops._prepare_wgrad_batch
+from mm_dfn_amd import ops_wgrad
+orig = ops_wgrad._prepare_wgrad_batch
 
 
 def spy(batch):
@@ -33,7 +34,7 @@ def spy(batch):
     return orig(batch)
 
 
-ops._prepare_wgrad_batch = spy
+ops_wgrad._prepare_wgrad_batch = spy
 if name in synthetic.STREAM_CONFIGS:
     out = model(b["streams"], b["qmask"], b["umask"], b["lengths"])[0]
 else:
