@@ -23,6 +23,8 @@
 // B[32 ct + (lane & 31)][16 ks + 8 (lane >> 5) + 0..7], zero outside N x K: exactly the B operand of v_mfma_f32_32x32x16_bf16.
 #include "mmdfn_internal.h"
 #include "../../include/mmdfn_hip.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -120,8 +122,11 @@ __global__ __launch_bounds__(256) void cut_planes_kernel(CutTable T) {
 //     fragment of phase p + 1 is needed, the X request in front of it is a whole phase old.  (The first version requested X rows
 //     one phase ahead and fragments two k-steps ahead: every phase stalled on the X latency at its third k-step.)
 //   * the X rows of phase p + 1 are cut and parked in the other LDS buffer behind phase p's last MFMA; ONE barrier per phase.
-template <int RH>
-__global__ __launch_bounds__(256, 4) void linear_planes_kernel(
+// HAND = true: the requests are asm statements with hand-counted waits (3 waves per SIMD: no spill may ever sit between a request
+// and its wait -- checked at build time, mm_dfn_amd/build.py); HAND = false: plain loads, hipcc's own schedule and waits (it sinks
+// the requests to their first use; 4 waves per SIMD).  The launcher picks by measurement (tools/bench_linear_planes.py).
+template <int RH, bool HAND>
+__global__ __launch_bounds__(256, HAND ? 3 : 4) void linear_planes_kernel(
     const float* __restrict__ X, const u32x4* __restrict__ planes, const float* __restrict__ bias,
     const float* __restrict__ bias2, int n1, float* __restrict__ Y, int R, int K, int N, int ldx, int ldy, int act,
     int accumulate, int nrb, int ncb) {
@@ -154,18 +159,29 @@ __global__ __launch_bounds__(256, 4) void linear_planes_kernel(
 
     const u32x4* bsrc = planes + ((int64_t)(has_tile ? ct : 0) * KS) * 3 * 64 + lane;
     u32x4 bq[2][PL_STG][3];                              // [phase parity][k-step][piece]
-    float4 raw[2][2];                                    // [phase parity][float4 of the 8 k values]: this wave's ONE staging task
+    f32x4 raw[2][2];                                     // [phase parity][float4 of the 8 k values]: this wave's ONE staging task
     // staging task of this wave in every phase: row half w & 1, k-step w >> 1; lane -> (row of the half, k group)
     const int shf = w & 1, sksl = w >> 1;
     const int srow = r0 + 32 * shf + (lane & 31);
     const float* xrow = X + (int64_t)(srow < R ? srow : R - 1) * ldx;
     const int skofs = 16 * sksl + 8 * (lane >> 5);       // k of this lane's first value inside the phase
 
+    // Every vector-memory request of the loop is an asm statement and every wait is hand-counted: left to hipcc the requests
+    // sink to their first use (right in front of the phase's barrier) and each phase opens by waiting for them.  A phase
+    // issues exactly PL_NLD requests (2 X + 6 B); vector-memory results return in order, so `vmcnt(PL_NLD)` behind a phase's own
+    // requests means "everything requested in earlier phases has landed".
+#define PL_GLOAD(DST, PTR)                                                                                  \
+    do {                                                                                                    \
+        if constexpr (HAND) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(DST) : "v"(PTR) : "memory"); \
+        else DST = *reinterpret_cast<const std::remove_reference_t<decltype(DST)>*>(PTR);                                            \
+    } while (0)
 #define PL_ISSUE_X(PAR, PH)                                                                                 \
     do {                                                                                                    \
         const int k0_ = 16 * PL_STG * (PH) + skofs;                                                         \
-        raw[PAR][0] = *reinterpret_cast<const float4*>(xrow + (k0_ < K ? k0_ : 0));                         \
-        raw[PAR][1] = *reinterpret_cast<const float4*>(xrow + (k0_ + 4 < K ? k0_ + 4 : 0));                 \
+        const float* xa_ = xrow + (k0_ < K ? k0_ : 0);                                                      \
+        const float* xb_ = xrow + (k0_ + 4 < K ? k0_ + 4 : 0);                                              \
+        PL_GLOAD(raw[PAR][0], xa_);                                                                         \
+        PL_GLOAD(raw[PAR][1], xb_);                                                                         \
     } while (0)
 #define PL_PARK(PAR, PH, BUF)                                                                               \
     do {                                                                                                    \
@@ -184,8 +200,21 @@ __global__ __launch_bounds__(256, 4) void linear_planes_kernel(
     do {                                                                                                    \
         _Pragma("unroll") for (int j_ = 0; j_ < PL_STG; ++j_) {                                             \
             const int ks_ = PL_STG * (PH) + j_ < KS ? PL_STG * (PH) + j_ : KS - 1;                           \
-            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) bq[PAR][j_][p_] = bsrc[((int64_t)ks_ * 3 + p_) * 64]; \
+            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                              \
+                const u32x4* bp_ = bsrc + ((int64_t)ks_ * 3 + p_) * 64;                                     \
+                PL_GLOAD(bq[PAR][j_][p_], bp_);                                                             \
+            }                                                                                               \
         }                                                                                                   \
+    } while (0)
+    // "everything requested before this phase's own PL_NLD requests has landed": the fragments of phase PAR and the X rows
+    // parked at the end of this phase (tied to the statement so that no use is scheduled in front of it)
+#define PL_WAIT_OLDER(PAR)                                                                                  \
+    do {                                                                                                    \
+        if constexpr (HAND)                                                                                 \
+            asm volatile("s_waitcnt vmcnt(8)"                                                               \
+                         : "+v"(bq[PAR][0][0]), "+v"(bq[PAR][0][1]), "+v"(bq[PAR][0][2]), "+v"(bq[PAR][1][0]), "+v"(bq[PAR][1][1]), \
+                           "+v"(bq[PAR][1][2]), "+v"(raw[(PAR) ^ 1][0]), "+v"(raw[(PAR) ^ 1][1])            \
+                         : : "memory");                                                                     \
     } while (0)
     // one phase: request X of phase PH + 2 and the fragments of phase PH + 1, multiply phase PH, park X of phase PH + 1
 #define PL_PHASE(PAR, PH)                                                                                   \
@@ -195,29 +224,36 @@ __global__ __launch_bounds__(256, 4) void linear_planes_kernel(
         /* multiplies tile 0 and stores nothing: no branch inside the phase)                                                    */ \
         PL_ISSUE_X(PAR, (PH) + 2 < NPH ? (PH) + 2 : NPH - 1);                                               \
         PL_ISSUE_B((PAR) ^ 1, (PH) + 1 < NPH ? (PH) + 1 : NPH - 1);                                         \
-        _Pragma("unroll") for (int j_ = 0; j_ < PL_STG; ++j_) {                                             \
-            u32x4 a_[RH][3];                                                                                \
+        /* the requests lead the phase (hipcc otherwise sinks them behind the MFMAs, right in front of the barrier, and the   */ \
+        /* next phase opens by waiting for them); then ALL A fragments of the phase are requested before its first MFMA        */ \
+        u32x4 a_[PL_STG][RH][3];                                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < PL_STG; ++j_)                                               \
             _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                \
                 _Pragma("unroll") for (int h_ = 0; h_ < RH; ++h_)                                           \
-                    a_[h_][p_] = As[PAR][((j_ * 3 + p_) * 2 + (RH == 2 ? h_ : myh)) * 64 + lane];           \
+                    a_[j_][h_][p_] = As[PAR][((j_ * 3 + p_) * 2 + (RH == 2 ? h_ : myh)) * 64 + lane];       \
+        PL_WAIT_OLDER(PAR);                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < PL_STG; ++j_) {                                             \
             /* products: against b1: a3 a2 a1;  against b2: a2 a1;  against b3: a1 */                      \
             _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                                              \
                 const int ahi_ = 2 - q_, alo_ = (q_ == 0) ? 1 : 0, blo_ = (q_ < 2) ? 1 : 2;                 \
                 _Pragma("unroll") for (int h_ = 0; h_ < RH; ++h_)                                           \
-                    acc[h_][0] = mfma_bf16(a_[h_][ahi_], bq[PAR][j_][0], acc[h_][0]);                       \
+                    acc[h_][0] = mfma_bf16(a_[j_][h_][ahi_], bq[PAR][j_][0], acc[h_][0]);                   \
                 _Pragma("unroll") for (int h_ = 0; h_ < RH; ++h_)                                           \
-                    acc[h_][NACC - 1] = mfma_bf16(a_[h_][alo_], bq[PAR][j_][blo_], acc[h_][NACC - 1]);      \
+                    acc[h_][NACC - 1] = mfma_bf16(a_[j_][h_][alo_], bq[PAR][j_][blo_], acc[h_][NACC - 1]);  \
             }                                                                                               \
         }                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
         if ((PH) + 1 < NPH) {                                                                               \
             PL_PARK((PAR) ^ 1, (PH) + 1, (PAR) ^ 1);    /* (the other buffer's readers passed the previous barrier) */ \
             __syncthreads();                                                                                \
         }                                                                                                   \
     } while (0)
 
+    static_assert(PL_STG == 2, "PL_WAIT_OLDER counts 2 X + 3 * PL_STG B requests per phase");
     PL_ISSUE_X(0, 0);
-    if (NPH > 1) PL_ISSUE_X(1, 1);
+    PL_ISSUE_X(1, NPH > 1 ? 1 : 0);
     PL_ISSUE_B(0, 0);
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(8)" : "+v"(raw[0][0]), "+v"(raw[0][1]) : : "memory");   // X of phase 0 (2 + 6 requests behind it)
     PL_PARK(0, 0, 0);
     __syncthreads();
     for (int ph = 0; ph < NPH; ph += 2) {
@@ -225,6 +261,8 @@ __global__ __launch_bounds__(256, 4) void linear_planes_kernel(
         if (ph + 1 < NPH) PL_PHASE(1, ph + 1);
     }
 #undef PL_PHASE
+#undef PL_WAIT_OLDER
+#undef PL_GLOAD
 #undef PL_ISSUE_B
 #undef PL_PARK
 #undef PL_ISSUE_X
@@ -302,12 +340,22 @@ int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, c
     const int ncb = narrow ? (NT + 1) / 2 : (NT + 3) / 4;
     const int64_t grid = (int64_t)((nrb + 7) / 8) * 8 * ncb;
     if (grid > (1ll << 30)) return -1;
-    if (narrow)
-        hipLaunchKernelGGL(linear_planes_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X,
-                           reinterpret_cast<const u32x4*>(planes), bias, bias2, n1, Y, R, K, N, ldx, ldy, act, accumulate, nrb, ncb);
-    else
-        hipLaunchKernelGGL(linear_planes_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X,
-                           reinterpret_cast<const u32x4*>(planes), bias, bias2, n1, Y, R, K, N, ldx, ldy, act, accumulate, nrb, ncb);
+    // same-box A/B inside the cfg2 step (tools/bench_linear_planes.py, bench.py through the tuning library, three alternating
+    // runs): 0.9640 / 0.9636 / 0.9630 ms with the hand-counted form, 0.9605 / 0.9674 / 0.9619 with hipcc's schedule (0.9816 /
+    // 0.9825 / 0.9798 without the plane form); isolated launches: 25.2 vs 21.9 us forward, 22.4 vs 23.4 us input gradient at
+    // 7 040 rows.  Equal in the step; hipcc's form keeps 4 waves per SIMD and needs no spill guard, so it ships.
+    bool hand = false;
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_PLANES_HAND")) hand = e[0] != '0';      // A/B aid
+#endif
+#define PL_LAUNCH(RH_, HAND_)                                                                                 \
+    hipLaunchKernelGGL((linear_planes_kernel<RH_, HAND_>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X, \
+                       reinterpret_cast<const u32x4*>(planes), bias, bias2, n1, Y, R, K, N, ldx, ldy, act, accumulate, nrb, ncb)
+    if (narrow && hand) PL_LAUNCH(1, true);
+    else if (narrow) PL_LAUNCH(1, false);
+    else if (hand) PL_LAUNCH(2, true);
+    else PL_LAUNCH(2, false);
+#undef PL_LAUNCH
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -473,7 +473,7 @@ def test_slab_stacks_of_the_head_and_the_gather_bias_ride_on_the_batch_reduction
     (mmdfn_gemm_tn_batch_ext): no head_reduce / colsum_final launch in the trace, same gradients as plain autograd (checked by
     the test above), and a second backward without zero_grad accumulates (the bias halves then take the autograd path)."""
     from torch.profiler import ProfilerActivity, profile
-    from mm_dfn_amd import ops_wgrad       # (the queue's own module: a name that is REBOUND has to be patched where it is looked up)
+    from mm_dfn_amd import ops, ops_wgrad  # (the queue's own module: a name that is REBOUND has to be patched where it is looked up)
     m = _model().train()
     b, flat = _step_inputs()
     seen = []
@@ -887,3 +887,29 @@ def test_reshuffled_epochs_stay_on_replays_with_the_bucketed_cache(tmp_path):
     late_hits = sum(h for h, _ in stats[3:])
     late = sum(h + mi for h, mi in stats[3:])
     assert late_hits >= 0.8 * late, stats
+
+
+def test_precaptured_buckets_leave_no_capture_to_the_passes(tmp_path):
+    """StepGraphCache.precapture (round 6): the bucket set is captured from the loader's length histogram BEFORE the first pass --
+    walks of the same loader under the seeds the passes will use (the reference reseeds every pass, run_train_erc.py:164, so its
+    shuffles are known in advance), no optimizer, no metrics -- and the training passes that follow capture NOTHING; the model's
+    .grad fields are left alone."""
+    p = D.write_synthetic_pickle(str(tmp_path / "f.pkl"), n_train=40, n_test=4, max_len=26, min_len=9, seed=12)
+    names = ['hap', 'sad', 'neu', 'ang', 'exc', 'fru']
+    loss_f = FocalLoss(gamma=0.5)
+    m = _model(27).train()
+    tr, _, _ = D.get_IEMOCAP_loaders(p, batch_size=4, valid_rate=0.0)
+    cache = T.StepGraphCache(m, loss_f, bucket_rows=16)
+    marker = torch.ones_like(m.smax_fc.bias)
+    m.smax_fc.bias.grad = marker
+    made = 0
+    for e in range(3):                                   # the warm-up: the passes' own shuffles (seed 100 + e, as below)
+        T.seed_everything(100 + e)
+        made += cache.precapture(D.DevicePrefetcher(tr), train_flag=True)
+    assert made == len(cache.entries) >= 1 and m.smax_fc.bias.grad is marker      # .grad fields untouched
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    for e in range(3):
+        before = cache.misses
+        T.train_or_eval_graph_model(m, loss_f, D.DevicePrefetcher(tr), e, True, opt, False, 'avl', names, seed=100 + e,
+                                    graph_cache=cache)
+        assert cache.misses == before, (e, cache.misses - before)      # zero captures after the warm-up
