@@ -265,19 +265,40 @@ int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const
  *
  * mmdfn_weight_planes_workspace: bytes of the plane buffer of a B operand with N output columns and K contraction
  *   (ceil(N/32) x ceil(K/16) x 3 pieces x 1 KB; zero-filled outside N x K by the cut).
- * mmdfn_cut_weight_planes: for weight i the STORED matrix has row stride ld[i] and is given as two row blocks: rows [0, n1[i])
- *   at w1[i], the rest at w2[i] (null when n1 covers every row).  transposed[i] == 0: B[n][k] = stored[n][k]  (forward:
- *   N = stored rows, K = stored columns);  transposed[i] == 1: B[n][k] = stored[k][n]  (the input gradient dX = dY . W:
- *   N = stored columns, K = stored rows).  planes[i]: 16-byte aligned, mmdfn_weight_planes_workspace(N[i], K[i]) bytes.
+ * mmdfn_cut_weight_planes: weight i is given as up to two fp32 matrices w1[i] / w2[i] of row stride ld[i] (w2 may be null) and a
+ *   mode[i] that says how the B operand (N[i] output columns, K[i] contraction) is read from them:
+ *     0  B[n][k] = stored[n][k], the stored rows split at n1[i] (rows [0, n1) in w1, the rest in w2): a forward product against
+ *        the two directions' own parameters;
+ *     1  B[n][k] = stored[k][n], the stored rows (= k) split at n1[i]: the input gradient dX = dY . W on the same parameters
+ *        (and y = x W for a weight stored (K, N): GraphConvolution.weight, model_GCN.py:172);
+ *     2  B[n][k] = w1[k][n] for n < n1[i], w2[k][n - n1] beyond: two (K, .) matrices side by side, transposed;
+ *     3  as 2 with the contraction index gate-interleaved, k = 4 u + g  <->  stored row g (K / 4) + u: [W_ih | W_hh] of the
+ *        reasoning module's LSTM cell for the backward launch below (K = 4H, N = 2H, or N = H with w2 = NULL).
+ *   planes[i]: 16-byte aligned, mmdfn_weight_planes_workspace(N[i], K[i]) bytes.
  * mmdfn_linear_planes:  Y = act(X B^T + bias) (+ Y);  X: R rows of K floats (row stride ldx, 16-byte aligned rows, K % 4 == 0),
  *   bias / bias2 split at n1 as in mmdfn_linear2 (either may be null), Y: R x N (row stride ldy), act: 0 identity, 1 ReLU.
  *   Arithmetic: six bf16 piece products per MAC, fp32 accumulation -- fp32-level error, as mmdfn_linear's many-row form.
+ * mmdfn_gcnii_layer_fwd_planes / _bwd_planes, mmdfn_lstm_gate_bwd_planes (gcn_planes.hip): the many-row forms of K7 forward /
+ *   backward and of K8 backward on the same pipeline -- operands, layouts and results (to fp32 rounding) of
+ *   mmdfn_gcnii_layer_fwd / mmdfn_gcnii_layer_bwd_ld / mmdfn_lstm_gate_bwd, with the weight replaced by its planes:
+ *   K7 forward  planes of GraphConvolution.weight (2H, H) in mode 1 (N = H, K = 2H);
+ *   K7 backward planes of the same weight in mode 0 (N = 2H, K = H);
+ *   K8 backward planes of (W_ih, W_hh) in mode 3 (N = 2H, K = 4H; has_h = 0: W_ih alone, N = H).
  * ------------------------------------------------------------------------- */
 int64_t mmdfn_weight_planes_workspace(int N, int K);
 int mmdfn_cut_weight_planes(int n, const float* const* w1, const float* const* w2, const int* n1, const int* ld,
-                            const int* N, const int* K, const int* transposed, void* const* planes, void* stream);
+                            const int* N, const int* K, const int* mode, void* const* planes, void* stream);
 int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, const float* bias2, int n1, float* Y, int R,
                         int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
+int mmdfn_gcnii_layer_fwd_planes(const float* hi, const float* h0, const void* planes, const float* q, const float* m,
+                                 float* out, float* gmask, float theta, float alpha, int R, int H, int ldo, float mscale,
+                                 void* stream);
+int mmdfn_gcnii_layer_bwd_planes(const float* dout, const float* gmask, const void* planes, float* dP, float* dhi,
+                                 float* dh0, float theta, float alpha, int R, int H, int lddo, int acc_h0, int lddhi,
+                                 void* stream);
+int mmdfn_lstm_gate_bwd_planes(const float* gates, const float* c_prev, const float* c_new, const float* dh_a, const float* dh_b,
+                               const float* dc_next, const void* planes, const float* dres, float* dG, float* dc_prev, float* dq,
+                               float* dh_prev, int R, int H, int has_h, int lddres, void* stream);
 
 /* A GROUP of few-row projections in one launch (linear_small.hip; n <= 8 problems, K <= 768, K % 4 == 0):
  *   Y_p = act(X_p W_p^T + b_p) (+ Y_p)      X_p: R_p rows of K_p floats (stride ldx), Y_p: R_p x N_p (stride ldy)

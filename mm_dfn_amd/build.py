@@ -22,7 +22,7 @@ ARCH = "gfx950"
 # kernels whose vector-memory requests are asm statements with hand-counted waits: a register spill between a request and its wait
 # would store a register the load has not written yet.  (source file, substring of the mangled kernel name) -> the build fails
 # unless hipcc reports ScratchSize 0 for every such kernel.
-NO_SPILL = {"linear_planes.hip": "linear_planes_kernelILi"}
+NO_SPILL = {}        # (round 6's hand-counted form of linear_planes.hip measured equal to hipcc's schedule and was removed)
 
 
 def sources():

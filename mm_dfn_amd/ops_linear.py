@@ -416,7 +416,7 @@ _PLANE_RECORDERS = []
 
 
 class _PlaneEntry:
-    __slots__ = ("w1", "w2", "transposed", "N", "K", "n1", "buf", "epoch", "stamp", "__weakref__")
+    __slots__ = ("w1", "w2", "mode", "N", "K", "n1", "buf", "epoch", "stamp", "__weakref__")
 
 
 def _plane_stamp(w1, w2):
@@ -444,7 +444,7 @@ def _cut_planes(entries):
         rc = _hip.lib().mmdfn_cut_weight_planes(
             len(chunk), pa([w1 for _, w1, _ in chunk]), pa([w2 for _, _, w2 in chunk]), ia([e.n1 for e, _, _ in chunk]),
             ia([w1.stride(0) for _, w1, _ in chunk]), ia([e.N for e, _, _ in chunk]), ia([e.K for e, _, _ in chunk]),
-            ia([1 if e.transposed else 0 for e, _, _ in chunk]), pa([e.buf for e, _, _ in chunk]), _hip.stream())
+            ia([e.mode for e, _, _ in chunk]), pa([e.buf for e, _, _ in chunk]), _hip.stream())
         _hip.check(rc, "mmdfn_cut_weight_planes")
         for e, w1, w2 in chunk:
             e.epoch = _PLANE_EPOCH[0]
@@ -457,11 +457,14 @@ def planes_supported(w1, w2=None):
     return ok(w1) and (w2 is None or (ok(w2) and w2.shape[1] == w1.shape[1] and w2.stride(0) == w1.stride(0)))
 
 
-def weight_planes(w1, w2=None, transposed=False):
-    """The piece-plane entry of the B operand built from the stored matrix [w1; w2] (``transposed``: of its transpose -- the
-    input gradient's operand); cut now if it is new or stale (see the section comment)."""
+def weight_planes(w1, w2=None, transposed=False, mode=None):
+    """The piece-plane entry of a B operand read from the stored matrices w1 / w2 (``mode``: mmdfn_cut_weight_planes' -- 0 the
+    stacked rows [w1; w2] as stored, 1 their transpose (``transposed=True``: the input gradient's operand), 2 / 3 two (K, .) matrices
+    side by side, transposed (3: gate-interleaved contraction index); cut now if the entry is new or stale (see the section comment)."""
     import weakref
-    key = (id(w1), 0 if w2 is None else id(w2), bool(transposed))
+    if mode is None:
+        mode = 1 if transposed else 0
+    key = (id(w1), 0 if w2 is None else id(w2), int(mode))
     e = _PLANES.get(key)
     if e is not None and (e.w1() is not w1 or (w2 is not None and e.w2() is not w2)):
         e = None                                   # an id recycled by another tensor
@@ -470,9 +473,15 @@ def weight_planes(w1, w2=None, transposed=False):
         cols = w1.shape[1]
         e = _PlaneEntry()
         e.w1, e.w2 = weakref.ref(w1), (None if w2 is None else weakref.ref(w2))
-        e.transposed = bool(transposed)
-        e.N, e.K = (cols, rows) if transposed else (rows, cols)
-        e.n1 = w1.shape[0]
+        e.mode = int(mode)
+        if mode == 0:
+            e.N, e.K, e.n1 = rows, cols, w1.shape[0]
+        elif mode == 1:
+            e.N, e.K, e.n1 = cols, rows, w1.shape[0]
+        else:                                      # two (K, .) matrices side by side
+            if w2 is not None and w2.shape[0] != w1.shape[0]:
+                raise ValueError("weight_planes: modes 2 / 3 need matrices with the same number of rows")
+            e.N, e.K, e.n1 = cols + (0 if w2 is None else w2.shape[1]), w1.shape[0], cols
         nbytes = _hip.lib().mmdfn_weight_planes_workspace(e.N, e.K)
         if nbytes <= 0:
             raise _hip.HipLibraryError("mmdfn_weight_planes_workspace refused N=%d K=%d" % (e.N, e.K))
@@ -538,7 +547,7 @@ def linear_planes_raw(x2, w1, w2=None, b1=None, b2=None, transposed=False, act=0
         raise ValueError("linear_planes_raw: contraction width %d, planes were cut for %d" % (K, e.K))
     if out is None:
         out = torch.empty(R, e.N, dtype=torch.float32, device=x2.device)
-    n1 = e.N if (transposed or w2 is None) else e.n1
+    n1 = e.N if (transposed or w2 is None) else e.n1      # (bias split: only the forward orientation has two bias blocks)
     rc = _hip.lib().mmdfn_linear_planes(_hip.ptr(x2), _hip.ptr(e.buf), _hip.ptr(b1), _hip.ptr(b2), n1, _hip.ptr(out), R, K, e.N,
                                         x2.stride(0), out.stride(0), int(act), 1 if accumulate else 0, _hip.stream())
     _hip.check(rc, "mmdfn_linear_planes")

@@ -151,6 +151,24 @@ def main():
         for name in sys.argv[1].split(","):
             stamps(name)
         return
+    if len(sys.argv) > 2 and sys.argv[2] == "abl":
+        # round 6: what the launch is made of -- timing-only ablations of gemm_tn_split_kernel (MMDFN_TNS_ABL:
+        # 1 no cutting, 2 no MFMAs, 4 no fragment reads, 8 no global loads; 7 = loads + LDS staging only, 15 = skeleton)
+        os.environ["MMDFN_TN_SPLIT"] = "1"
+        for name in sys.argv[1].split(","):
+            batch, flops = make_batch(name)
+            for rep in range(2):
+                row = []
+                for abl, what in ((0, "full"), (1, "no cut"), (2, "no MFMA"), (4, "no fragment reads"), (8, "no global loads"),
+                                  (7, "loads + staging only"), (15, "skeleton")):
+                    if abl:
+                        os.environ["MMDFN_TNS_ABL"] = str(abl)
+                    else:
+                        os.environ.pop("MMDFN_TNS_ABL", None)
+                    row.append("%s %.1f" % (what, gtime(lambda: run(batch))))
+                os.environ.pop("MMDFN_TNS_ABL", None)
+                print("%-5s (%.2f GFLOP) us per launch pair: %s" % (name, flops / 1e9, " | ".join(row)), flush=True)
+        return
     names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["cfg2", "cfg3", "cfg4", "cfg5"]
     do_check = len(sys.argv) > 2
     for name in names:
