@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 14: 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 15: 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -272,33 +272,18 @@ int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const
  *     1  B[n][k] = stored[k][n], the stored rows (= k) split at n1[i]: the input gradient dX = dY . W on the same parameters
  *        (and y = x W for a weight stored (K, N): GraphConvolution.weight, model_GCN.py:172);
  *     2  B[n][k] = w1[k][n] for n < n1[i], w2[k][n - n1] beyond: two (K, .) matrices side by side, transposed;
- *     3  as 2 with the contraction index gate-interleaved, k = 4 u + g  <->  stored row g (K / 4) + u: [W_ih | W_hh] of the
- *        reasoning module's LSTM cell for the backward launch below (K = 4H, N = 2H, or N = H with w2 = NULL).
+ *     3  as 2 with the contraction index gate-interleaved, k = 4 u + g  <->  stored row g (K / 4) + u ([W_ih | W_hh] of an LSTM
+ *        cell, K = 4H; used by the stack-kernel experiment under tools/gcn_planes/).
  *   planes[i]: 16-byte aligned, mmdfn_weight_planes_workspace(N[i], K[i]) bytes.
  * mmdfn_linear_planes:  Y = act(X B^T + bias) (+ Y);  X: R rows of K floats (row stride ldx, 16-byte aligned rows, K % 4 == 0),
  *   bias / bias2 split at n1 as in mmdfn_linear2 (either may be null), Y: R x N (row stride ldy), act: 0 identity, 1 ReLU.
  *   Arithmetic: six bf16 piece products per MAC, fp32 accumulation -- fp32-level error, as mmdfn_linear's many-row form.
- * mmdfn_gcnii_layer_fwd_planes / _bwd_planes, mmdfn_lstm_gate_bwd_planes (gcn_planes.hip): the many-row forms of K7 forward /
- *   backward and of K8 backward on the same pipeline -- operands, layouts and results (to fp32 rounding) of
- *   mmdfn_gcnii_layer_fwd / mmdfn_gcnii_layer_bwd_ld / mmdfn_lstm_gate_bwd, with the weight replaced by its planes:
- *   K7 forward  planes of GraphConvolution.weight (2H, H) in mode 1 (N = H, K = 2H);
- *   K7 backward planes of the same weight in mode 0 (N = 2H, K = H);
- *   K8 backward planes of (W_ih, W_hh) in mode 3 (N = 2H, K = 4H; has_h = 0: W_ih alone, N = H).
  * ------------------------------------------------------------------------- */
 int64_t mmdfn_weight_planes_workspace(int N, int K);
 int mmdfn_cut_weight_planes(int n, const float* const* w1, const float* const* w2, const int* n1, const int* ld,
                             const int* N, const int* K, const int* mode, void* const* planes, void* stream);
 int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, const float* bias2, int n1, float* Y, int R,
                         int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
-int mmdfn_gcnii_layer_fwd_planes(const float* hi, const float* h0, const void* planes, const float* q, const float* m,
-                                 float* out, float* gmask, float theta, float alpha, int R, int H, int ldo, float mscale,
-                                 void* stream);
-int mmdfn_gcnii_layer_bwd_planes(const float* dout, const float* gmask, const void* planes, float* dP, float* dhi,
-                                 float* dh0, float theta, float alpha, int R, int H, int lddo, int acc_h0, int lddhi,
-                                 void* stream);
-int mmdfn_lstm_gate_bwd_planes(const float* gates, const float* c_prev, const float* c_new, const float* dh_a, const float* dh_b,
-                               const float* dc_next, const void* planes, const float* dres, float* dG, float* dc_prev, float* dq,
-                               float* dh_prev, int R, int H, int has_h, int lddres, void* stream);
 
 /* A GROUP of few-row projections in one launch (linear_small.hip; n <= 8 problems, K <= 768, K % 4 == 0):
  *   Y_p = act(X_p W_p^T + b_p) (+ Y_p)      X_p: R_p rows of K_p floats (stride ldx), Y_p: R_p x N_p (stride ldy)

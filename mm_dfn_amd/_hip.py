@@ -48,9 +48,6 @@ SIGNATURES = {
     "mmdfn_weight_planes_workspace": [_I, _I],
     "mmdfn_cut_weight_planes": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_linear_planes": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "mmdfn_gcnii_layer_fwd_planes": [_P] * 7 + [_F, _F, _I, _I, _I, _F, _P],
-    "mmdfn_gcnii_layer_bwd_planes": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _I, _P],
-    "mmdfn_lstm_gate_bwd_planes": [_P] * 12 + [_I] * 4 + [_P],
     "mmdfn_linear_group_supported": [_I, _I, _I],
     "mmdfn_linear_group": [_I] + [_P] * 15 + [_I, _P],
     "mmdfn_linear_group_addend": [_I] + [_P] * 17 + [_I, _P],

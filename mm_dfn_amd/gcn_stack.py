@@ -20,12 +20,6 @@ import torch
 
 from . import _hip, ops
 
-# many-row launches of K7 forward / backward and K8 backward on the weight's bf16 piece planes (csrc/gcn_planes.hip: planes cut
-# once per optimizer step, ops_linear.weight_planes); a huge value keeps the exact-f32 kernels of csrc/gcn_stack.hip (A/B aid)
-_env_rows = lambda name, default: int(__import__("os").environ.get(name, default))
-K7_PLANES_ROWS = _env_rows("MMDFN_K7_PLANES_ROWS", "16384")
-K8_PLANES_ROWS = _env_rows("MMDFN_K8_PLANES_ROWS", "16384")
-
 ROW_LIMIT = 131072        # measured to 98 304 rows (cfg5 B = 32): the fused node is 8-9 % ahead of the op-by-op path at every size (round 4)
 # test tap: a list to which every forward of the fused node appends references to its ReLU decisions (h0, the per-layer
 # gate masks, the output) -- tests/util.relu_flips_from_tap compares them with the oracle's pre-activations to find the
@@ -97,14 +91,8 @@ class _GcnStack(torch.autograd.Function):
                 dst, ldo = new(R, H), H
             gmask = new(R, H)
             theta = math.log(lamda / (i + 1) + 1)
-            if R >= K7_PLANES_ROWS and ops.planes_supported(convW[i]):
-                pl = ops.weight_planes(convW[i], mode=1)       # P = [hi | h0] W: B[n][k] = W[k][n]
-                _hip.check(lib.mmdfn_gcnii_layer_fwd_planes(P(hi), P(h0), P(pl.buf), P(q if reason else None), P(ml[i]), P(dst),
-                                                            P(gmask), theta, alpha, R, H, ldo, mscale, st),
-                           "mmdfn_gcnii_layer_fwd_planes")
-            else:
-                _hip.check(lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(convW[i]), P(q if reason else None), P(ml[i]), P(dst),
-                                                     P(gmask), theta, alpha, R, H, ldo, mscale, st), "mmdfn_gcnii_layer_fwd")
+            _hip.check(lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(convW[i]), P(q if reason else None), P(ml[i]), P(dst),
+                                                 P(gmask), theta, alpha, R, H, ldo, mscale, st), "mmdfn_gcnii_layer_fwd")
             rec.update(zin=zin, hi=hi, gmask=gmask, theta=theta)
             layers.append(rec)
             cur = dst
@@ -166,15 +154,8 @@ class _GcnStack(torch.autograd.Function):
             L = ctx.layers[i]
             dP = new(R, H)
             dhi = dhi_all[:, i * H:(i + 1) * H] if one_outer else new(R, H)
-            if R >= K7_PLANES_ROWS and ops.planes_supported(convW[i]):
-                pl = ops.weight_planes(convW[i], mode=0)       # [dhi | dh0] = dP W^T: B[n][k] = W[n][k]
-                _hip.check(lib.mmdfn_gcnii_layer_bwd_planes(P(dcur), P(L["gmask"]), P(pl.buf), P(dP), P(dhi), P(dh0), L["theta"],
-                                                            m["alpha"], R, H, lddo, acc_h0, dhi.stride(0), st),
-                           "mmdfn_gcnii_layer_bwd_planes")
-            else:
-                _hip.check(lib.mmdfn_gcnii_layer_bwd_ld(P(dcur), P(L["gmask"]), P(convW[i]), P(dP), P(dhi), P(dh0), L["theta"],
-                                                        m["alpha"], R, H, lddo, acc_h0, dhi.stride(0), st),
-                           "mmdfn_gcnii_layer_bwd_ld")
+            _hip.check(lib.mmdfn_gcnii_layer_bwd_ld(P(dcur), P(L["gmask"]), P(convW[i]), P(dP), P(dhi), P(dh0), L["theta"],
+                                                    m["alpha"], R, H, lddo, acc_h0, dhi.stride(0), st), "mmdfn_gcnii_layer_bwd_ld")
             acc_h0 = 1
             # dW_i = [hi | h0]^T dP: two row ranges of the (2H, H) parameter, the concatenated operand never exists
             wgrad(L["hi"], dP, convW[i], rows=(0, H))
@@ -187,18 +168,9 @@ class _GcnStack(torch.autograd.Function):
                 dG, dq = new(R, 4 * H), new(R, H)
                 dh_prev = new(R, H) if has_h else None
                 dc_prev = new(R, H) if has_h else None
-                if R >= K8_PLANES_ROWS and ops.planes_supported(w_ih) and ops.planes_supported(w_hh):
-                    # [dq | dh_prev] = dG [W_ih | W_hh], contraction index gate-interleaved (mode 3); the first layer has no
-                    # incoming state: dq = dG W_ih alone
-                    pl = ops.weight_planes(w_ih, w_hh if has_h else None, mode=3)
-                    _hip.check(lib.mmdfn_lstm_gate_bwd_planes(P(L["gates"]), P(L["c_prev"]), P(L["c_new"]), P(dz), P(dh_carry),
-                                                              P(dc_carry), P(pl.buf), P(dcur), P(dG), P(dc_prev), P(dq),
-                                                              P(dh_prev), R, H, 1 if has_h else 0, lddo, st),
-                               "mmdfn_lstm_gate_bwd_planes")
-                else:
-                    _hip.check(lib.mmdfn_lstm_gate_bwd(P(L["gates"]), P(L["c_prev"]), P(L["c_new"]), P(dz), P(dh_carry),
-                                                       P(dc_carry), P(w_ih), P(w_hh), P(dcur), P(dG), P(dc_prev), P(dq),
-                                                       P(dh_prev), R, H, 1 if has_h else 0, lddo, st), "mmdfn_lstm_gate_bwd")
+                _hip.check(lib.mmdfn_lstm_gate_bwd(P(L["gates"]), P(L["c_prev"]), P(L["c_new"]), P(dz), P(dh_carry),
+                                                   P(dc_carry), P(w_ih), P(w_hh), P(dcur), P(dG), P(dc_prev), P(dq),
+                                                   P(dh_prev), R, H, 1 if has_h else 0, lddo, st), "mmdfn_lstm_gate_bwd")
                 wgrad(dG, L["q"], w_ih, [b_ih, b_hh])
                 if has_h:
                     wgrad(dG, L["h_prev"], w_hh)

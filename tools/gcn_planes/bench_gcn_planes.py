@@ -2,7 +2,7 @@
 at the stack's row counts (cfg2 5 280, cfg4 10 560, cfg5 B=8 24 576, cfg5 B=32 98 304); captured launches, HIP events."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mm_dfn_amd import _hip, ops  # noqa: E402
 
 dev = "cuda"

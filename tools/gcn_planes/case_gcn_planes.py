@@ -1,4 +1,4 @@
-"""GPU: the many-row forms of K7 forward / backward and K8 backward on bf16 piece planes (csrc/gcn_planes.hip) against fp64 and
+"""(Not collected by pytest: the parity cases that were run against the experiment, see README.md.)  GPU: the many-row forms of K7 forward / backward and K8 backward on bf16 piece planes (csrc/gcn_planes.hip) against fp64 and
 against the exact-f32 kernels of csrc/gcn_stack.hip they stand in for (same operands, same layouts)."""
 import numpy as np
 import pytest

@@ -11,9 +11,9 @@
 //             128-byte row segments)
 //   backward  dP = theta dout (.) gmask (written out: operand of dW);  [dhi | dh0] = dP W^T + [c1 dP | c2 dP]
 //             A = dP formed while staging (K = H), B = W planes as stored (N = 2H: two column blocks; block 0 also writes dP)
-// Same operands, layouts and results (to fp32 rounding) as mmdfn_gcnii_layer_fwd / _bwd_ld, which dispatch here above
-// MMDFN_K7_PLANES_ROWS rows when the caller hands over planes.
-#include "planes_common.h"
+// Same operands, layouts and results (to fp32 rounding) as mmdfn_gcnii_layer_fwd / _bwd_ld.
+// NOT PART OF THE LIBRARY: measured slower than the exact-f32 kernels in the step (README.md next to this file).
+#include "planes_common.h"      // (mm_dfn_amd/csrc/)
 #include "../../include/mmdfn_hip.h"
 
 namespace {
