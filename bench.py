@@ -92,7 +92,7 @@ def profile_json(name):
         return None
 
 
-TRAFFIC_JSON = "r05_propagate_traffic.json"      # (this round's PMC passes)
+TRAFFIC_JSON = "r06_propagate_traffic.json"      # (this round's PMC passes)
 
 
 def measured_traffic(key, kernel):
@@ -406,6 +406,10 @@ def streamed_leg(cfgname, dropout, nbatches=32, passes=2):
         pre = D.DevicePrefetcher(make(7000, nbatches), device=dev)
         # the bucket set is captured BEFORE the first pass from four passes' worth of batches drawn like the ones to come
         # (StepGraphCache.precapture: forward + loss + backward of the first batch of every new bucket, no optimizer, no metrics)
+        # (two real steps first: FlatAdam lays the parameters out in its flat buffer at its first step, and a captured step bakes
+        # the parameter storages -- entries captured before that would all be captured again)
+        pre.loader = make(6000, 2)
+        train.train_or_eval_graph_model(model, loss_f, pre, 0, True, opt, False, graph_cache=cache)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         made = 0
@@ -431,7 +435,9 @@ def streamed_leg(cfgname, dropout, nbatches=32, passes=2):
             "bucket_rows": 32, "entries": len(cache.entries), "precaptured_entries": made, "precapture_s": precapture_s,
             "note": "the bucket set is captured ahead of the first pass (StepGraphCache.precapture over 4 x %d batches drawn like "
                     "the timed ones: precapture_s); every timed pass -- the FIRST one included -- streams length tuples the cache has "
-                    "never seen; a pass that still meets a new bucket pays ~25 ms for it" % nbatches, "passes": passes_out}
+                    "never seen; a pass that still meets a new bucket (the draws do not cover all ~40 possible ones) pays ~90 ms for it; "
+                    "tools/streamed_gap.py splits a replayed step: 0.96 ms device time of the real dialogues, +0.02 bucket padding / "
+                    "extra dialogue / retarget, +0.22 host, H2D, optimizer and metrics" % nbatches, "passes": passes_out}
         del model, opt, cache, pre
         torch.cuda.empty_cache()
     except Exception as exc:

@@ -141,7 +141,9 @@ class StepGraphCache:
         the loader's length histogram is what decides the set, so this is the loader the passes will use or one drawn like
         it -- and steps only the first batch of each new key (forward + loss + backward into the entry's own gradient
         buffers; no optimizer, no metrics; dropout draws are put back by CapturedStep).  Returns the number of entries
-        captured; the model's ``.grad`` fields are left as they were."""
+        captured; the model's ``.grad`` fields are left as they were.  Call it AFTER anything that re-points parameter storage
+        (FlatAdam lays the parameters out at its first step; ``.to()``; ``load_state_dict(assign=True)``): a captured step bakes
+        the storages and is captured again when they move."""
         grads = [(p, p.grad) for p in self.model.parameters()]
         made = 0
         for data in loader:

@@ -1,9 +1,9 @@
-# Round evidence in one go (run on the GPU box):  bash tools/collect_round_profiles.sh r05
+# Round evidence in one go (run on the GPU box):  bash tools/collect_round_profiles.sh r06
 #   gpurun_out/<r>_bench_cfg2.json                      the unmodified `python bench.py` line
 #   gpurun_out/<r>_bench_{cfg2,cfg3,cfg4}_kernel_stats.csv + <r>_step_breakdown_*.json   rocprofv3 --kernel-trace --stats of one workload each
 #   gpurun_out/<r>_cfg5_stream_{b8,b32}_kernel_stats.csv
 #   gpurun_out/<r>_k6_roofline_legs_kernel_stats.csv
-r=${1:-r05}
+r=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $root/gpurun_out
 cd /tmp; export TMPDIR=/tmp

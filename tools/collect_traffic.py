@@ -1,6 +1,6 @@
 """HBM traffic of the K6 roofline legs: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in SEPARATE passes over
 `bench.py --only-roofline` (kernel-trace only), FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64,
-MI355X_MICROARCH.md), written to profiles/r05_propagate_traffic.json together with the commit the library was built from.
+MI355X_MICROARCH.md), written to profiles/r06_propagate_traffic.json together with the commit the library was built from.
 
     COMMIT=$(git rev-parse --short HEAD) gpurun -- 'python tools/collect_traffic.py <commit>'
 """
@@ -91,6 +91,6 @@ st = stack_traffic()
 if st:
     res["cfg5_b32_bwd_stack"] = {"kernel": "tile_dot_split_kernel", "traffic_bytes": st["traffic_bytes"], "iterations": st["iterations"],
                                  "detail": st["detail"]}
-with open(os.path.join(ROOT, "gpurun_out", "r05_propagate_traffic.json"), "w") as fh:
+with open(os.path.join(ROOT, "gpurun_out", "r06_propagate_traffic.json"), "w") as fh:
     json.dump(res, fh, indent=1)
 print(json.dumps({k: res[k] for k in res if k in ("cfg2", "cfg5_b32", "cfg5_b32_bwd_stack", "commit")}, indent=1))
