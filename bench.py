@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per cpu_baseline mode")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for smoke tests)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use GPU 0 (needs --backend gloo)")
+    ap.add_argument("--no-floor", action="store_true",
+                    help="do not measure the dependent-launch cost live (a chain of 6 400 tiny launches: it would sit in a "
+                         "rocprof kernel summary of this run); the step floor then uses the price list's 1.45 us")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel machinery (process group, flat bucket, all-reduce) even at N = 1")
     ap.add_argument("--eager-allreduce", action="store_true",
@@ -749,7 +752,8 @@ def main():
         out["dominant"] = (profile_json("r06_step_breakdown_%s.json" % a.config) or profile_json("r05_step_breakdown_%s.json" % a.config)
                            or profile_json("r04_step_breakdown_%s.json" % a.config))
         try:
-            out["dominant"] = attach_step_floor(out["dominant"], a.config, [int(x) for x in lengths], dependent_launch_us())
+            out["dominant"] = attach_step_floor(out["dominant"], a.config, [int(x) for x in lengths],
+                                                1.45 if a.no_floor else dependent_launch_us())
         except Exception as exc:
             print("[bench] step floor not attached: %s: %s" % (type(exc).__name__, exc), file=sys.stderr)
         if world == 1 and not a.no_extra and not use_dp:

@@ -147,3 +147,48 @@ def test_linear2_node_on_planes_matches_autograd():
     assert float((x.grad.double() - xr.grad).abs().max()) <= 2e-6 * float(xr.grad.abs().max())
     for p, q in zip(prm, pr):
         assert float((p.grad.double() - q.grad).abs().max()) <= 3e-6 * float(q.grad.abs().max())
+
+
+def test_captured_step_with_flat_adam_keeps_planes_in_step(monkeypatch):
+    """A cfg2-size captured step (its party-GRU input products run on the plane kernels) replayed between FlatAdam steps: the graph
+    holds no cut, FlatAdam's kernel writes the weights behind autograd's version counters, so the planes stay right only because
+    FlatAdam invalidates them and CapturedStep.replay() re-cuts what its capture recorded.  Same losses as the run without the plane
+    form (a stale plane set would miss a 1e-2 learning-rate step: orders of magnitude above the tolerance)."""
+    from mm_dfn_amd import FocalLoss, ops_linear, synthetic, train
+    from mm_dfn_amd.graphs import CapturedStep
+    from mm_dfn_amd.optim import FlatAdam
+    cfg = dict(synthetic.CONFIGS["cfg2"])
+    batch = synthetic.make_batch(2021, device="cuda", **cfg)
+    label = train.flatten_labels(batch["label"], batch["lengths"])
+    loss_f = FocalLoss(gamma=0.5)
+
+    def run(min_rows):
+        monkeypatch.setattr(ops_linear, "PLANES_MIN_ROWS", min_rows)
+        model = synthetic.build_model(dropout=0.0, **cfg)
+        model.load_state_dict(synthetic.seeded_state_dict(model.state_dict(), 2021))
+        model = model.cuda().train()
+
+        def fwd_bwd():
+            logp = model(batch["textf"], batch["qmask"], batch["umask"], batch["lengths"], batch["acouf"], batch["visuf"])[0]
+            loss = loss_f(logp, label)
+            train.backward(loss)
+            return loss
+        model.zero_grad(set_to_none=True)
+        fwd_bwd()
+        opt = FlatAdam(model, lr=1e-2, weight_decay=1e-4)
+        opt.bucket.flatten()
+        opt._materialise()
+        cap = CapturedStep(model, fwd_bwd, warmup=2, bucket=opt.bucket)
+        used = len(cap._planes)
+        losses = []
+        for _ in range(4):
+            losses.append(float(cap.replay()))
+            opt.step(grads_already_flat=True)
+        return losses, used
+
+    with_planes, used = run(4096)
+    without, unused = run(1 << 30)
+    assert used >= 2 and unused == 0
+    assert with_planes[0] != with_planes[-1]                       # the steps do move the loss
+    for a, b in zip(with_planes, without):
+        assert abs(a - b) <= 2e-4 * abs(b), (with_planes, without)

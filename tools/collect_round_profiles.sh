@@ -16,9 +16,9 @@ prof() {   # tag, command...
   if [ -z "$f" ]; then echo "no stats for $tag"; tail -5 /tmp/p_$tag.log; return; fi
   cp $f $root/gpurun_out/${r}_${tag}_kernel_stats.csv
 }
-prof bench_cfg2 python $root/bench.py --config cfg2 --no-extra --no-roofline --no-cpu-baseline --steps 200 --warmup 30
-prof bench_cfg3 python $root/bench.py --config cfg3 --ragged --no-extra --no-roofline --no-cpu-baseline --steps 60 --warmup 15
-prof bench_cfg4 python $root/bench.py --config cfg4 --no-extra --no-roofline --no-cpu-baseline --steps 60 --warmup 15
+prof bench_cfg2 python $root/bench.py --config cfg2 --no-extra --no-roofline --no-cpu-baseline --no-floor --steps 200 --warmup 30
+prof bench_cfg3 python $root/bench.py --config cfg3 --ragged --no-extra --no-roofline --no-cpu-baseline --no-floor --steps 60 --warmup 15
+prof bench_cfg4 python $root/bench.py --config cfg4 --no-extra --no-roofline --no-cpu-baseline --no-floor --steps 60 --warmup 15
 prof cfg5_stream_b8 python $root/tools/prof_cfg5.py cfg5 20
 prof cfg5_stream_b32 python $root/tools/prof_cfg5.py cfg5_b32 8
 prof k6_roofline_legs python $root/bench.py --only-roofline
