@@ -31,15 +31,23 @@ def model_and_loss():
     return m.to(dev).train(), FocalLoss(gamma=0.5)
 
 
-def timed(fn, reps=3):
+HOST = {}
+
+
+def timed(fn, reps=3, tag=None):
     fn()
     torch.cuda.synchronize()
-    best = 1e9
+    best = host = 1e9
     for _ in range(reps):
         t0 = time.perf_counter()
         fn()
+        th = time.perf_counter() - t0               # the host is done issuing (the pass loop's own .cpu() at its end included)
         torch.cuda.synchronize()
-        best = min(best, time.perf_counter() - t0)
+        t1 = time.perf_counter() - t0
+        if t1 < best:
+            best, host = t1, th
+    if tag:
+        HOST[tag] = host / NB * 1e3
     return best / NB * 1e3
 
 
@@ -54,13 +62,32 @@ m, loss_f = model_and_loss()
 buck = train.StepGraphCache(m, loss_f, max_entries=96, bucket_rows=32)
 for w in range(4):
     buck.precapture(make(7000 + 100 * w, NB, pin=False), train_flag=True)
-b_ = timed(lambda: [buck.step(tuple(b), l, True) for b, l in zip(batches, lens)])
+b_ = timed(lambda: [buck.step(tuple(b), l, True) for b, l in zip(batches, lens)], tag='B')
 h0, m0 = buck.hits, buck.misses
 opt = FlatAdam(m, lr=3e-4, weight_decay=1e-4)
+class _Batch(list):
+    lengths = None
+
+
+res = []                                                               # the same batches, already on the device, lengths on the host
+for i, (b, l) in enumerate(zip(batches, lens)):
+    r = _Batch(list(b) + [["r%d" % i]])
+    r.lengths = list(l)
+    res.append(r)
+c1 = timed(lambda: train.train_or_eval_graph_model(m, loss_f, res, 0, True, opt, False, graph_cache=buck), tag='C1')
+
 pre = D.DevicePrefetcher(make(9000, NB, pin=True), device=dev)
-c = timed(lambda: train.train_or_eval_graph_model(m, loss_f, pre, 0, True, opt, False, graph_cache=buck))
+c = timed(lambda: train.train_or_eval_graph_model(m, loss_f, pre, 0, True, opt, False, graph_cache=buck), tag='C')
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+train.train_or_eval_graph_model(m, loss_f, pre, 0, True, opt, False, graph_cache=buck)
+pr.disable(); torch.cuda.synchronize()
+
 print("avg utterances per batch %.0f" % utt)
 print("A exact-signature replays, resident inputs          %.3f ms/step" % a)
 print("B bucketed replays, resident inputs                 %.3f ms/step   (B - A = %.3f: bucket padding + extra dialogue + retarget)" % (b_, b_ - a))
-print("C streamed pass (H2D + FlatAdam + metrics), bucketed %.3f ms/step   (C - B = %.3f: host / H2D / optimizer / metrics)" % (c, c - b_))
+print("C1 pass loop, resident inputs (FlatAdam + metrics)  %.3f ms/step   (C1 - B = %.3f: optimizer step, plane refresh, metrics, loop)" % (c1, c1 - b_))
+print("C streamed pass (H2D + FlatAdam + metrics), bucketed %.3f ms/step   (C - C1 = %.3f: pinned-host prefetch / staging)" % (c, c - c1))
+print("host issue time per step: B %.3f ms, C1 %.3f ms, C %.3f ms" % (HOST["B"], HOST["C1"], HOST["C"]))
+pstats.Stats(pr).sort_stats("cumtime").print_stats(28)
 print("bucketed entries %d, captures during the timed runs %d" % (len(buck.entries), buck.misses - m0))
