@@ -440,9 +440,10 @@ def streamed_leg(cfgname, dropout, nbatches=32, passes=2):
                     "the timed ones: precapture_s); every timed pass -- the FIRST one included -- streams length tuples the cache has "
                     "never seen; a pass that still meets a new bucket (the draws do not cover all ~40 possible ones) pays ~90 ms for it; "
                     "tools/streamed_gap.py splits a replayed step: 0.96 ms device time of the real dialogues (exact-signature replays, "
-                    "resident inputs), +0.02 for the bucket (padding dialogue, rounding, index retarget); the rest is HOST time -- the "
-                    "pass loop issues a step in 1.1-1.2 ms (retarget 0.16, staging 0.2-0.3, FlatAdam's gradient pack 0.2, replay 0.1, "
-                    "metrics bookkeeping), i.e. the loop is host-bound, not device-bound" % nbatches, "passes": passes_out}
+                    "resident inputs), +0.02 for the bucket (padding dialogue, rounding, index retarget), +0.10-0.14 for what the pass "
+                    "loop adds on the device around a replay (gradient pack, FlatAdam step, plane refresh, metrics copies, one graph "
+                    "launch per step), +0.10-0.20 with the batches coming from pinned host memory (the host itself issues a step in "
+                    "~0.6 ms and then waits for the device in the staging ring)" % nbatches, "passes": passes_out}
         del model, opt, cache, pre
         torch.cuda.empty_cache()
     except Exception as exc:

@@ -89,5 +89,5 @@ print("B bucketed replays, resident inputs                 %.3f ms/step   (B - A
 print("C1 pass loop, resident inputs (FlatAdam + metrics)  %.3f ms/step   (C1 - B = %.3f: optimizer step, plane refresh, metrics, loop)" % (c1, c1 - b_))
 print("C streamed pass (H2D + FlatAdam + metrics), bucketed %.3f ms/step   (C - C1 = %.3f: pinned-host prefetch / staging)" % (c, c - c1))
 print("host issue time per step: B %.3f ms, C1 %.3f ms, C %.3f ms" % (HOST["B"], HOST["C1"], HOST["C"]))
-pstats.Stats(pr).sort_stats("cumtime").print_stats(28)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
 print("bucketed entries %d, captures during the timed runs %d" % (len(buck.entries), buck.misses - m0))
