@@ -292,6 +292,12 @@ extern "C" int mmdfn_adj_build(const float* feats, float* unit, float* norm, flo
                                void* stream) {
     if (B <= 0 || M <= 0 || M > MAXM || N <= 0 || D <= 0 || (D & 3) || max_len <= 0) return -1;
     hipStream_t s = (hipStream_t)stream;
+    {
+        // short dialogues: one workgroup per (dialogue, modality), one launch + the cross diagonals (adjacency_small.hip)
+        const int rc = mmdfn_launch_adj_small_fwd(feats, unit, norm, cosg, cdot, rdeg, tiles, cross, dia_len, row_start,
+                                                  tile_base, B, M, N, D, max_len, modal_weight, s);
+        if (rc != -2) return rc;
+    }
 #define UNIT_CROSS(KERN) hipLaunchKernelGGL(KERN, dim3((N + 3) / 4), dim3(256), 0, s, feats, unit, norm, cdot, cross, rdeg, M, N, D, modal_weight)
     if (M <= 3 && D <= 256) UNIT_CROSS((unit_cross_reg_kernel<3, 4>));
     else if (M <= 6 && D <= 256) UNIT_CROSS((unit_cross_reg_kernel<6, 4>));
@@ -315,10 +321,14 @@ extern "C" int mmdfn_adj_build_bwd(const float* dtiles, const float* dcross, con
                                    float* dunit, float* dfeats, const float* addend, const int32_t* dia_len,
                                    const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int D,
                                    int max_len, float modal_weight, void* stream) {
-    (void)tiles;
-    (void)cross;
     if (B <= 0 || M <= 0 || M > MAXM || N <= 0 || D <= 0 || (D & 3) || max_len <= 0) return -1;
     hipStream_t s = (hipStream_t)stream;
+    {
+        // (the form the forward pass of these tensors took: the choice depends on the shape only)
+        const int rc = mmdfn_launch_adj_small_bwd(dtiles, dcross, unit, norm, cosg, cdot, rdeg, tiles, cross, addend, dfeats,
+                                                  dia_len, row_start, tile_base, B, M, N, D, max_len, modal_weight, s);
+        if (rc != -2) return rc;
+    }
     const int nb = (max_len + 31) / 32;
     const int rowblocks = (max_len + 3) / 4;
     hipLaunchKernelGGL(symmetrize_kernel, dim3(B * nb * nb, M), dim3(256), 0, s, dtiles, wsym, dia_len, tile_base, nb);

@@ -58,6 +58,17 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
                            const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
                            int B, int M, int N, int d, int ldh, int ldo, int max_len, int transpose, hipStream_t s);
 
+// one-workgroup-per-(dialogue, modality) form of the adjacency build for short dialogues (adjacency_small.hip); -2 = not covered
+int mmdfn_launch_adj_small_fwd(const float* feats, float* unit, float* norm, float* cosg, float* cdot, float* rdeg,
+                               float* tiles, float* cross, const int32_t* dia_len, const int32_t* row_start,
+                               const int64_t* tile_base, int B, int M, int N, int D, int max_len, float modal_weight,
+                               hipStream_t s);
+int mmdfn_launch_adj_small_bwd(const float* dtiles, const float* dcross, const float* unit, const float* norm,
+                               const float* cosg, const float* cdot, const float* rdeg, const float* tiles,
+                               const float* cross, const float* addend, float* dfeats, const int32_t* dia_len,
+                               const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int D, int max_len,
+                               float modal_weight, hipStream_t s);
+
 // bf16-piece variant of the forward product for large launches (propagate_split.hip); -2 = shape not covered
 int mmdfn_launch_propagate_split(const float* tiles, const float* cross, const float* H, float* out,
                                  const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,
