@@ -39,39 +39,20 @@ constexpr int KS_SE = 132;                  // row stride (floats) of the strips
 #define KS_STOP(K) do { } while (0)
 #endif
 
-// Reductions on the DPP path (hipcc turns __shfl_xor into ds_bpermute_b32: an LDS round trip per step, and a workgroup
-// here is one serial chain).  After the two quad steps every quad holds its sum in all four lanes, so the mirror steps are
-// exchanges between equal halves: all 16 lanes of a row end with the same bits.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float sum16(float v) {
-    v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);         // row_half_mirror
-    v += dpp_mov<0x140>(v);         // row_mirror
-    return v;
-}
-__device__ __forceinline__ float lane_value(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-// sum over the 32 lanes of each half of the wave (lanes 0-31 get the lower half's sum, 32-63 the upper's)
-__device__ __forceinline__ float sum32(float v) {
-    v = sum16(v);
-    const float lo = lane_value(v, 0) + lane_value(v, 16);
-    const float hi = lane_value(v, 32) + lane_value(v, 48);
-    return (threadIdx.x & 32) ? hi : lo;
-}
-__device__ __forceinline__ float sum64(float v) {
-    v = sum16(v);
-    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
-}
+__device__ __forceinline__ float sum16(float v) { return row_sum16(v); }        // (DPP reductions: mmdfn_internal.h)
+__device__ __forceinline__ float sum32(float v) { return half_sum32(v); }
+__device__ __forceinline__ float sum64(float v) { return wave_sum(v); }
 // x / d with 1 / d at hand: quotient estimate + one residual correction (the core of the division expansion without its
 // range scaling: operands here are feature values and their norm)
 __device__ __forceinline__ float div_by(float x, float d, float inv) {
     const float q = x * inv;
     return fmaf(fmaf(-q, d, x), inv, q);
+}
+// d sim / d c = a / (pi sqrt(1 - (a c)^2)) on the hardware reciprocal square root (1 ulp; mmdfn_dsim's correctly rounded
+// sqrt + division are ~60 instructions per element of a workgroup that is one serial chain)
+__device__ __forceinline__ float ks_dsim(float c) {
+    const float ac = c * MMDFN_COS_SHRINK;
+    return (MMDFN_COS_SHRINK / MMDFN_PI_F) * __builtin_amdgcn_rsqf(1.0f - ac * ac);
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
 
@@ -103,6 +84,7 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_fwd_kernel(
     const int L = dia_len[i];
     const int r0 = st * SR;
     if (r0 >= L) return;
+    KS_STOP(9);
     const int ld = (L + 3) & ~3;
     const int Lp = (L + 15) & ~15;
     const int nt = Lp >> 4;
@@ -126,32 +108,40 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_fwd_kernel(
 
     // ---- every load of the stage first: this modality's rows of the whole dialogue (a 16-lane group owns a row, lane j
     // holds elements 64 s + 4 j .. + 3), the other modalities' rows of the strip
+    // (one lane-masked region per 64-wide k slice; rows past the dialogue are clamped and zeroed / skipped where they are used)
     float4 xm[4][4];
+    float4 xo[RI][2][4];
+    {
+        const float* fm = feats + ((int64_t)m * N + rs) * D;
+        const float* f0 = feats + ((int64_t)(o0 >= 0 ? o0 : m) * N + rs) * D;
+        const float* f1 = feats + ((int64_t)(o1 >= 0 ? o1 : m) * N + rs) * D;
+        unsigned offm[4], offo[RI];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int p = 32 * it + 4 * w + g;
-        const int64_t grow = rs + (p < L ? p : L - 1);
+        for (int it = 0; it < 4; ++it) {
+            const int p = 32 * it + 4 * w + g;
+            offm[it] = (unsigned)(p < L ? p : L - 1) * (unsigned)D + 4 * fi;
+        }
+#pragma unroll
+        for (int j = 0; j < RI; ++j) {
+            const int p = r0 + 32 * j + 4 * w + g;
+            offo[j] = (unsigned)(p < L ? p : L - 1) * (unsigned)D + 4 * fi;
+        }
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
-            const int k = 64 * sidx + 4 * fi;
-            xm[it][sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (32 * it < Lp && k < D) xm[it][sidx] = *reinterpret_cast<const float4*>(feats + ((int64_t)m * N + grow) * D + k);
-        }
-    }
-    float4 xo[RI][2][4];
 #pragma unroll
-    for (int j = 0; j < RI; ++j) {
-        const int p = r0 + 32 * j + 4 * w + g;
-        const int64_t grow = rs + (p < L ? p : L - 1);
+            for (int it = 0; it < 4; ++it) xm[it][sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int oi = 0; oi < 2; ++oi) {
-            const int o = oi == 0 ? o0 : o1;
+            for (int j = 0; j < RI; ++j) { xo[j][0][sidx] = make_float4(0.f, 0.f, 0.f, 0.f); xo[j][1][sidx] = xo[j][0][sidx]; }
+            if (64 * sidx + 4 * fi < D) {
 #pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                const int k = 64 * sidx + 4 * fi;
-                xo[j][oi][sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (o >= 0 && r0 + 32 * j < Lp && k < D)
-                    xo[j][oi][sidx] = *reinterpret_cast<const float4*>(feats + ((int64_t)o * N + grow) * D + k);
+                for (int it = 0; it < 4; ++it)
+                    if (32 * it < Lp) xm[it][sidx] = *reinterpret_cast<const float4*>(fm + offm[it] + 64 * sidx);
+#pragma unroll
+                for (int j = 0; j < RI; ++j) {
+                    if (r0 + 32 * j >= Lp) continue;
+                    if (o0 >= 0) xo[j][0][sidx] = *reinterpret_cast<const float4*>(f0 + offo[j] + 64 * sidx);
+                    if (o1 >= 0) xo[j][1][sidx] = *reinterpret_cast<const float4*>(f1 + offo[j] + 64 * sidx);
+                }
             }
         }
     }
@@ -363,6 +353,7 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
     const int L = dia_len[i];
     const int r0 = st * SR;
     if (r0 >= L) return;
+    KS_STOP(9);
     const int ld = (L + 3) & ~3;
     const int Lp = (L + 15) & ~15;
     const int nt = Lp >> 4;
@@ -386,15 +377,24 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
 
     // ---- requested now, used last: the B fragments of d(unit) = E . U for this wave's column tiles (ct = w, w + 8).
     // MFMA step j of the 16-wide k group kc contracts q = 16 kc + 4 g + j (the A side reads E[row][16 kc + 4 g .. + 3]).
+    // Rows q >= L and columns >= D are clamped, not masked: they meet E columns that are zero / feed outputs nobody stores.
     float bfr[2][32];
+    {
+        const float* um = unit + ((int64_t)m * N + rs) * D;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int col = 16 * (w + KS_NW * h) + fi;
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
-            const int q = 16 * (kk >> 2) + 4 * g + (kk & 3);
-            bfr[h][kk] = 0.f;
-            if (w + KS_NW * h < nct && q < L && col < D) bfr[h][kk] = unit[((int64_t)m * N + rs + q) * D + col];
+            for (int kk = 0; kk < 32; ++kk) bfr[h][kk] = 0.f;
+            if (w + KS_NW * h >= nct) continue;
+            const int col = 16 * (w + KS_NW * h) + fi;
+            const unsigned colc = col < D ? col : D - 1;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                if (16 * (kk >> 2) >= Lp) continue;                    // (uniform)
+                const int q = 16 * (kk >> 2) + 4 * g + (kk & 3);
+                const unsigned qc = q < L ? q : L - 1;
+                bfr[h][kk] = um[qc * (unsigned)D + colc];
+            }
         }
     }
     // ---- the saved cosines of the strip (stage 3)
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int q = lane + 64 * e;
-            cg[j][e] = (p < L && q < L) ? cosg[toff_m + (int64_t)p * ld + q] : 0.f;
+            cg[j][e] = cosg[toff_m + (unsigned)((p < L ? p : L - 1) * ld + (q < L ? q : L - 1))];      // (clamped; used for p, q < L only)
         }
     }
 
@@ -422,21 +422,76 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
         }
     }
 
-    // ---- stage 1: Z = dT o T of every modality: row sums, column sums; this modality's strip rows / strip columns of dT -> LDS
+    // ---- stage 1: Z = dT o T: row sums, column sums (this modality: the whole tile; the others: what the strip's rows need);
+    // this modality's strip rows / strip columns of dT -> LDS
     {
         const int c4 = lane & 31, sub = lane >> 5;
         const int q = 4 * c4;
         for (int n = 0; n < M; ++n) {
             const int64_t toff = tile_base[i] + (int64_t)n * L * ld;
+            if (n != m) {
+                // another modality: only d(degree) of the STRIP's rows is needed (the cross diagonals): row sums of the strip's
+                // rows, column sums of the strip's columns (CQ lanes per row, RPW rows per wave and request)
+                constexpr int CQ = SR / 4, RPW = 64 / CQ, NI = KS_MAXL / (KS_NW * RPW);
+                const float* dtn = dtiles + toff;
+                const float* ttn = tiles + toff;
+                const unsigned qc = q < ld ? q : ld - 4;
+                float4 dr[RT], tr[RT], dc[NI], tc[NI];
+#pragma unroll
+                for (int j = 0; j < RT; ++j) {
+                    const int p = r0 + 16 * j + 2 * w + sub;
+                    const unsigned off = (unsigned)(p < L ? p : L - 1) * (unsigned)ld + qc;
+                    dr[j] = *reinterpret_cast<const float4*>(dtn + off);
+                    tr[j] = *reinterpret_cast<const float4*>(ttn + off);
+                }
+                const int cq = lane % CQ, rq = lane / CQ;
+                const int colq = r0 + 4 * cq;
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int p = KS_NW * RPW * it + RPW * w + rq;
+                    const unsigned off = (unsigned)(p < L ? p : L - 1) * (unsigned)ld + (unsigned)(colq < ld ? colq : ld - 4);
+                    dc[it] = *reinterpret_cast<const float4*>(dtn + off);
+                    tc[it] = *reinterpret_cast<const float4*>(ttn + off);
+                }
+#pragma unroll
+                for (int j = 0; j < RT; ++j) {
+                    const int p = r0 + 16 * j + 2 * w + sub;
+                    const bool rowin = p < L;
+                    float zs = 0.f;
+                    zs += (rowin && q + 0 < L) ? dr[j].x * tr[j].x : 0.f;
+                    zs += (rowin && q + 1 < L) ? dr[j].y * tr[j].y : 0.f;
+                    zs += (rowin && q + 2 < L) ? dr[j].z * tr[j].z : 0.f;
+                    zs += (rowin && q + 3 < L) ? dr[j].w * tr[j].w : 0.f;
+                    const float zr = sum32(zs);
+                    if (c4 == 0 && p < KS_MAXL) zrow[n * KS_MAXL + p] = zr;
+                }
+                float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    const int p = KS_NW * RPW * it + RPW * w + rq;
+                    const bool rowin = p < L;
+                    cacc.x += (rowin && colq + 0 < L) ? dc[it].x * tc[it].x : 0.f;
+                    cacc.y += (rowin && colq + 1 < L) ? dc[it].y * tc[it].y : 0.f;
+                    cacc.z += (rowin && colq + 2 < L) ? dc[it].z * tc[it].z : 0.f;
+                    cacc.w += (rowin && colq + 3 < L) ? dc[it].w * tc[it].w : 0.f;
+                }
+                // colp slot of modality n: [KS_NW * RPW partial sums][SR strip columns]
+                *reinterpret_cast<float4*>(colp + n * 16 * KS_MAXL + (RPW * w + rq) * SR + 4 * cq) = cacc;
+                continue;
+            }
             float4 dt[8], tt[8];
+            const float* dtn = dtiles + toff;
+            const float* ttn = tiles + toff;
+            const unsigned qc = q < ld ? q : ld - 4;                  // (lanes past the row: clamped, zeroed below)
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int p = 16 * it + 2 * w + sub;
                 dt[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 tt[it] = dt[it];
-                if (p < L && q < ld) {
-                    dt[it] = *reinterpret_cast<const float4*>(dtiles + toff + (int64_t)p * ld + q);
-                    tt[it] = *reinterpret_cast<const float4*>(tiles + toff + (int64_t)p * ld + q);
+                if (16 * it < L) {                                     // (uniform; rows past the tile: clamped, zeroed below)
+                    const unsigned off = (unsigned)(p < L ? p : L - 1) * (unsigned)ld + qc;
+                    dt[it] = *reinterpret_cast<const float4*>(dtn + off);
+                    tt[it] = *reinterpret_cast<const float4*>(ttn + off);
                 }
             }
             float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -445,15 +500,16 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
                 if (16 * it >= Lp) continue;
                 const int p = 16 * it + 2 * w + sub;
                 float4 d4 = dt[it];
-                if (q + 0 >= L) d4.x = 0.f;
-                if (q + 1 >= L) d4.y = 0.f;
-                if (q + 2 >= L) d4.z = 0.f;
-                if (q + 3 >= L) d4.w = 0.f;
+                const bool rowin = p < L;
+                d4.x = (rowin && q + 0 < L) ? d4.x : 0.f;
+                d4.y = (rowin && q + 1 < L) ? d4.y : 0.f;
+                d4.z = (rowin && q + 2 < L) ? d4.z : 0.f;
+                d4.w = (rowin && q + 3 < L) ? d4.w : 0.f;
                 const float4 z = make_float4(d4.x * tt[it].x, d4.y * tt[it].y, d4.z * tt[it].z, d4.w * tt[it].w);
                 const float zr = sum32((z.x + z.y) + (z.z + z.w));
                 if (c4 == 0) zrow[n * KS_MAXL + p] = zr;
                 cacc.x += z.x; cacc.y += z.y; cacc.z += z.z; cacc.w += z.w;
-                if (n == m) {
+                {
                     const int pl = p - r0;
                     if (pl >= 0 && pl < SR) *reinterpret_cast<float4*>(Rw + pl * KS_SE + q) = d4;
                     const int cl = q - r0;                       // (r0, q multiples of 4: the four columns are in or out together)
@@ -475,10 +531,16 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
     for (int e = tid; e < M * KS_MAXL; e += 64 * KS_NW) {
         const int n = e >> 7, p = e & 127;
         if (p >= L) continue;
+        if (n != m && (p < r0 || p >= r0 + SR)) continue;       // (other modalities: the strip's rows only)
         const int64_t grow = rs + p;
         float zz = zrow[n * KS_MAXL + p];
         float zc = 0.f;
-        for (int ww = 0; ww < 2 * KS_NW; ++ww) zc += colp[(n * 16 + ww) * KS_MAXL + p];
+        if (n == m) {
+            for (int ww = 0; ww < 2 * KS_NW; ++ww) zc += colp[(n * 16 + ww) * KS_MAXL + p];
+        } else {
+            constexpr int NP = KS_NW * (64 / (SR / 4));
+            for (int ww = 0; ww < NP; ++ww) zc += colp[n * 16 * KS_MAXL + ww * SR + (p - r0)];
+        }
         zz += zc;
         for (int k = 0; k < M; ++k) {
             if (k == n) continue;
@@ -507,14 +569,14 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
                 const int q = lane + 64 * e;
                 if (q >= L) continue;
                 const float wv = Rw[pl * KS_SE + q] + Ct[pl * KS_SE + q];
-                Rw[pl * KS_SE + q] = (wv * rp * rm[q] + ddp + dm[q]) * mmdfn_dsim(cg[j][e]);
+                Rw[pl * KS_SE + q] = (wv * rp * rm[q] + ddp + dm[q]) * ks_dsim(cg[j][e]);
             }
         }
         {
             const int n = tid / SR, pl = tid - n * SR;       // (3 SR <= 512 threads)
             const int p = r0 + pl;
             if (n < M && n != m && p < L)
-                ec[n * SR + pl] = (pre_dc * rm[p] * rl[n * KS_MAXL + p] + dm[p] + dd[n * KS_MAXL + p]) * modal_weight * mmdfn_dsim(pre_cd);
+                ec[n * SR + pl] = (pre_dc * rm[p] * rl[n * KS_MAXL + p] + dm[p] + dd[n * KS_MAXL + p]) * modal_weight * ks_dsim(pre_cd);
         }
     }
     // ---- requested now, used after the MFMAs: the unit rows / addend rows of the epilogue (lane = four columns)
@@ -524,42 +586,59 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
     float4 eu[RJ], e0[RJ], e1[RJ], ea[RJ];
     float einv[RJ];
     const int k4 = 4 * lane;
+    {
+        // (rows / columns past the end are clamped, not masked: their results are not stored; absent operands read `unit`
+        // and are not used -- every request stays a plain global load)
+        const unsigned kc4 = k4 < D ? k4 : D - 4;
+        const float* pu = unit + ((int64_t)m * N + rs) * D;
+        const float* p0 = unit + ((int64_t)(o0 >= 0 ? o0 : m) * N + rs) * D;
+        const float* p1 = unit + ((int64_t)(o1 >= 0 ? o1 : m) * N + rs) * D;
+        const float* pa = addend ? addend + ((int64_t)m * N + rs) * D : pu;
+        const float* pn = norm + (int64_t)m * N + rs;
 #pragma unroll
-    for (int j = 0; j < RJ; ++j) {
-        const int p = r0 + w + KS_NW * j;
-        const bool ok = p < L && k4 < D;
-        const int64_t grow = rs + (p < L ? p : 0);
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        eu[j] = ok ? *reinterpret_cast<const float4*>(unit + ((int64_t)m * N + grow) * D + k4) : z4;
-        e0[j] = (ok && o0 >= 0) ? *reinterpret_cast<const float4*>(unit + ((int64_t)o0 * N + grow) * D + k4) : z4;
-        e1[j] = (ok && o1 >= 0) ? *reinterpret_cast<const float4*>(unit + ((int64_t)o1 * N + grow) * D + k4) : z4;
-        ea[j] = (ok && addend) ? *reinterpret_cast<const float4*>(addend + ((int64_t)m * N + grow) * D + k4) : z4;
-        einv[j] = norm[(int64_t)m * N + grow];               // (||x||: the division waits for the load, so it is done in the epilogue)
+        for (int j = 0; j < RJ; ++j) {
+            const int p = r0 + w + KS_NW * j;
+            const unsigned off = (unsigned)(p < L ? p : L - 1) * (unsigned)D + kc4;
+            eu[j] = *reinterpret_cast<const float4*>(pu + off);
+            e0[j] = *reinterpret_cast<const float4*>(p0 + off);
+            e1[j] = *reinterpret_cast<const float4*>(p1 + off);
+            ea[j] = *reinterpret_cast<const float4*>(pa + off);
+            einv[j] = pn[p < L ? p : L - 1];                 // (||x||: the division waits for the load, so it is done in the epilogue)
+        }
     }
     __syncthreads();
     KS_STOP(3);
 
     // ---- stage 4: d(unit) strip = E strip . U on exact-f32 MFMAs -> LDS
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int ct = w + KS_NW * h;
-        if (ct >= nct) continue;
+    // per row tile: all eight A fragments are read first (columns past the tile hold zeros), then the two column tiles'
+    // accumulator chains run interleaved
+    if (w < nct) {
+        const bool two = w + KS_NW < nct;
 #pragma unroll
         for (int a = 0; a < RT; ++a) {
             if (r0 + 16 * a >= Lp) continue;
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float* ea_ = Rw + (16 * a + fi) * KS_SE + 4 * g;
+            float4 av[8];
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) av[kc] = *reinterpret_cast<const float4*>(ea_ + 16 * kc);
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 if (kc >= nt) continue;
-                const float4 av = *reinterpret_cast<const float4*>(ea_ + 16 * kc);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bfr[h][4 * kc + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bfr[h][4 * kc + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bfr[h][4 * kc + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bfr[h][4 * kc + 3], acc, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].x, bfr[0][4 * kc + 0], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].x, bfr[1][4 * kc + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].y, bfr[0][4 * kc + 1], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].y, bfr[1][4 * kc + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].z, bfr[0][4 * kc + 2], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].z, bfr[1][4 * kc + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].w, bfr[0][4 * kc + 3], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc].w, bfr[1][4 * kc + 3], acc1, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dUl[(16 * a + 4 * g + r) * SD + 16 * ct + fi] = acc[r];
+            for (int r = 0; r < 4; ++r) {
+                dUl[(16 * a + 4 * g + r) * SD + 16 * w + fi] = acc0[r];
+                if (two) dUl[(16 * a + 4 * g + r) * SD + 16 * (w + KS_NW) + fi] = acc1[r];
+            }
         }
     }
     __syncthreads();
@@ -573,16 +652,18 @@ __global__ __launch_bounds__(64 * KS_NW) void adj_strip_bwd_kernel(
         if (p >= L) continue;
         const bool ok = k4 < D;
         float4 du = ok ? *reinterpret_cast<const float4*>(dUl + pl * SD + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 uu = ok ? eu[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ad = addend ? ea[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (o0 >= 0) { const float c = ec[o0 * SR + pl]; du.x += c * e0[j].x; du.y += c * e0[j].y; du.z += c * e0[j].z; du.w += c * e0[j].w; }
         if (o1 >= 0) { const float c = ec[o1 * SR + pl]; du.x += c * e1[j].x; du.y += c * e1[j].y; du.z += c * e1[j].z; du.w += c * e1[j].w; }
-        const float s = sum64(dot4(eu[j], du));
+        const float s = sum64(dot4(uu, du));
         if (ok) {
             const float inv = 1.0f / einv[j];
             float4 v;
-            v.x = (du.x - eu[j].x * s) * inv + ea[j].x;
-            v.y = (du.y - eu[j].y * s) * inv + ea[j].y;
-            v.z = (du.z - eu[j].z * s) * inv + ea[j].z;
-            v.w = (du.w - eu[j].w * s) * inv + ea[j].w;
+            v.x = (du.x - uu.x * s) * inv + ad.x;
+            v.y = (du.y - uu.y * s) * inv + ad.y;
+            v.z = (du.z - uu.z * s) * inv + ad.z;
+            v.w = (du.w - uu.w * s) * inv + ad.w;
             *reinterpret_cast<float4*>(dfeats + ((int64_t)m * N + rs + p) * D + k4) = v;
         }
     }

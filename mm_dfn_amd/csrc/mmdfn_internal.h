@@ -29,10 +29,35 @@ __host__ __device__ __forceinline__ int mmdfn_pair_index(int m, int n, int M) {
     return m * (2 * M - m - 1) / 2 + (n - m - 1);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Reductions on the DPP path (hipcc turns __shfl_xor into ds_bpermute_b32: an LDS round trip per step).  After the two quad
+// steps every quad holds its sum in all four lanes, so the mirror steps are exchanges between equal halves: all 16 lanes of a
+// row end with the same bits.
+template <int CTRL>
+__device__ __forceinline__ float mmdfn_dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over each row of 16 lanes (every lane of the row gets it)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += mmdfn_dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += mmdfn_dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += mmdfn_dpp_mov<0x141>(v);         // row_half_mirror
+    v += mmdfn_dpp_mov<0x140>(v);         // row_mirror
     return v;
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// sum over the whole wave (every lane gets it): four row sums met through scalar registers in a fixed order
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row_sum16(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+// sum over the 32 lanes of each half of the wave (lanes 0-31 get the lower half's sum, 32-63 the upper's)
+__device__ __forceinline__ float half_sum32(float v) {
+    v = row_sum16(v);
+    const float lo = lane_value(v, 0) + lane_value(v, 16);
+    const float hi = lane_value(v, 32) + lane_value(v, 48);
+    return (threadIdx.x & 32) ? hi : lo;
 }
 
 // more than 64 KB of dynamic LDS per workgroup needs the attribute raised once per kernel (gfx950: 160 KB per CU)

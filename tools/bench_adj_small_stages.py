@@ -1,6 +1,6 @@
 """Where the time of the K5s strip kernels goes: the tuning build's early-return switch MMDFN_ADJ_STOP=k (timing only; results are
 incomplete) on the cfg2 shape.  Forward k: 1 unit rows in LDS, 2 + cross-modal part, 3 + Gram / similarity / partial sums, 0 all.
-Backward k: 1 Z sums + strip capture, 2 + d(degree), 3 + E strip, 4 + MFMAs, 0 all."""
+k = 9: nothing but the launch and the block decode.  Backward k: 1 Z sums + strip capture, 2 + d(degree), 3 + E strip, 4 + MFMAs, 0 all."""
 import os, sys
 os.environ["MMDFN_TUNING_LIB"] = "1"
 import torch
@@ -21,7 +21,7 @@ for sr in os.environ.get("ADJ_SRS", "32,64").split(","):
     os.environ["MMDFN_ADJ_SR"] = sr
     for rep in range(2):
         out = []
-        for stop in (1, 2, 3, 0):
+        for stop in (9, 1, 2, 3, 0):
             os.environ["MMDFN_ADJ_STOP"] = str(stop)
             out.append("%d: %5.1f" % (stop, timed(lambda k=0: run_fwd(bufs[k], lay, M, N, D))))
         print("SR %s forward  (incl. finish launch) stop-> us  " % sr + "   ".join(out), flush=True)
@@ -29,7 +29,7 @@ for sr in os.environ.get("ADJ_SRS", "32,64").split(","):
         for k in range(NSET):
             run_fwd(bufs[k], lay, M, N, D)
         out = []
-        for stop in (1, 2, 3, 4, 0):
+        for stop in (9, 1, 2, 3, 4, 0):
             os.environ["MMDFN_ADJ_STOP"] = str(stop)
             out.append("%d: %5.1f" % (stop, timed(lambda k=0: run_bwd(bufs[k], lay, M, N, D))))
         print("SR %s backward stop-> us  " % sr + "   ".join(out), flush=True)
