@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 15: 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 16: 15 + mmdfn_linear_planes_group; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -278,12 +278,19 @@ int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const
  * mmdfn_linear_planes:  Y = act(X B^T + bias) (+ Y);  X: R rows of K floats (row stride ldx, 16-byte aligned rows, K % 4 == 0),
  *   bias / bias2 split at n1 as in mmdfn_linear2 (either may be null), Y: R x N (row stride ldy), act: 0 identity, 1 ReLU.
  *   Arithmetic: six bf16 piece products per MAC, fp32 accumulation -- fp32-level error, as mmdfn_linear's many-row form.
+ * mmdfn_linear_planes_group (ABI 16): n <= 4 such products in ONE launch (problem i: X[i], planes[i], ... as above; bias / bias2
+ *   may be null arrays; R[i] == 0 skips a problem) -- the hoisted input contractions of the context and the party GRU of one
+ *   layer (model.py:866-868, 1082, 1132) and their input gradients, which do not depend on each other.  Every problem keeps the
+ *   tile form it takes alone, so its results are the bits of its own mmdfn_linear_planes launch.
  * ------------------------------------------------------------------------- */
 int64_t mmdfn_weight_planes_workspace(int N, int K);
 int mmdfn_cut_weight_planes(int n, const float* const* w1, const float* const* w2, const int* n1, const int* ld,
                             const int* N, const int* K, const int* mode, void* const* planes, void* stream);
 int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, const float* bias2, int n1, float* Y, int R,
                         int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
+int mmdfn_linear_planes_group(int n, const float* const* X, const void* const* planes, const float* const* bias,
+                              const float* const* bias2, const int* n1, float* const* Y, const int* R, const int* K,
+                              const int* N, const int* ldx, const int* ldy, int act, int accumulate, void* stream);
 
 /* A GROUP of few-row projections in one launch (linear_small.hip; n <= 8 problems, K <= 768, K % 4 == 0):
  *   Y_p = act(X_p W_p^T + b_p) (+ Y_p)      X_p: R_p rows of K_p floats (stride ldx), Y_p: R_p x N_p (stride ldy)

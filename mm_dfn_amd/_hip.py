@@ -48,6 +48,7 @@ SIGNATURES = {
     "mmdfn_weight_planes_workspace": [_I, _I],
     "mmdfn_cut_weight_planes": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_linear_planes": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mmdfn_linear_planes_group": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "mmdfn_linear_group_supported": [_I, _I, _I],
     "mmdfn_linear_group": [_I] + [_P] * 15 + [_I, _P],
     "mmdfn_linear_group_addend": [_I] + [_P] * 17 + [_I, _P],
@@ -88,7 +89,7 @@ SIGNATURES = {
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class HipLibraryError(RuntimeError):

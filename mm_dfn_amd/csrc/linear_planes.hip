@@ -104,16 +104,16 @@ __global__ __launch_bounds__(256) void cut_planes_kernel(CutTable T) {
 // RH = row halves per wave: 2 -> wave = 64 rows x one 32-column tile, workgroup = 64 x 128 (many column tiles: the forward
 // products, N = 600); 1 -> wave = 32 rows x one tile, workgroup = 64 x 64 (few column tiles: the input gradients, N = 200 --
 // twice the workgroups, half the MFMA chain per wave).  A = the X rows: every wave cuts ONE (row half, k-step) task per phase.
+// one workgroup's share of Y = act(X B^T + bias) (+ Y); `bid`: the workgroup's number inside ITS problem's block range
 template <int RH>
-__global__ __launch_bounds__(256, 4) void linear_planes_kernel(
-    const float* __restrict__ X, const u32x4* __restrict__ planes, const float* __restrict__ bias,
+__device__ __forceinline__ void linear_planes_body(
+    u32x4* As, const float* __restrict__ X, const u32x4* __restrict__ planes, const float* __restrict__ bias,
     const float* __restrict__ bias2, int n1, float* __restrict__ Y, int R, int K, int N, int ldx, int ldy, int act,
-    int accumulate, int nrb, int ncb) {
-    __shared__ u32x4 As[PL_LDS];
+    int accumulate, int nrb, int ncb, int bid) {
     constexpr int TPW = 4 / (3 - RH);                   // column tiles per workgroup: RH = 2 -> 4, RH = 1 -> 2
     constexpr int NACC = (RH == 2) ? 1 : 2;
     int rb, cb;
-    if (!pl_decode(nrb, ncb, rb, cb)) return;
+    if (!pl_decode(nrb, ncb, rb, cb, bid)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
@@ -186,6 +186,52 @@ __global__ __launch_bounds__(256, 4) void linear_planes_kernel(
         }
 }
 
+template <int RH>
+__global__ __launch_bounds__(256, 4) void linear_planes_kernel(
+    const float* __restrict__ X, const u32x4* __restrict__ planes, const float* __restrict__ bias,
+    const float* __restrict__ bias2, int n1, float* __restrict__ Y, int R, int K, int N, int ldx, int ldy, int act,
+    int accumulate, int nrb, int ncb) {
+    __shared__ u32x4 As[PL_LDS];
+    linear_planes_body<RH>(As, X, planes, bias, bias2, n1, Y, R, K, N, ldx, ldy, act, accumulate, nrb, ncb, (int)blockIdx.x);
+}
+
+// Several independent projections in ONE launch (the context and the party encoder's input contractions of a GRU layer, their
+// input gradients): problem p owns the blocks [blk0[p], blk0[p + 1]) and keeps the tile form it would take alone.
+constexpr int PL_MAXG = 4;
+struct PlGroup {
+    const float* X[PL_MAXG];
+    const u32x4* planes[PL_MAXG];
+    const float* bias[PL_MAXG];
+    const float* bias2[PL_MAXG];
+    float* Y[PL_MAXG];
+    int n1[PL_MAXG], R[PL_MAXG], K[PL_MAXG], N[PL_MAXG], ldx[PL_MAXG], ldy[PL_MAXG], nrb[PL_MAXG], ncb[PL_MAXG], rh[PL_MAXG];
+    int blk0[PL_MAXG + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256, 4) void linear_planes_group_kernel(PlGroup G, int act, int accumulate) {
+    __shared__ u32x4 As[PL_LDS];
+    int p = 0;
+    while (p + 1 < G.n && (int)blockIdx.x >= G.blk0[p + 1]) ++p;
+    const int bid = (int)blockIdx.x - G.blk0[p];
+    if (G.rh[p] == 2)
+        linear_planes_body<2>(As, G.X[p], G.planes[p], G.bias[p], G.bias2[p], G.n1[p], G.Y[p], G.R[p], G.K[p], G.N[p], G.ldx[p],
+                              G.ldy[p], act, accumulate, G.nrb[p], G.ncb[p], bid);
+    else
+        linear_planes_body<1>(As, G.X[p], G.planes[p], G.bias[p], G.bias2[p], G.n1[p], G.Y[p], G.R[p], G.K[p], G.N[p], G.ldx[p],
+                              G.ldy[p], act, accumulate, G.nrb[p], G.ncb[p], bid);
+}
+
+// tile form of one problem: few column tiles (an input gradient, N = 200) or few rows -> 64 x 64 workgroups, so that the launch
+// has workgroups for every CU
+inline void pl_form(int R, int N, int* nrb, int* ncb, int* rh) {
+    *nrb = (R + PL_BM - 1) / PL_BM;
+    const int NT = (N + 31) / 32;
+    const bool narrow = (int64_t)*nrb * ((NT + 3) / 4) < 400;
+    *ncb = narrow ? (NT + 1) / 2 : (NT + 3) / 4;
+    *rh = narrow ? 1 : 2;
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,11 +279,9 @@ int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, c
     if (R <= 0) return 0;
     if (!X || !planes || !Y || K < 4 || (K & 3) || N <= 0 || (ldx & 3) || ldx < K || ldy < N) return -1;
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return -1;
-    const int nrb = (R + PL_BM - 1) / PL_BM;
-    const int NT = (N + 31) / 32;
-    // few column tiles (an input gradient, N = 200) or few rows: 64 x 64 workgroups, so that the launch has workgroups for every CU
-    const bool narrow = (int64_t)nrb * ((NT + 3) / 4) < 400;
-    const int ncb = narrow ? (NT + 1) / 2 : (NT + 3) / 4;
+    int nrb, ncb, rh;
+    pl_form(R, N, &nrb, &ncb, &rh);
+    const bool narrow = rh == 1;
     const int64_t grid = pl_grid(nrb, ncb);
     if (grid > (1ll << 30)) return -1;
     if (narrow)
@@ -246,6 +290,42 @@ int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, c
     else
         hipLaunchKernelGGL(linear_planes_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, X,
                            reinterpret_cast<const u32x4*>(planes), bias, bias2, n1, Y, R, K, N, ldx, ldy, act, accumulate, nrb, ncb);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmdfn_linear_planes_group(int n, const float* const* X, const void* const* planes, const float* const* bias,
+                              const float* const* bias2, const int* n1, float* const* Y, const int* R, const int* K,
+                              const int* N, const int* ldx, const int* ldy, int act, int accumulate, void* stream) {
+    if (n <= 0 || n > PL_MAXG) return -1;
+    PlGroup G;
+    G.n = 0;
+    G.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (R[i] <= 0) continue;                   // (an empty problem takes no blocks)
+        if (!X[i] || !planes[i] || !Y[i] || K[i] < 4 || (K[i] & 3) || N[i] <= 0 || (ldx[i] & 3) || ldx[i] < K[i] || ldy[i] < N[i])
+            return -1;
+        if ((reinterpret_cast<uintptr_t>(X[i]) & 15) || (reinterpret_cast<uintptr_t>(planes[i]) & 15)) return -1;
+        const int p = G.n++;
+        G.X[p] = X[i];
+        G.planes[p] = reinterpret_cast<const u32x4*>(planes[i]);
+        G.bias[p] = bias ? bias[i] : nullptr;
+        G.bias2[p] = bias2 ? bias2[i] : nullptr;
+        G.Y[p] = Y[i];
+        G.n1[p] = n1[i]; G.R[p] = R[i]; G.K[p] = K[i]; G.N[p] = N[i]; G.ldx[p] = ldx[i]; G.ldy[p] = ldy[i];
+        pl_form(R[i], N[i], &G.nrb[p], &G.ncb[p], &G.rh[p]);
+        const int64_t blocks = pl_grid(G.nrb[p], G.ncb[p]);
+        if (G.blk0[p] + blocks > (1ll << 30)) return -1;
+        G.blk0[p + 1] = G.blk0[p] + (int)blocks;
+    }
+    if (G.n == 0) return 0;
+    for (int p = G.n; p < PL_MAXG; ++p) {
+        G.X[p] = nullptr; G.planes[p] = nullptr; G.bias[p] = G.bias2[p] = nullptr; G.Y[p] = nullptr;
+        G.n1[p] = G.R[p] = G.K[p] = G.N[p] = G.ldx[p] = G.ldy[p] = G.nrb[p] = G.ncb[p] = G.rh[p] = 0;
+        G.blk0[p + 1] = G.blk0[G.n];
+    }
+    hipLaunchKernelGGL(linear_planes_group_kernel, dim3((unsigned)G.blk0[G.n]), dim3(256), 0, (hipStream_t)stream, G, act,
+                       accumulate);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -47,8 +47,7 @@ __device__ __forceinline__ void pl_cut8(const float (&x)[8], u32x4& p1, u32x4& p
 
 // workgroup decode shared by the launches: grid = 8 ceil(row blocks / 8) ncb; blockIdx % 8 (the XCD) owns the row blocks = its
 // number (mod 8) and runs the ncb column blocks of a row block back to back, so the A rows of a row block are fetched into ONE L2
-__device__ __forceinline__ bool pl_decode(int nrb, int ncb, int& rb, int& cb) {
-    const int bid = blockIdx.x;
+__device__ __forceinline__ bool pl_decode(int nrb, int ncb, int& rb, int& cb, int bid) {
     const int yq = bid >> 3;
     rb = (yq / ncb) * 8 + (bid & 7);
     cb = yq % ncb;

@@ -372,11 +372,16 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
         # hoisted input contractions (all t, both directions) of every group: one launch per group on the two
         # directions' own weight_ih / bias_ih parameters
         pre = gi0 if (layer == 0 and gi0 is not None) else [None] * len(grus)
-        gis = [pre[g] if pre[g] is not None else
-               ops.linear2(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1],
-                           None if wcat is None else wcat[layer * len(grus) + g],
-                           None if bcat is None else bcat[layer * len(grus) + g])
-               for g in range(len(grus))]
+        todo = [g for g in range(len(grus)) if pre[g] is None]
+        gis = list(pre)
+        # the groups' contractions do not depend on each other: ONE launch against the weights' piece planes when there are
+        # several (the context and the party encoder's second layer: 1 760 + 7 040 rows at cfg2), each way
+        joint = ops.linear2_group([(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1]) for g in todo]) \
+            if len(todo) >= 2 else None
+        for k, g in enumerate(todo):
+            gis[g] = joint[k] if joint is not None else ops.linear2(
+                cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1],
+                None if wcat is None else wcat[layer * len(grus) + g], None if bcat is None else bcat[layer * len(grus) + g])
         args = []
         for gi, p in zip(gis, prm):
             args += [gi] + p[2]

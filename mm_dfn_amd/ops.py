@@ -29,7 +29,7 @@ from .ops_linear import (  # noqa: F401
     _Linear, _MatmulKN, _linear_forward, _linear_dx, _LinearGroup, linear_group, _GateLinear, gate_linear, _Linear2,
     PLANES_MIN_ROWS, _PLANES, _PLANE_EPOCH, _PLANE_RECORDERS, _PlaneEntry, _plane_stamp, _plane_params, _plane_fresh,
     _cut_planes, planes_supported, weight_planes, refresh_planes, invalidate_planes, planes_recording,
-    linear_planes_raw, LINEAR2_FEW_ROWS, GROUP_ROWS, linear2, matmul_kn, linear,
+    linear_planes_raw, linear_planes_group_raw, linear2_group, LINEAR2_FEW_ROWS, GROUP_ROWS, linear2, matmul_kn, linear,
 )
 from .ops_party import (  # noqa: F401
     _PartyGather, party_gather, _HalvesGrad, _queue_bias_halves, _ProjectGather, project_gather, _PartyCombine,

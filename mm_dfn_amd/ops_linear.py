@@ -554,6 +554,105 @@ def linear_planes_raw(x2, w1, w2=None, b1=None, b2=None, transposed=False, act=0
     return out
 
 
+def linear_planes_group_raw(problems, transposed=False, act=0):
+    """Up to four independent products x2 B^T + [b1; b2] against piece planes in ONE launch (mmdfn_linear_planes_group).
+    problems: dicts with x (2-D), w1, w2 and optionally b1, b2, out; returns the outputs.  Every problem's result is
+    bit-identical to its own linear_planes_raw launch (it keeps the tile form it takes alone)."""
+    lib = _hip.lib()
+    xs, ents, outs = [], [], []
+    for pr in problems:
+        x2 = pr["x"]
+        _hip.require_cuda(x2, pr["w1"])
+        _hip.require_f32(x2, pr["w1"], pr.get("w2"), pr.get("b1"), pr.get("b2"), pr.get("out"))
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        e = weight_planes(pr["w1"], pr.get("w2"), transposed)
+        if x2.shape[1] != e.K:
+            raise ValueError("linear_planes_group_raw: contraction width %d, planes were cut for %d" % (x2.shape[1], e.K))
+        out = pr.get("out")
+        if out is None:
+            out = torch.empty(x2.shape[0], e.N, dtype=torch.float32, device=x2.device)
+        xs.append(x2)
+        ents.append(e)
+        outs.append(out)
+    for i in range(0, len(problems), 4):
+        sl = slice(i, i + 4)
+        prs, x4, e4, o4 = problems[sl], xs[sl], ents[sl], outs[sl]
+        n1 = [e.N if (transposed or pr.get("w2") is None) else e.n1 for pr, e in zip(prs, e4)]
+        rc = lib.mmdfn_linear_planes_group(len(prs), _hip.ptr_array(x4), _hip.ptr_array([e.buf for e in e4]),
+                                           _hip.ptr_array([pr.get("b1") for pr in prs]), _hip.ptr_array([pr.get("b2") for pr in prs]),
+                                           _hip.int_array(n1), _hip.ptr_array(o4), _hip.int_array([x.shape[0] for x in x4]),
+                                           _hip.int_array([e.K for e in e4]), _hip.int_array([e.N for e in e4]),
+                                           _hip.int_array([x.stride(0) for x in x4]), _hip.int_array([o.stride(0) for o in o4]),
+                                           int(act), 0, _hip.stream())
+        _hip.check(rc, "mmdfn_linear_planes_group")
+    return outs
+
+
+class _Linear2Group(torch.autograd.Function):
+    """G projections y_g = x_g [W1_g; W2_g]^T + [b1_g; b2_g] that do not depend on each other (the context and the party GRU's
+    hoisted input contractions of one layer) as ONE node: one grouped launch against the weights' piece planes forward, one for
+    the input gradients; weight / bias gradients per group as in _Linear2.  args: (x, w1, w2, b1, b2) per group."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        grp = [args[5 * g:5 * g + 5] for g in range(n)]
+        shapes, x2s = [], []
+        for x, w1, w2, b1, b2 in grp:
+            shapes.append(x.shape)
+            x2 = x.reshape(-1, x.shape[-1])
+            if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+                x2 = x2.contiguous()
+            x2s.append(x2)
+        ys = linear_planes_group_raw([dict(x=x2, w1=w1, w2=w2, b1=b1, b2=b2) for x2, (_, w1, w2, b1, b2) in zip(x2s, grp)])
+        ctx.n = n
+        ctx.refs = [(w1, w2, b1, b2) for _, w1, w2, b1, b2 in grp]
+        ctx.save_for_backward(*x2s)
+        return tuple(y.view(*shp[:-1], y.shape[1]) for y, shp in zip(ys, shapes))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2s = ctx.saved_tensors
+        n = ctx.n
+        dy2s = []
+        for g in range(n):
+            dy = dys[g]
+            if dy is None:
+                N = ctx.refs[g][0].shape[0] + ctx.refs[g][1].shape[0]
+                dy = torch.zeros(x2s[g].shape[0], N, dtype=torch.float32, device=x2s[g].device)
+            dy2s.append(dy.reshape(-1, dy.shape[-1]).contiguous())
+        need = [g for g in range(n) if ctx.needs_input_grad[1 + 5 * g]]
+        dxs = [None] * n
+        if need:
+            got = linear_planes_group_raw([dict(x=dy2s[g], w1=ctx.refs[g][0], w2=ctx.refs[g][1]) for g in need], transposed=True)
+            for g, dx in zip(need, got):
+                dxs[g] = dx
+        out = [None]
+        for g in range(n):
+            p1, p2, b1, b2 = ctx.refs[g]
+            n1 = p1.shape[0]
+            d1, d2 = dy2s[g][:, :n1], dy2s[g][:, n1:]
+            dw1, db1 = _wgrad(d1, x2s[g], p1, b1)
+            dw2, db2 = _wgrad(d2, x2s[g], p2, b2)
+            dx = dxs[g]
+            if dx is not None:
+                lead = dys[g].shape[:-1] if dys[g] is not None else (x2s[g].shape[0],)
+                dx = dx.view(*lead, p1.shape[1])
+            out += [dx, dw1, dw2, db1, db2]
+        return tuple(out)
+
+
+def linear2_group(groups):
+    """groups: [(x, w1, w2, b1, b2), ...] -> [y, ...]; one launch each way when every group's weights have piece planes and the
+    launch as a whole has the rows the plane form wants, one linear2 per group otherwise."""
+    rows = sum(int(x.numel() // x.shape[-1]) for x, *_ in groups)
+    if (len(groups) >= 2 and rows >= PLANES_MIN_ROWS and all(x.is_cuda and x.dtype == torch.float32 for x, *_ in groups)
+            and all(planes_supported(w1, w2) and b1 is not None and b2 is not None for _, w1, w2, b1, b2 in groups)):
+        flat = [t for grp in groups for t in grp]
+        return list(_Linear2Group.apply(len(groups), *flat))
+    return None
+
+
 LINEAR2_FEW_ROWS = 2048
 GROUP_ROWS = 4096          # _LinearGroup: row count up to which a group of projections runs as one few-row launch
 

@@ -192,3 +192,63 @@ def test_captured_step_with_flat_adam_keeps_planes_in_step(monkeypatch):
     assert with_planes[0] != with_planes[-1]                       # the steps do move the loss
     for a, b in zip(with_planes, without):
         assert abs(a - b) <= 2e-4 * abs(b), (with_planes, without)
+
+
+DEV = "cuda"
+
+
+def test_grouped_launch_is_the_bits_of_the_single_launches():
+    """mmdfn_linear_planes_group (ABI 16): every problem keeps its own tile form, so its result is bit-identical to its own launch."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    shapes = [(7040, 200, 300, 300), (1760, 200, 300, 300), (130, 100, 300, 300), (4100, 600, 100, 100)]   # (R, K, n1, n2)
+    probs = []
+    for R, K, n1, n2 in shapes:
+        probs.append(dict(x=torch.randn(R, K, device=DEV, generator=g), w1=torch.randn(n1, K, device=DEV, generator=g) * 0.1,
+                          w2=torch.randn(n2, K, device=DEV, generator=g) * 0.1, b1=torch.randn(n1, device=DEV, generator=g),
+                          b2=torch.randn(n2, device=DEV, generator=g)))
+    got = ops.linear_planes_group_raw(probs)
+    for pr, y in zip(probs, got):
+        want = ops.linear_planes_raw(pr["x"], pr["w1"], pr["w2"], pr["b1"], pr["b2"])
+        assert torch.equal(y, want)
+    # the input-gradient orientation (no biases), two problems
+    dys = [torch.randn(7040, 600, device=DEV, generator=g), torch.randn(1760, 600, device=DEV, generator=g)]
+    got = ops.linear_planes_group_raw([dict(x=dy, w1=pr["w1"], w2=pr["w2"]) for dy, pr in zip(dys, probs[:2])], transposed=True)
+    for dy, pr, dx in zip(dys, probs[:2], got):
+        assert torch.equal(dx, ops.linear_planes_raw(dy, pr["w1"], pr["w2"], transposed=True))
+
+
+def test_linear2_group_node_against_separate_nodes():
+    """_Linear2Group (the context + party input contractions of a GRU layer as one node) against one linear2 per group:
+    outputs, input gradients and weight / bias gradients."""
+    from mm_dfn_amd import train as T
+    g = torch.Generator(device=DEV).manual_seed(12)
+    mk = lambda *s: (torch.randn(*s, device=DEV, generator=g) * 0.2)
+    groups = []
+    for rows in ((110, 16), (110, 64)):
+        x = mk(*rows, 200).requires_grad_(True)
+        prm = [torch.nn.Parameter(mk(300, 200)), torch.nn.Parameter(mk(300, 200)), torch.nn.Parameter(mk(300)), torch.nn.Parameter(mk(300))]
+        groups.append([x] + prm)
+    cot = [mk(*grp[0].shape[:-1], 600) for grp in groups]
+
+    def run(joint):
+        for grp in groups:
+            for t in grp:
+                t.grad = None
+        if joint:
+            ys = ops.linear2_group([tuple(grp) for grp in groups])
+            assert ys is not None
+        else:
+            ys = [ops.linear2(*grp) for grp in groups]
+        loss = sum((y * c).sum() for y, c in zip(ys, cot))
+        T.backward(loss)
+        return [y.detach().clone() for y in ys], [[t.grad.detach().clone() for t in grp] for grp in groups]
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    for a, b in zip(y1, y0):
+        # (the 1 760-row group alone takes the exact-f32 few-row kernel, inside the group the bf16-piece plane kernel:
+        # both at fp32 rounding level)
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-6
+    for ga, gb in zip(g1, g0):
+        for a, b in zip(ga, gb):
+            assert float((a - b).abs().max() / b.abs().max()) < 3e-6

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, 4) void gcnii_layer_fwd_planes_kernel(
     constexpr int TPW = 4 / (3 - RH);
     constexpr int NACC = (RH == 2) ? 1 : 2;
     int rb, cb;
-    if (!pl_decode(nrb, ncb, rb, cb)) return;
+    if (!pl_decode(nrb, ncb, rb, cb, (int)blockIdx.x)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 4) void gcnii_layer_bwd_planes_kernel(
     constexpr int TPW = 4 / (3 - RH);
     constexpr int NACC = (RH == 2) ? 1 : 2;
     int rb, cb;
-    if (!pl_decode(nrb, ncb, rb, cb)) return;
+    if (!pl_decode(nrb, ncb, rb, cb, (int)blockIdx.x)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 3) void lstm_gate_bwd_planes_kernel(
     constexpr int TPW = 4 / (3 - RH);
     constexpr int NACC = (RH == 2) ? 1 : 2;
     int rb, cb;
-    if (!pl_decode(nrb, ncb, rb, cb)) return;
+    if (!pl_decode(nrb, ncb, rb, cb, (int)blockIdx.x)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
