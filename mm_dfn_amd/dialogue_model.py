@@ -224,13 +224,23 @@ class DialogueGNNModel(nn.Module):
             # cfg2's 7040 party rows the extra small launches cost more than the halved GEMMs save: 1.146 vs
             # 1.125 ms per step, tools/ab_project_then_gather.py, round 2)
             w_ih, b_ih, _ = fused_gru._layer_params(self.rnn_parties, 0)
-            gi_p, rank, *passed = ops.project_gather([X[m] for m in act], qmask, w_ih[0], w_ih[1], b_ih[0], b_ih[1],
-                                                     fused_gru._stacked_view(*w_ih), fused_gru._stacked_view(*b_ih))
+            # the context GRUs' first-layer input contractions read the same projected utterances and do not depend on the
+            # party branch: they ride in its grouped projection launch (ops.project_gather riders) instead of one launch each
+            riders, ridx = [], {}
+            for m, gru in zip(ctx_mods, ctx_grus):
+                if m in act and gru.input_size == X[m].shape[-1] and gru.bias:
+                    cw, cb, _ = fused_gru._layer_params(gru, 0)
+                    ridx[m] = len(riders)
+                    riders.append((act.index(m), cw[0], cw[1], cb[0], cb[1], fused_gru._stacked_view(*cw)))
+            gi_p, rank, *rest = ops.project_gather([X[m] for m in act], qmask, w_ih[0], w_ih[1], b_ih[0], b_ih[1],
+                                                   fused_gru._stacked_view(*w_ih), fused_gru._stacked_view(*b_ih), riders=riders)
+            passed, rode = rest[:len(act)], rest[len(act):]
             X.update(zip(act, passed))          # the gathered modalities come back as identities (one consumer each)
             if truncate:
                 party = (len(ctx_mods), rank, table)
             outs = fused_gru.bigru2([X[m] for m in ctx_mods] + [None], ctx_grus + [self.rnn_parties], self.dropout,
-                                    self.training, gi0=[None] * len(ctx_mods) + [gi_p], party=party)
+                                    self.training, gi0=[rode[ridx[m]] if m in ridx else None for m in ctx_mods] + [gi_p],
+                                    party=party)
         else:
             # the gathered modalities come back as identities (passthrough): the combine stage below reads those, so
             # each projected modality has one consumer and its two gradient paths meet inside the gather's backward

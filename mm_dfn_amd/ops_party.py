@@ -6,7 +6,7 @@ Every function launches hand-written gfx950 kernels on the current HIP stream; t
 import torch
 
 from . import _hip
-from .ops_linear import linear_group_raw
+from .ops_linear import _wgrad, linear_group_raw
 from .ops_wgrad import _WGQ, _queueable, _wgrad_inline, colsum, flush_queued_wgrads, queue_wgrad, slab_reduce_queueable
 
 
@@ -111,7 +111,14 @@ class _ProjectGather(torch.autograd.Function):
     with X_m' identities of the inputs (see _PartyGather)."""
 
     @staticmethod
-    def forward(ctx, qmask, w1, w2, b1, b2, wcat, bcat, *Xs):
+    def forward(ctx, qmask, w1, w2, b1, b2, wcat, bcat, riders, *rest):
+        # riders: [(index into Xs, has_wcat), ...]; rest = 5 tensors per rider (w1, w2, b1, b2, wcat-or-None), then Xs.
+        # A rider is ANOTHER projection of one of the gathered inputs that does not depend on this node's result (the context
+        # GRU's first-layer input contraction of the same utterance rows, model.py:1132): it rides in the grouped launch of the
+        # party projections instead of taking a launch of its own.  Its result comes back as an extra output.
+        nr = len(riders)
+        rprm = [rest[5 * i:5 * i + 5] for i in range(nr)]
+        Xs = rest[5 * nr:]
         _hip.require_cuda(qmask, w1, w2, *Xs)
         mods = [x.contiguous() for x in Xs]
         qmask = qmask.contiguous()
@@ -121,7 +128,13 @@ class _ProjectGather(torch.autograd.Function):
         w1c, w2c = w1.contiguous(), w2.contiguous()
         n1, N = w1.shape[0], w1.shape[0] + w2.shape[0]
         G = torch.empty(Mn, L * B, N, dtype=torch.float32, device=qmask.device)
-        linear_group_raw([dict(x=m.view(L * B, H), w=w1c, w2=w2c, out=G[i]) for i, m in enumerate(mods)])
+        probs = [dict(x=m.view(L * B, H), w=w1c, w2=w2c, out=G[i]) for i, m in enumerate(mods)]
+        routs = []
+        for (src, _), (rw1, rw2, rb1, rb2, _rw) in zip(riders, rprm):
+            o = torch.empty(L * B, rw1.shape[0] + rw2.shape[0], dtype=torch.float32, device=qmask.device)
+            probs.append(dict(x=mods[src].view(L * B, H), w=rw1.contiguous(), w2=rw2.contiguous(), b=rb1, b2=rb2, out=o))
+            routs.append(o)
+        linear_group_raw(probs)
         bias = None
         if b1 is not None:
             bias = bcat if bcat is not None else torch.cat([b1, b2])
@@ -132,16 +145,21 @@ class _ProjectGather(torch.autograd.Function):
         _hip.check(rc, "mmdfn_party_gather")
         ctx.dims = (L, B, P, H, Mn, n1, N)
         ctx.refs = (w1, w2, b1, b2)
-        ctx.save_for_backward(rank, w1c, w2c, wcat, *mods)
+        ctx.riders = [(src, tuple(pr[:4])) for (src, _), pr in zip(riders, rprm)]
+        ctx.save_for_backward(rank, w1c, w2c, wcat, *[pr[4] for pr in rprm], *[pr[0] for pr in rprm], *[pr[1] for pr in rprm], *mods)
         ctx.mark_non_differentiable(rank)
         ctx.set_materialize_grads(False)
-        return (S, rank) + tuple(Xs)
+        return (S, rank) + tuple(Xs) + tuple(o.view(L, B, -1) for o in routs)
 
     @staticmethod
     def backward(ctx, dS, _drank, *dpass):
-        rank, w1, w2, wcat, *mods = ctx.saved_tensors
+        nr = len(ctx.riders)
+        rank, w1, w2, wcat, *tail = ctx.saved_tensors
+        rwcat, rw1c, rw2c, mods = tail[:nr], tail[nr:2 * nr], tail[2 * nr:3 * nr], tail[3 * nr:]
         p1, p2, b1, b2 = ctx.refs
         L, B, P, H, Mn, n1, N = ctx.dims
+        dride = dpass[Mn:]                      # gradients of the riders' outputs
+        dpass = dpass[:Mn]
         dev = rank.device
         dS = dS.contiguous() if dS is not None else torch.zeros(L, Mn * B * P, N, dtype=torch.float32, device=dev)
         dG = torch.empty(Mn, L * B, N, dtype=torch.float32, device=dev)
@@ -160,7 +178,7 @@ class _ProjectGather(torch.autograd.Function):
                 db1, db2 = db[:n1], db[n1:]
         # input gradients: dX_m = dG_m [W1; W2] (+ the gradient that reached X_m's alias), one grouped launch
         dXs = [None] * Mn
-        need = [m for m in range(Mn) if ctx.needs_input_grad[7 + m]]
+        need = [m for m in range(Mn) if ctx.needs_input_grad[8 + 5 * nr + m]]
         if need:
             # dX_m = dG_m [W1; W2] + (the gradient that reached X_m's passthrough alias), out of place: the incoming gradient is
             # only READ (the kernel's addend), never written -- autograd may hand the same tensor to several nodes (ADVICE r03;
@@ -190,6 +208,29 @@ class _ProjectGather(torch.autograd.Function):
                 dXs[m] = o.view(L, B, H)
         else:
             dXs = [d for d in dpass] + [None] * (Mn - len(dpass))
+        # riders: their input gradient is added onto the source modality's (second launch: two workgroups of one launch may not
+        # write the same rows), their weight / bias gradients are queued like any projection's
+        rgrads = []
+        for i, (src, (rp1, rp2, rb1, rb2)) in enumerate(ctx.riders):
+            dyr = dride[i] if i < len(dride) else None
+            if dyr is None:
+                rgrads += [None, None, None, None, None]
+                continue
+            dy2 = dyr.reshape(L * B, -1).contiguous()
+            rn1 = rp1.shape[0]
+            if ctx.needs_input_grad[8 + 5 * nr + src]:
+                if dXs[src] is None:
+                    dXs[src] = torch.zeros(L, B, H, dtype=torch.float32, device=dev)
+                tgt = dXs[src].view(L * B, H)
+                if rwcat[i] is not None:
+                    linear_group_raw([dict(x=dy2, wk=rwcat[i], out=tgt, accumulate=True)])
+                else:
+                    linear_group_raw([dict(x=dy2[:, :rn1], wk=rw1c[i], out=tgt, accumulate=True)])
+                    linear_group_raw([dict(x=dy2[:, rn1:], wk=rw2c[i], out=tgt, accumulate=True)])
+            xs2 = mods[src].view(L * B, H)
+            dwa, dba = _wgrad(dy2[:, :rn1], xs2, rp1, rb1)
+            dwb, dbb = _wgrad(dy2[:, rn1:], xs2, rp2, rb2)
+            rgrads += [dwa, dwb, dba, dbb, None]
         # weight gradients: one segment per modality and direction
         dw1 = dw2 = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
@@ -204,16 +245,19 @@ class _ProjectGather(torch.autograd.Function):
                     b, _ = _wgrad_inline(dG[m][:, n1:], x2[m], False)
                     dw1 = a if dw1 is None else dw1 + a
                     dw2 = b if dw2 is None else dw2 + b
-        return (None, dw1, dw2, db1, db2, None, None) + tuple(dXs)
+        return (None, dw1, dw2, db1, db2, None, None, None) + tuple(rgrads) + tuple(dXs)
 
 
-def project_gather(Xs, qmask, w1, w2, b1, b2, wcat=None, bcat=None):
-    """(gi_p, rank, X_0', ..): see _ProjectGather.  ``wcat`` / ``bcat``: optional stacked views of [w1; w2] / [b1; b2] (no
-    gradient flows through them; without wcat the input gradient takes two launches per modality, without bcat the bias is
-    concatenated per call)."""
+def project_gather(Xs, qmask, w1, w2, b1, b2, wcat=None, bcat=None, riders=()):
+    """(gi_p, rank, X_0', .., [rider outputs]): see _ProjectGather.  ``wcat`` / ``bcat``: optional stacked views of [w1; w2] /
+    [b1; b2] (no gradient flows through them; without wcat the input gradient takes two launches per modality, without bcat the
+    bias is concatenated per call).  ``riders``: [(index into Xs, w1, w2, b1, b2, wcat-or-None), ...] -- further projections
+    X_index [w1; w2]^T + [b1; b2] computed in the same grouped launch, returned behind the identities as (L, B, .) tensors."""
     if w1.shape[1] % 4 or (w1.shape[0] + w2.shape[0]) % 4:
         raise ValueError("project_gather: widths must be multiples of 4")
-    return _ProjectGather.apply(qmask, w1, w2, b1, b2, wcat, bcat, *Xs)
+    meta = [(int(r[0]), r[5] is not None) for r in riders]
+    flat = [t for r in riders for t in r[1:6]]
+    return _ProjectGather.apply(qmask, w1, w2, b1, b2, wcat, bcat, meta, *flat, *Xs)
 
 
 class _PartyCombine(torch.autograd.Function):
