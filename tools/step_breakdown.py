@@ -18,7 +18,7 @@ FAMILIES = [
     ("weight_gradients", r"gemm_tn"),
     ("gcn_stack_fused", r"lstm_gate_|gcnii_layer_|gcn_input_|lstm_pointwise|gcnii_combine"),
     ("propagate_K6", r"propagate_"),
-    ("adjacency_K5_K6b", r"tile_dot|unit_cross|rdeg_cross|scale_tiles|symmetrize|bwd_rowsum|bwd_etile|bwd_ecross|cross_dot|unit_bwd"),
+    ("adjacency_K5_K6b", r"tile_dot|unit_cross|rdeg_cross|scale_tiles|symmetrize|bwd_rowsum|bwd_etile|bwd_ecross|cross_dot|unit_bwd|adj_strip|adj_finish"),
     ("projections_hand_written", r"linear_kernel|linear_split|linear_small|linear_lds|linear2|linear_planes|cut_planes"),
     ("fusion_modules", r"softmax_scale|mfn_mem|gated_pair|rowscale_colsum"),
     ("library_gemm_k_not_multiple_of_4", r"^Cijk_"),

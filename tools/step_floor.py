@@ -52,11 +52,12 @@ def inventory(B, L, lengths, D_t, D_a, D_v, nl, P, n_act=2, He=200, d=100, C=6, 
 
     fam["projections_hand_written"] = [
         _cls("modality projections (3 groups)", 1, 4.0 * (R * Dsum + Dsum * He + 3 * R * He), 2.0 * R * Dsum * He),
-        _cls("context GRU l0 input contraction", 1, **dense(R, He, G)),
-        _cls("party GRU l0 input contraction", 1, **dense(RP, He, G)),
-        _cls("GRU l1 input contraction (context + party)", 1, **dense(R + RP, He, G)),
-        _cls("dX of GRU l1", 1, **dense(R + RP, G, He)),
-        _cls("dX of party GRU l0", 1, **dense(RP, G, He)),
+        # (project-then-gather: the party branch projects its n_act x R utterance rows, not the P-fold party rows; the context
+        # GRU's contraction rides in the same grouped launch)
+        _cls("GRU l0 input contractions (party modalities + context, one grouped launch)", 1, **dense(n_act * R + R, He, G)),
+        _cls("GRU l1 input contraction (context + party, one grouped launch)", 1, **dense(R + RP, He, G)),
+        _cls("dX of GRU l1 (context + party, one grouped launch)", 1, **dense(R + RP, G, He)),
+        _cls("dX of party GRU l0", 1, **dense(n_act * R, G, He)),
         _cls("dX of context GRU l0", 1, **dense(R, G, He)),
     ]
     T = L
@@ -80,19 +81,17 @@ def inventory(B, L, lengths, D_t, D_a, D_v, nl, P, n_act=2, He=200, d=100, C=6, 
     fam["propagate_K6"] = [
         _cls("propagate forward (A.H)", nl, k6_b, 2.0 * d * nnz),
         _cls("propagate backward (dH = A.dO)", nl, k6_b, 2.0 * d * nnz),
-        _cls("adjacency backward: E.unit (D = 200)", 1, 4.0 * nnz + 8.0 * MN * F, 2.0 * F * nnz),
     ]
     tiles = sum(M * l * l for l in lengths)
+    # short dialogues (L <= 128): the strip form of csrc/adjacency_small.hip -- forward two launches, backward one
     fam["adjacency_K5_K6b"] = [
-        _cls("unit vectors + cross-modal cosines", 1, 8.0 * MN * F),
-        _cls("cosine tiles (Gram, acos epilogue)", 1, 4.0 * MN * F + 8.0 * nnz, 2.0 * F * tiles),
-        _cls("degrees, normalisation (2 launches)", 2, 8.0 * nnz),
+        _cls("strip forward (unit rows, cross cosines, Gram, similarity, degrees)", 1, 8.0 * MN * F + 8.0 * nnz, 2.0 * F * tiles),
+        _cls("finish (column degrees onto the tiles, cross diagonals)", 1, 8.0 * nnz),
         _cls("adjacency gradient of the stack (dA = dO.H^T, all layers)", 1, 8.0 * MN * nl * d + 4.0 * nnz, 2.0 * nl * d * nnz),
-        _cls("symmetrise, row sums, dE (3 launches)", 3, 10.0 * nnz),
-        _cls("unit-vector backward", 1, 12.0 * MN * F),
+        _cls("strip backward (d(degree), E, E.unit, unit-vector backward)", 1, 12.0 * nnz + 12.0 * MN * F, 2.0 * F * nnz),
     ]
     wg = []
-    for c in fam["projections_hand_written"][:4]:
+    for c in fam["projections_hand_written"][:3]:           # (the forward contractions: each has a weight gradient)
         wg.append((c["flops"], c["bytes"]))
     for c in fam["gcn_stack_fused"]:
         if "forward" in c["name"]:
