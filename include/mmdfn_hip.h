@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 16: 15 + mmdfn_linear_planes_group; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 16: 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -206,6 +206,12 @@ int mmdfn_party_gather(int Mn, const float* const* X, const float* qmask, const 
                        int32_t* rank, int L, int B, int P, int H, void* stream);
 int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* rank, float* const* dX,
                            const float* const* addend, int L, int B, int P, int H, void* stream);
+/* ABI 16: mmdfn_party_gather_bwd and mmdfn_colsum_partial of the SAME dS (viewed as (L Mn B P) x H; the party GRU's bias
+ * gradient, model.py:1082) in one launch; returns the number of [H] slabs written to `workspace` (mmdfn_colsum_workspace(H)
+ * floats) for mmdfn_gemm_tn_batch_ext to sum, negative = rejected. */
+int mmdfn_party_gather_bwd_colsum(int Mn, const float* dS, const int32_t* rank, float* const* dX,
+                                  const float* const* addend, int L, int B, int P, int H, float* workspace, void* stream);
+
 /* Column sums out[c] = sum_r A[r][c] of an (R, H) matrix (row stride lda; H, lda % 4 == 0, 16-byte aligned), bit-reproducible
  * (slab partial sums + a small final launch): the bias gradient of gate pre-activations gathered after a bias-free
  * projection (replaces the autograd `sum` of the broadcast bias add, model.py:1082).
@@ -226,6 +232,12 @@ int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const 
 int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t* rank, const int64_t* flat_idx,
                             float* const* dbase, float* dE, const float* weights,
                             int L, int B, int P, int N, int H, void* stream);
+/* ABI 16: the same gradients written destination by destination -- dbase / dE need NOT be zeroed by the caller (its fill was a
+ * launch of its own).  inv: (L * B) int64, the row of (t, b) in the stripped order or -1 (the inverse of flat_idx).
+ * Returns -2 when the shape is not covered (L > 2048): use mmdfn_party_combine_bwd on pre-zeroed buffers. */
+int mmdfn_party_combine_bwd_dst(int Mn, const float* dout, const int32_t* rank, const int64_t* inv, float* const* dbase,
+                                float* dE, const float* weights, int L, int B, int P, int N, int H, void* stream);
+
 
 /* ---------------------------------------------------------------------------
  * Dropout as a multiply by precomputed keep flags, several tensors per launch (the inter-layer dropout of
@@ -281,7 +293,9 @@ int mmdfn_linear2(const float* X, const float* W, const float* W2, int N1, const
  * mmdfn_linear_planes_group (ABI 16): n <= 4 such products in ONE launch (problem i: X[i], planes[i], ... as above; bias / bias2
  *   may be null arrays; R[i] == 0 skips a problem) -- the hoisted input contractions of the context and the party GRU of one
  *   layer (model.py:866-868, 1082, 1132) and their input gradients, which do not depend on each other.  Every problem keeps the
- *   tile form it takes alone, so its results are the bits of its own mmdfn_linear_planes launch.
+ *   tile form it takes alone, so its results are the bits of its own mmdfn_linear_planes launch.  mask (may be null, entries may
+ *   be null): R[i] x N[i] keep flags (0 / 1, contiguous); Y_i is multiplied by mask_i * mask_scale after the activation -- the
+ *   backward of the dropout between the GRU layers (nn.GRU(dropout=), model.py:866) folded into the input gradient's epilogue.
  * ------------------------------------------------------------------------- */
 int64_t mmdfn_weight_planes_workspace(int N, int K);
 int mmdfn_cut_weight_planes(int n, const float* const* w1, const float* const* w2, const int* n1, const int* ld,
@@ -290,7 +304,8 @@ int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, c
                         int K, int N, int ldx, int ldy, int act, int accumulate, void* stream);
 int mmdfn_linear_planes_group(int n, const float* const* X, const void* const* planes, const float* const* bias,
                               const float* const* bias2, const int* n1, float* const* Y, const int* R, const int* K,
-                              const int* N, const int* ldx, const int* ldy, int act, int accumulate, void* stream);
+                              const int* N, const int* ldx, const int* ldy, int act, int accumulate,
+                              const float* const* mask, float mask_scale, void* stream);
 
 /* A GROUP of few-row projections in one launch (linear_small.hip; n <= 8 problems, K <= 768, K % 4 == 0):
  *   Y_p = act(X_p W_p^T + b_p) (+ Y_p)      X_p: R_p rows of K_p floats (stride ldx), Y_p: R_p x N_p (stride ldy)

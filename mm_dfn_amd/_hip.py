@@ -48,7 +48,7 @@ SIGNATURES = {
     "mmdfn_weight_planes_workspace": [_I, _I],
     "mmdfn_cut_weight_planes": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_linear_planes": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "mmdfn_linear_planes_group": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "mmdfn_linear_planes_group": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _P],
     "mmdfn_linear_group_supported": [_I, _I, _I],
     "mmdfn_linear_group": [_I] + [_P] * 15 + [_I, _P],
     "mmdfn_linear_group_addend": [_I] + [_P] * 17 + [_I, _P],
@@ -81,8 +81,10 @@ SIGNATURES = {
     "mmdfn_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "mmdfn_party_gather": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "mmdfn_party_gather_bwd": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "mmdfn_party_gather_bwd_colsum": [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "mmdfn_party_combine": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mmdfn_party_combine_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mmdfn_party_combine_bwd_dst": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mmdfn_mask_scale": [_I, _P, _P, _P, _P, _F, _P],
     "mmdfn_keep_flags": [_P, _L, _F, _P, _P],
     "mmdfn_colsum_workspace": [_I],

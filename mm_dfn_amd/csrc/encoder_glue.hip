@@ -80,13 +80,13 @@ __global__ __launch_bounds__(256) void party_gather_kernel(ModPtrs X, const floa
 }
 
 // dX_m[t,b,:] = addend_m[t,b,:] + sum_p [rank[t,b,p] >= 0] dS[rank, (m,b,p), :]
-__global__ void party_gather_bwd_kernel(const float* __restrict__ dS, const int32_t* __restrict__ rank, ModPtrsW dX,
-                                        ModPtrs addend, int L, int B, int P, int Mn, int H) {
+__device__ __forceinline__ void party_gather_bwd_body(const float* __restrict__ dS, const int32_t* __restrict__ rank,
+                                                      const ModPtrsW& dX, const ModPtrs& addend, int L, int B, int P, int Mn, int H,
+                                                      int bid, int nblocks) {
     const int H4 = H / 4;
     const int64_t total = (int64_t)Mn * L * B * H4;
     const int64_t cols = (int64_t)Mn * B * P;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = bid * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)nblocks * blockDim.x) {
         const int c4 = (int)(idx % H4);
         int64_t r = idx / H4;
         const int b = (int)(r % B);
@@ -107,6 +107,11 @@ __global__ void party_gather_bwd_kernel(const float* __restrict__ dS, const int3
         }
         *reinterpret_cast<float4*>(dX.p[m] + ((int64_t)t * B + b) * H + 4 * c4) = acc;
     }
+}
+
+__global__ void party_gather_bwd_kernel(const float* __restrict__ dS, const int32_t* __restrict__ rank, ModPtrsW dX,
+                                        ModPtrs addend, int L, int B, int P, int Mn, int H) {
+    party_gather_bwd_body(dS, rank, dX, addend, L, B, P, Mn, H, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // out[m][n][:] = base_m[t,b,:] + w_m * E[rank[t,b,p*], (m,b,p*), :],  flat_idx[n] = t*B + b
@@ -181,6 +186,81 @@ __global__ void party_combine_bwd_kernel(const float* __restrict__ dout, const i
     }
 }
 
+// The same gradients written DESTINATION by destination, so that nothing has to be zeroed first (the caller's fill was a launch
+// of its own): workgroup (b, p, row slice) rebuilds the party's time list from `rank`, writes dE[k, (m, b, p), :] = w_m dout[m][n]
+// for k below the party's count and zeros above it; the p = 0 workgroups also write dbase_m[t, b, :] = dout[m][n] or zero (padding).
+// inv[t * B + b] = n, the row of (t, b) in the stripped order, or -1.
+__global__ __launch_bounds__(256) void party_combine_bwd_dst_kernel(const float* __restrict__ dout, const int32_t* __restrict__ rank,
+                                                                    const int64_t* __restrict__ inv, ModPtrsW dbase,
+                                                                    float* __restrict__ dE, float w0, float w1, float w2, float w3,
+                                                                    int L, int B, int P, int Mn, int N, int H) {
+    __shared__ int sel[MAXL];
+    __shared__ int cnt_s;
+    const int b = blockIdx.x / P;
+    const int p = blockIdx.x - b * P;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < L; t += 256) {
+        const int k = rank[((int64_t)t * B + b) * P + p];
+        if (k >= 0) sel[k] = t;
+    }
+    if (tid < 64) {
+        int c = 0;
+        for (int t0 = 0; t0 < L; t0 += 64) {
+            const int t = t0 + tid;
+            c += __popcll(__ballot(t < L && rank[((int64_t)t * B + b) * P + p] >= 0));
+        }
+        if (tid == 0) cnt_s = c;
+    }
+    __syncthreads();
+    const int cnt = cnt_s;
+    const float wv[MAXMOD] = {w0, w1, w2, w3};
+    int slot[MAXMOD], nact = 0;
+#pragma unroll
+    for (int q = 0; q < MAXMOD; ++q) { slot[q] = nact; nact += (q < Mn && wv[q] != 0.f) ? 1 : 0; }
+    const int64_t cols = (int64_t)nact * B * P;
+    const int H4 = H / 4;
+    const int kper = (L + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kper;
+    const int k_hi = (k_lo + kper < L) ? k_lo + kper : L;
+    const int nk = k_hi - k_lo;
+    // source rows of the slice, looked up once (the element loop below then has no dependent load): sel is reused for them
+    __shared__ int src_e[MAXL / 8 + 8], src_b[MAXL / 8 + 8];
+    int my_e = -1, my_b = -1;
+    if (tid < nk) {
+        const int k = k_lo + tid;
+        if (k < cnt) my_e = (int)inv[(int64_t)sel[k] * B + b];
+        if (p == 0) my_b = (int)inv[(int64_t)k * B + b];
+    }
+    __syncthreads();
+    if (tid < nk) { src_e[tid] = my_e; src_b[tid] = my_b; }
+    __syncthreads();
+    // elements (modality, row of the slice, 16-byte column) spread over the threads: independent loads
+    const int total = Mn * nk * H4;
+    for (int e = tid; e < total; e += 256) {
+        const int c4 = e % H4;
+        const int r = e / H4;
+        const int kk = r % nk;
+        const int m = r / nk;
+        const float w = wv[m];
+        const float* dm = dout + (int64_t)m * N * H + 4 * c4;
+        if (dE != nullptr && w != 0.f) {
+            const int n = src_e[kk];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n >= 0) {
+                const float4 g = *reinterpret_cast<const float4*>(dm + (int64_t)n * H);
+                v = make_float4(w * g.x, w * g.y, w * g.z, w * g.w);
+            }
+            *reinterpret_cast<float4*>(dE + ((int64_t)(k_lo + kk) * cols + ((int64_t)slot[m] * B + b) * P + p) * H + 4 * c4) = v;
+        }
+        if (p == 0) {
+            const int n = src_b[kk];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n >= 0) v = *reinterpret_cast<const float4*>(dm + (int64_t)n * H);
+            *reinterpret_cast<float4*>(dbase.p[m] + ((int64_t)(k_lo + kk) * B + b) * H + 4 * c4) = v;
+        }
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b > 4096) b = 4096;
@@ -217,10 +297,8 @@ __global__ void mask_scale_kernel(MaskScaleGroups G, int ngroups, float scale) {
 // [slab][H] and a second small launch adds them in slab order (bit-reproducible).  (A single launch whose last workgroup
 // finishes the sum needs a device-scope release fence per workgroup; on this chip that writes back the L2's dirty lines --
 // the 17 MB of dS the GRU backward has just produced -- and took 43 us against 8 us for the two launches.)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t R, int H, int lda,
-                                                     float* __restrict__ ws) {
-    __shared__ float4 part[16][16];
-    const int cb = blockIdx.x, sl = blockIdx.y, nsl = gridDim.y;
+__device__ __forceinline__ void colsum_body(float4 (*part)[16], const float* __restrict__ A, int64_t R, int H, int lda,
+                                            float* __restrict__ ws, int cb, int sl, int nsl) {
     const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;           // 16 lanes x 16 bytes = the 64 columns; 16 row groups
     const int col = 64 * cb + 4 * c4;
     const int64_t rper = (R + nsl - 1) / nsl;
@@ -252,6 +330,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A
         for (int q = 1; q < 16; ++q) { const float4 v = part[q][c4]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
         *reinterpret_cast<float4*>(ws + (int64_t)sl * H + col) = s4;
     }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ A, int64_t R, int H, int lda,
+                                                     float* __restrict__ ws) {
+    __shared__ float4 part[16][16];
+    colsum_body(part, A, R, H, lda, ws, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// The scatter of the party gradient and the column-sum slabs of the SAME dS (the party GRU's bias gradient) in one launch:
+// blocks [0, ngather) scatter, the ncb x nsl blocks behind them sum (both only read dS; nothing one half writes is read by
+// the other)
+__global__ __launch_bounds__(256) void party_gather_bwd_colsum_kernel(const float* __restrict__ dS, const int32_t* __restrict__ rank,
+                                                                      ModPtrsW dX, ModPtrs addend, int L, int B, int P, int Mn,
+                                                                      int H, int ngather, int64_t R, int ncb, int nsl,
+                                                                      float* __restrict__ ws) {
+    __shared__ float4 part[16][16];
+    const int bid = blockIdx.x;
+    if (bid < ngather) {
+        party_gather_bwd_body(dS, rank, dX, addend, L, B, P, Mn, H, bid, ngather);
+        return;
+    }
+    const int j = bid - ngather;
+    colsum_body(part, dS, R, H, H, ws, j % ncb, j / ncb, nsl);
 }
 
 // out[c] = sum over slabs (in slab order) of ws[slab][c]
@@ -353,6 +454,31 @@ extern "C" int mmdfn_party_gather_bwd(int Mn, const float* dS, const int32_t* ra
     return 0;
 }
 
+// mmdfn_party_gather_bwd + mmdfn_colsum_partial(dS as (L * Mn*B*P) x H, workspace) in ONE launch; returns the number of [H]
+// slabs in `workspace` (> 0) like mmdfn_colsum_partial, negative = rejected
+extern "C" int mmdfn_party_gather_bwd_colsum(int Mn, const float* dS, const int32_t* rank, float* const* dX,
+                                             const float* const* addend, int L, int B, int P, int H, float* workspace,
+                                             void* stream) {
+    if (Mn <= 0 || Mn > MAXMOD || L <= 0 || B <= 0 || P <= 0 || H <= 0 || (H & 3) || workspace == nullptr) return -1;
+    if (reinterpret_cast<uintptr_t>(dS) & 15) return -1;
+    ModPtrsW x;
+    ModPtrs a;
+    for (int m = 0; m < MAXMOD; ++m) {
+        x.p[m] = m < Mn ? dX[m] : nullptr;
+        a.p[m] = (addend && m < Mn) ? addend[m] : nullptr;
+    }
+    const int64_t R = (int64_t)L * Mn * B * P;
+    const int ncb = (H + 63) / 64;
+    if (ncb > 64) return -1;
+    int nsl = COLSUM_SLABS;
+    if ((int64_t)nsl * 64 > R) nsl = (int)((R + 63) / 64);
+    const int ngather = grid_for((int64_t)Mn * L * B * (H / 4));
+    hipLaunchKernelGGL(party_gather_bwd_colsum_kernel, dim3(ngather + ncb * nsl), dim3(256), 0, (hipStream_t)stream, dS, rank, x, a, L,
+                       B, P, Mn, H, ngather, R, ncb, nsl, workspace);
+    if (hipGetLastError() != hipSuccess) return -2;
+    return nsl;
+}
+
 extern "C" int mmdfn_party_combine(int Mn, const float* const* base, const float* E, const int32_t* rank,
                                    const int64_t* flat_idx, float* out, const float* weights, int L, int B, int P,
                                    int N, int H, void* stream) {
@@ -381,6 +507,29 @@ extern "C" int mmdfn_party_combine_bwd(int Mn, const float* dout, const int32_t*
     }
     hipLaunchKernelGGL(party_combine_bwd_kernel, dim3(grid_for((int64_t)Mn * N * (H / 4))), dim3(256), 0,
                        (hipStream_t)stream, dout, rank, flat_idx, x, dE, w[0], w[1], w[2], w[3], L, B, P, Mn, N, H);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+// mmdfn_party_combine_bwd without the caller's zero fill: dbase / dE need NOT be initialised.  inv: (L * B) int64, the row of
+// (t, b) in the stripped order or -1 (the inverse of flat_idx).  -2: shape not covered (L > 2048): use the pre-zeroed form.
+extern "C" int mmdfn_party_combine_bwd_dst(int Mn, const float* dout, const int32_t* rank, const int64_t* inv,
+                                           float* const* dbase, float* dE, const float* weights, int L, int B, int P, int N,
+                                           int H, void* stream) {
+    if (Mn <= 0 || Mn > MAXMOD || L <= 0 || B <= 0 || P <= 0 || N <= 0 || H <= 0 || (H & 3) || inv == nullptr) return -1;
+    if (L > MAXL) return -2;
+    ModPtrsW x;
+    float w[MAXMOD] = {0, 0, 0, 0};
+    for (int m = 0; m < MAXMOD; ++m) {
+        x.p[m] = m < Mn ? dbase[m] : nullptr;
+        if (m < Mn) w[m] = weights[m];
+    }
+    int ny = 1024 / (B * P);                 // row slices: B * P workgroups alone leave most of the chip idle
+    if (ny > (L + 7) / 8) ny = (L + 7) / 8;
+    if (ny < (L + 255) / 256) ny = (L + 255) / 256;      // (a slice's rows are looked up by one thread each)
+    if (ny < 1) ny = 1;
+    hipLaunchKernelGGL(party_combine_bwd_dst_kernel, dim3(B * P, ny), dim3(256), 0, (hipStream_t)stream, dout, rank, inv, x, dE,
+                       w[0], w[1], w[2], w[3], L, B, P, Mn, N, H);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -109,7 +109,7 @@ template <int RH>
 __device__ __forceinline__ void linear_planes_body(
     u32x4* As, const float* __restrict__ X, const u32x4* __restrict__ planes, const float* __restrict__ bias,
     const float* __restrict__ bias2, int n1, float* __restrict__ Y, int R, int K, int N, int ldx, int ldy, int act,
-    int accumulate, int nrb, int ncb, int bid) {
+    int accumulate, int nrb, int ncb, int bid, const float* __restrict__ mask = nullptr, float mscale = 1.0f) {
     constexpr int TPW = 4 / (3 - RH);                   // column tiles per workgroup: RH = 2 -> 4, RH = 1 -> 2
     constexpr int NACC = (RH == 2) ? 1 : 2;
     int rb, cb;
@@ -180,6 +180,7 @@ __device__ __forceinline__ void linear_planes_body(
                 float* yp = Y + (int64_t)row * ldy + col;
                 float v = (NACC == 2 ? acc[h][0][r] + acc[h][NACC - 1][r] : acc[h][0][r]) + bv;
                 if (act == 1) v = v > 0.f ? v : 0.f;
+                if (mask) v *= mask[(int64_t)row * N + col] * mscale;      // (R x N keep flags: a dropout's backward folded in)
                 if (accumulate) v += *yp;
                 *yp = v;
             }
@@ -204,22 +205,23 @@ struct PlGroup {
     const float* bias[PL_MAXG];
     const float* bias2[PL_MAXG];
     float* Y[PL_MAXG];
+    const float* mask[PL_MAXG];
     int n1[PL_MAXG], R[PL_MAXG], K[PL_MAXG], N[PL_MAXG], ldx[PL_MAXG], ldy[PL_MAXG], nrb[PL_MAXG], ncb[PL_MAXG], rh[PL_MAXG];
     int blk0[PL_MAXG + 1];
     int n;
 };
 
-__global__ __launch_bounds__(256, 4) void linear_planes_group_kernel(PlGroup G, int act, int accumulate) {
+__global__ __launch_bounds__(256, 4) void linear_planes_group_kernel(PlGroup G, int act, int accumulate, float mscale) {
     __shared__ u32x4 As[PL_LDS];
     int p = 0;
     while (p + 1 < G.n && (int)blockIdx.x >= G.blk0[p + 1]) ++p;
     const int bid = (int)blockIdx.x - G.blk0[p];
     if (G.rh[p] == 2)
         linear_planes_body<2>(As, G.X[p], G.planes[p], G.bias[p], G.bias2[p], G.n1[p], G.Y[p], G.R[p], G.K[p], G.N[p], G.ldx[p],
-                              G.ldy[p], act, accumulate, G.nrb[p], G.ncb[p], bid);
+                              G.ldy[p], act, accumulate, G.nrb[p], G.ncb[p], bid, G.mask[p], mscale);
     else
         linear_planes_body<1>(As, G.X[p], G.planes[p], G.bias[p], G.bias2[p], G.n1[p], G.Y[p], G.R[p], G.K[p], G.N[p], G.ldx[p],
-                              G.ldy[p], act, accumulate, G.nrb[p], G.ncb[p], bid);
+                              G.ldy[p], act, accumulate, G.nrb[p], G.ncb[p], bid, G.mask[p], mscale);
 }
 
 // tile form of one problem: few column tiles (an input gradient, N = 200) or few rows -> 64 x 64 workgroups, so that the launch
@@ -296,7 +298,8 @@ int mmdfn_linear_planes(const float* X, const void* planes, const float* bias, c
 
 int mmdfn_linear_planes_group(int n, const float* const* X, const void* const* planes, const float* const* bias,
                               const float* const* bias2, const int* n1, float* const* Y, const int* R, const int* K,
-                              const int* N, const int* ldx, const int* ldy, int act, int accumulate, void* stream) {
+                              const int* N, const int* ldx, const int* ldy, int act, int accumulate,
+                              const float* const* mask, float mask_scale, void* stream) {
     if (n <= 0 || n > PL_MAXG) return -1;
     PlGroup G;
     G.n = 0;
@@ -312,6 +315,7 @@ int mmdfn_linear_planes_group(int n, const float* const* X, const void* const* p
         G.bias[p] = bias ? bias[i] : nullptr;
         G.bias2[p] = bias2 ? bias2[i] : nullptr;
         G.Y[p] = Y[i];
+        G.mask[p] = mask ? mask[i] : nullptr;
         G.n1[p] = n1[i]; G.R[p] = R[i]; G.K[p] = K[i]; G.N[p] = N[i]; G.ldx[p] = ldx[i]; G.ldy[p] = ldy[i];
         pl_form(R[i], N[i], &G.nrb[p], &G.ncb[p], &G.rh[p]);
         const int64_t blocks = pl_grid(G.nrb[p], G.ncb[p]);
@@ -320,12 +324,12 @@ int mmdfn_linear_planes_group(int n, const float* const* X, const void* const* p
     }
     if (G.n == 0) return 0;
     for (int p = G.n; p < PL_MAXG; ++p) {
-        G.X[p] = nullptr; G.planes[p] = nullptr; G.bias[p] = G.bias2[p] = nullptr; G.Y[p] = nullptr;
+        G.X[p] = nullptr; G.planes[p] = nullptr; G.bias[p] = G.bias2[p] = nullptr; G.Y[p] = nullptr; G.mask[p] = nullptr;
         G.n1[p] = G.R[p] = G.K[p] = G.N[p] = G.ldx[p] = G.ldy[p] = G.nrb[p] = G.ncb[p] = G.rh[p] = 0;
         G.blk0[p + 1] = G.blk0[G.n];
     }
     hipLaunchKernelGGL(linear_planes_group_kernel, dim3((unsigned)G.blk0[G.n]), dim3(256), 0, (hipStream_t)stream, G, act,
-                       accumulate);
+                       accumulate, mask_scale);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }

@@ -43,6 +43,22 @@ def _flat_index(lengths, L, B, device):
     return _FLAT_CACHE.get((tuple(lengths), L, B, str(device)), lambda: torch.from_numpy(rows(lengths)).to(device))
 
 
+def _flat_inverse(lengths, L, B, device):
+    """(L * B,) int64: the row of padded-grid position t*B+b in the dialogue-major stripped order, -1 for padding (the inverse of
+    _flat_index; the combine stage's backward writes its outputs by destination with it)."""
+    def rows(lens):
+        lens = np.asarray([int(n) for n in lens], dtype=np.int64)
+        start = np.cumsum(lens) - lens
+        t = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(start, lens)
+        inv = np.full(L * B, -1, dtype=np.int64)
+        inv[t * B + np.repeat(np.arange(lens.size, dtype=np.int64), lens)] = np.arange(int(lens.sum()), dtype=np.int64)
+        return inv
+    scope = IndexScope.current()
+    if scope is not None:
+        return scope.tensor(("flat_inv", L, B, str(device)), lengths, rows, device)
+    return _FLAT_CACHE.get((tuple(lengths), L, B, str(device), "inv"), lambda: torch.from_numpy(rows(lengths)).to(device))
+
+
 class _Scalar(nn.Module):
     def __init__(self, i, o, bias):
         super().__init__()
@@ -203,6 +219,7 @@ class DialogueGNNModel(nn.Module):
         proj = ops.linear_group([raw[m] for m in present], [lin[m].weight for m in present], [lin[m].bias for m in present])
         X = dict(zip(present, proj))
         idx = _flat_index([int(x) for x in seq_lengths], L, B, proj[0].device)
+        inv = _flat_inverse([int(x) for x in seq_lengths], L, B, proj[0].device)
         table = None
         if use_table:
             # (launched behind the projections in program order, so the main stream's first kernel is not held up by the
@@ -214,7 +231,7 @@ class DialogueGNNModel(nn.Module):
             base = dict(X)
             base.update(zip(ctx_mods, outs))
             rank = torch.full((L, B, P), -1, dtype=torch.int32, device=proj[0].device)
-            return ops.party_combine([base[m] for m in present], None, rank, idx, [0.0] * len(present))
+            return ops.party_combine([base[m] for m in present], None, rank, idx, [0.0] * len(present), inv)
         party = None
         if len(act) * L * B * P >= PROJECT_THEN_GATHER_ROWS or P >= 4:
             # first party-GRU layer: gather(X) W_ih^T + b == gather(X W_ih^T) + b (padding rows = b), so the input
@@ -252,7 +269,7 @@ class DialogueGNNModel(nn.Module):
                                     self.training, party=party)
         base = dict(X)
         base.update(zip(ctx_mods, outs[:-1]))
-        return ops.party_combine([base[m] for m in present], outs[-1], rank, idx, weights)
+        return ops.party_combine([base[m] for m in present], outs[-1], rank, idx, weights, inv)
 
     # ------------------------------------------------------------------ forward
     def forward(self, U, qmask, umask, seq_lengths, U_a=None, U_v=None, test_label=False):

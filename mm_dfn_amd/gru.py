@@ -367,6 +367,7 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
                                    device=halves[0].device)
                 torch._foreach_copy_([wcat[i // 2, (i % 2) * halves[0].shape[0]:(i % 2 + 1) * halves[0].shape[0]]
                                       for i in range(len(halves))], halves)
+    pending = None                  # (keep flags, scale) of the dropout in front of the next layer
     for layer in range(2):
         prm = [_layer_params(gru, layer) for gru in grus]
         # hoisted input contractions (all t, both directions) of every group: one launch per group on the two
@@ -376,8 +377,18 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
         gis = list(pre)
         # the groups' contractions do not depend on each other: ONE launch against the weights' piece planes when there are
         # several (the context and the party encoder's second layer: 1 760 + 7 040 rows at cfg2), each way
-        joint = ops.linear2_group([(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1]) for g in todo]) \
-            if len(todo) >= 2 else None
+        joint = None
+        if len(todo) >= 2:
+            # (the dropout between the layers rides along: its forward is one launch inside the node, its backward the input
+            # gradient launch's epilogue)
+            pm = None if pending is None or len(todo) != len(grus) else pending[0]
+            joint = ops.linear2_group([(cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1]) for g in todo],
+                                      masks=pm, scale=1.0 if pm is None else pending[1])
+            if joint is not None and pm is not None:
+                pending = None
+        if pending is not None:
+            cur = list(ops.mask_scale(cur, pending[0], pending[1]))
+            pending = None
         for k, g in enumerate(todo):
             gis[g] = joint[k] if joint is not None else ops.linear2(
                 cur[g], prm[g][0][0], prm[g][0][1], prm[g][1][0], prm[g][1][1],
@@ -398,6 +409,6 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
             cur = list(_GruRecurrence.apply(_Seg(party[0], party[1], 0), None, *args))
         if layer == 0 and training and dropout > 0:
             # nn.GRU's dropout between the layers: 0 / 1 keep flags from the step's flag pool (no generator launch of its
-            # own) applied to every group's output by ONE launch each way
-            cur = list(ops.mask_scale(cur, [ops.keep_flags(y.numel(), dropout, y.device) for y in cur], ops.keep_scale(dropout)))
+            # own) applied to every group's output by ONE launch each way -- at the head of the next layer (see there)
+            pending = ([ops.keep_flags(y.numel(), dropout, y.device) for y in cur], ops.keep_scale(dropout))
     return cur

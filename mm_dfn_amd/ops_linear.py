@@ -554,9 +554,10 @@ def linear_planes_raw(x2, w1, w2=None, b1=None, b2=None, transposed=False, act=0
     return out
 
 
-def linear_planes_group_raw(problems, transposed=False, act=0):
+def linear_planes_group_raw(problems, transposed=False, act=0, mask_scale=1.0):
     """Up to four independent products x2 B^T + [b1; b2] against piece planes in ONE launch (mmdfn_linear_planes_group).
-    problems: dicts with x (2-D), w1, w2 and optionally b1, b2, out; returns the outputs.  Every problem's result is
+    problems: dicts with x (2-D), w1, w2 and optionally b1, b2, out, mask (keep flags with the OUTPUT's element count: the
+    result is multiplied by mask * mask_scale); returns the outputs.  Every problem's result is
     bit-identical to its own linear_planes_raw launch (it keeps the tile form it takes alone)."""
     lib = _hip.lib()
     xs, ents, outs = [], [], []
@@ -572,6 +573,9 @@ def linear_planes_group_raw(problems, transposed=False, act=0):
         out = pr.get("out")
         if out is None:
             out = torch.empty(x2.shape[0], e.N, dtype=torch.float32, device=x2.device)
+        mk = pr.get("mask")
+        if mk is not None and (mk.numel() != out.numel() or mk.dtype != torch.float32 or not mk.is_contiguous() or out.stride(0) != e.N):
+            raise _hip.HipLibraryError("linear_planes_group_raw: mask must be contiguous fp32 flags of the (contiguous) output's size")
         xs.append(x2)
         ents.append(e)
         outs.append(out)
@@ -584,7 +588,8 @@ def linear_planes_group_raw(problems, transposed=False, act=0):
                                            _hip.int_array(n1), _hip.ptr_array(o4), _hip.int_array([x.shape[0] for x in x4]),
                                            _hip.int_array([e.K for e in e4]), _hip.int_array([e.N for e in e4]),
                                            _hip.int_array([x.stride(0) for x in x4]), _hip.int_array([o.stride(0) for o in o4]),
-                                           int(act), 0, _hip.stream())
+                                           int(act), 0, _hip.ptr_array([pr.get("mask") for pr in prs]), float(mask_scale),
+                                           _hip.stream())
         _hip.check(rc, "mmdfn_linear_planes_group")
     return outs
 
@@ -592,20 +597,30 @@ def linear_planes_group_raw(problems, transposed=False, act=0):
 class _Linear2Group(torch.autograd.Function):
     """G projections y_g = x_g [W1_g; W2_g]^T + [b1_g; b2_g] that do not depend on each other (the context and the party GRU's
     hoisted input contractions of one layer) as ONE node: one grouped launch against the weights' piece planes forward, one for
-    the input gradients; weight / bias gradients per group as in _Linear2.  args: (x, w1, w2, b1, b2) per group."""
+    the input gradients; weight / bias gradients per group as in _Linear2.  args: (x, w1, w2, b1, b2) per group.
+    ``masks`` (optional, keep flags per group) / ``scale``: the inputs pass through a dropout first (nn.GRU's between its layers):
+    x_g * mask_g * scale is formed by ONE launch for all groups here, and the dropout's backward is the input-gradient launch's
+    epilogue instead of a launch of its own."""
 
     @staticmethod
-    def forward(ctx, n, *args):
+    def forward(ctx, n, masks, scale, *args):
         grp = [args[5 * g:5 * g + 5] for g in range(n)]
         shapes, x2s = [], []
-        for x, w1, w2, b1, b2 in grp:
+        if masks is not None:
+            from .ops_flags import _MaskScale
+            xin = [x.contiguous() for x, *_ in grp]
+            dropped = [torch.empty_like(x) for x in xin]
+            _MaskScale._launch(xin, list(masks), dropped, float(scale))
+        for g, (x, w1, w2, b1, b2) in enumerate(grp):
             shapes.append(x.shape)
-            x2 = x.reshape(-1, x.shape[-1])
+            x2 = (dropped[g] if masks is not None else x).reshape(-1, x.shape[-1])
             if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
                 x2 = x2.contiguous()
             x2s.append(x2)
         ys = linear_planes_group_raw([dict(x=x2, w1=w1, w2=w2, b1=b1, b2=b2) for x2, (_, w1, w2, b1, b2) in zip(x2s, grp)])
         ctx.n = n
+        ctx.masks = None if masks is None else list(masks)
+        ctx.scale = float(scale)
         ctx.refs = [(w1, w2, b1, b2) for _, w1, w2, b1, b2 in grp]
         ctx.save_for_backward(*x2s)
         return tuple(y.view(*shp[:-1], y.shape[1]) for y, shp in zip(ys, shapes))
@@ -621,13 +636,15 @@ class _Linear2Group(torch.autograd.Function):
                 N = ctx.refs[g][0].shape[0] + ctx.refs[g][1].shape[0]
                 dy = torch.zeros(x2s[g].shape[0], N, dtype=torch.float32, device=x2s[g].device)
             dy2s.append(dy.reshape(-1, dy.shape[-1]).contiguous())
-        need = [g for g in range(n) if ctx.needs_input_grad[1 + 5 * g]]
+        need = [g for g in range(n) if ctx.needs_input_grad[3 + 5 * g]]
         dxs = [None] * n
         if need:
-            got = linear_planes_group_raw([dict(x=dy2s[g], w1=ctx.refs[g][0], w2=ctx.refs[g][1]) for g in need], transposed=True)
+            got = linear_planes_group_raw([dict(x=dy2s[g], w1=ctx.refs[g][0], w2=ctx.refs[g][1],
+                                                mask=None if ctx.masks is None else ctx.masks[g]) for g in need],
+                                          transposed=True, mask_scale=ctx.scale)
             for g, dx in zip(need, got):
                 dxs[g] = dx
-        out = [None]
+        out = [None, None, None]
         for g in range(n):
             p1, p2, b1, b2 = ctx.refs[g]
             n1 = p1.shape[0]
@@ -642,14 +659,16 @@ class _Linear2Group(torch.autograd.Function):
         return tuple(out)
 
 
-def linear2_group(groups):
+def linear2_group(groups, masks=None, scale=1.0):
     """groups: [(x, w1, w2, b1, b2), ...] -> [y, ...]; one launch each way when every group's weights have piece planes and the
-    launch as a whole has the rows the plane form wants, one linear2 per group otherwise."""
+    launch as a whole has the rows the plane form wants; None otherwise (the caller runs one linear2 per group).  ``masks`` /
+    ``scale``: keep flags of a dropout applied to the inputs first (see _Linear2Group)."""
     rows = sum(int(x.numel() // x.shape[-1]) for x, *_ in groups)
     if (len(groups) >= 2 and rows >= PLANES_MIN_ROWS and all(x.is_cuda and x.dtype == torch.float32 for x, *_ in groups)
-            and all(planes_supported(w1, w2) and b1 is not None and b2 is not None for _, w1, w2, b1, b2 in groups)):
+            and all(planes_supported(w1, w2) and b1 is not None and b2 is not None for _, w1, w2, b1, b2 in groups)
+            and (masks is None or all(m.numel() == x.numel() and x.numel() % 4 == 0 for m, (x, *_) in zip(masks, groups)))):
         flat = [t for grp in groups for t in grp]
-        return list(_Linear2Group.apply(len(groups), *flat))
+        return list(_Linear2Group.apply(len(groups), None if masks is None else list(masks), float(scale), *flat))
     return None
 
 

@@ -81,19 +81,23 @@ class _HalvesGrad:
         self.grad = buf
 
 
-def _queue_bias_halves(A, b1, b2, n1):
-    """b1.grad, b2.grad = halves of the column sums of A (R, N): the slab kernel runs now, the sum over slabs rides on the
-    backward pass's last reduction launch."""
+def _queue_bias_halves(A, b1, b2, n1, slabs=None):
+    """b1.grad, b2.grad = halves of the column sums of A (R, N): the slab kernel runs now (or has run: ``slabs`` = (workspace,
+    number of slabs) from a launch that produced them on the way), the sum over slabs rides on the backward pass's last
+    reduction launch."""
     _hip.require_cuda(A)
     _hip.require_f32(A)
     if A.stride(1) != 1:
         A = A.contiguous()
     R, N = A.shape
     lib = _hip.lib()
-    ws = torch.empty(int(lib.mmdfn_colsum_workspace(N)), dtype=torch.float32, device=A.device)
-    nsl = lib.mmdfn_colsum_partial(_hip.ptr(A), R, N, A.stride(0), _hip.ptr(ws), _hip.stream())
-    if nsl <= 0:
-        raise _hip.HipLibraryError("mmdfn_colsum_partial rejected the operand (%d)" % nsl)
+    if slabs is not None:
+        ws, nsl = slabs
+    else:
+        ws = torch.empty(int(lib.mmdfn_colsum_workspace(N)), dtype=torch.float32, device=A.device)
+        nsl = lib.mmdfn_colsum_partial(_hip.ptr(A), R, N, A.stride(0), _hip.ptr(ws), _hip.stream())
+        if nsl <= 0:
+            raise _hip.HipLibraryError("mmdfn_colsum_partial rejected the operand (%d)" % nsl)
     buf = torch.empty(N, dtype=torch.float32, device=A.device)
     b1.grad, b2.grad = buf[:n1], buf[n1:]
     _WGQ["ext"].append(dict(part=None, colpart=ws, splits=int(nsl), M=int(N), N=0, weight=None, bias=_HalvesGrad(buf), acc=0))
@@ -163,19 +167,28 @@ class _ProjectGather(torch.autograd.Function):
         dev = rank.device
         dS = dS.contiguous() if dS is not None else torch.zeros(L, Mn * B * P, N, dtype=torch.float32, device=dev)
         dG = torch.empty(Mn, L * B, N, dtype=torch.float32, device=dev)
-        rc = _hip.lib().mmdfn_party_gather_bwd(Mn, _hip.ptr(dS), _hip.ptr(rank), _hip.ptr_array([dG[m] for m in range(Mn)]),
-                                               None, L, B, P, N, _hip.stream())
-        _hip.check(rc, "mmdfn_party_gather_bwd")
+        want_db = b1 is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        # the column sums stay slab stacks; the step's last reduction launch sums them into ONE (N,) buffer of which the two
+        # biases' .grad are the halves (views handed over here, filled at the end of the backward pass)
+        queue_db = (want_db and ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and slab_reduce_queueable(None, [b1, b2])
+                    and b1.grad is None and b2.grad is None)
+        lib = _hip.lib()
+        if queue_db:
+            # the scatter and the column-sum slabs read the same dS: one launch
+            ws = torch.empty(int(lib.mmdfn_colsum_workspace(N)), dtype=torch.float32, device=dev)
+            nsl = lib.mmdfn_party_gather_bwd_colsum(Mn, _hip.ptr(dS), _hip.ptr(rank), _hip.ptr_array([dG[m] for m in range(Mn)]),
+                                                    None, L, B, P, N, _hip.ptr(ws), _hip.stream())
+            if nsl <= 0:
+                raise _hip.HipLibraryError("mmdfn_party_gather_bwd_colsum rejected the operands (%d)" % nsl)
+            _queue_bias_halves(dS.view(-1, N), b1, b2, n1, slabs=(ws, int(nsl)))
+        else:
+            rc = lib.mmdfn_party_gather_bwd(Mn, _hip.ptr(dS), _hip.ptr(rank), _hip.ptr_array([dG[m] for m in range(Mn)]),
+                                            None, L, B, P, N, _hip.stream())
+            _hip.check(rc, "mmdfn_party_gather_bwd")
         db1 = db2 = None
-        if b1 is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
-            if (ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and slab_reduce_queueable(None, [b1, b2])
-                    and b1.grad is None and b2.grad is None):
-                # the column sums stay slab stacks; the step's last reduction launch sums them into ONE (N,) buffer of which the two
-                # biases' .grad are the halves (views handed over here, filled at the end of the backward pass)
-                _queue_bias_halves(dS.view(-1, N), b1, b2, n1)
-            else:
-                db = colsum(dS.view(-1, N))
-                db1, db2 = db[:n1], db[n1:]
+        if want_db and not queue_db:
+            db = colsum(dS.view(-1, N))
+            db1, db2 = db[:n1], db[n1:]
         # input gradients: dX_m = dG_m [W1; W2] (+ the gradient that reached X_m's alias), one grouped launch
         dXs = [None] * Mn
         need = [m for m in range(Mn) if ctx.needs_input_grad[8 + 5 * nr + m]]
@@ -265,7 +278,7 @@ class _PartyCombine(torch.autograd.Function):
     (B*P)-column block per modality with a NON-ZERO weight, in modality order."""
 
     @staticmethod
-    def forward(ctx, E, rank, flat_idx, weights, *bases):
+    def forward(ctx, E, rank, flat_idx, weights, inv, *bases):
         _hip.require_cuda(rank, *bases)
         bases = [x.contiguous() for x in bases]
         L, B, P = rank.shape
@@ -280,25 +293,39 @@ class _PartyCombine(torch.autograd.Function):
         ctx.dims = (L, B, P, H, Mn, N)
         ctx.weights = list(weights)
         ctx.has_E = E is not None
-        ctx.save_for_backward(rank, flat_idx)
+        ctx.save_for_backward(rank, flat_idx, inv)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        rank, flat_idx = ctx.saved_tensors
+        rank, flat_idx, inv = ctx.saved_tensors
         L, B, P, H, Mn, N = ctx.dims
         dout = dout.contiguous()
         nact = sum(1 for w in ctx.weights[:Mn] if w != 0.0)
         nb, ne = Mn * L * B * H, (L * nact * B * P * H if ctx.has_E else 0)
-        zero = torch.zeros(nb + ne, dtype=torch.float32, device=dout.device)       # one fill for both (pad rows stay 0)
-        dbase = zero[:nb].view(Mn, L, B, H)
-        dE = zero[nb:].view(L, nact * B * P, H) if ctx.has_E else None
-        rc = _hip.lib().mmdfn_party_combine_bwd(Mn, _hip.ptr(dout), _hip.ptr(rank), _hip.ptr(flat_idx),
-                                                _hip.ptr_array([dbase[m] for m in range(Mn)]), _hip.ptr(dE),
-                                                _hip.float_array(ctx.weights), L, B, P, N, H, _hip.stream())
-        _hip.check(rc, "mmdfn_party_combine_bwd")
-        return (dE, None, None, None) + tuple(dbase[m] for m in range(Mn))
+        rc = -2
+        if inv is not None:
+            # destination-driven form: every element of dbase / dE is written by the kernel, no fill launch in front of it
+            buf = torch.empty(nb + ne, dtype=torch.float32, device=dout.device)
+            dbase = buf[:nb].view(Mn, L, B, H)
+            dE = buf[nb:].view(L, nact * B * P, H) if ctx.has_E else None
+            rc = _hip.lib().mmdfn_party_combine_bwd_dst(Mn, _hip.ptr(dout), _hip.ptr(rank), _hip.ptr(inv),
+                                                        _hip.ptr_array([dbase[m] for m in range(Mn)]), _hip.ptr(dE),
+                                                        _hip.float_array(ctx.weights), L, B, P, N, H, _hip.stream())
+            if rc != -2:
+                _hip.check(rc, "mmdfn_party_combine_bwd_dst")
+        if rc == -2:
+            zero = torch.zeros(nb + ne, dtype=torch.float32, device=dout.device)       # one fill for both (pad rows stay 0)
+            dbase = zero[:nb].view(Mn, L, B, H)
+            dE = zero[nb:].view(L, nact * B * P, H) if ctx.has_E else None
+            rc = _hip.lib().mmdfn_party_combine_bwd(Mn, _hip.ptr(dout), _hip.ptr(rank), _hip.ptr(flat_idx),
+                                                    _hip.ptr_array([dbase[m] for m in range(Mn)]), _hip.ptr(dE),
+                                                    _hip.float_array(ctx.weights), L, B, P, N, H, _hip.stream())
+            _hip.check(rc, "mmdfn_party_combine_bwd")
+        return (dE, None, None, None, None) + tuple(dbase[m] for m in range(Mn))
 
 
-def party_combine(bases, E, rank, flat_idx, weights):
-    return _PartyCombine.apply(E, rank, flat_idx, list(weights), *bases)
+def party_combine(bases, E, rank, flat_idx, weights, inv=None):
+    """``inv`` (optional, (L * B) int64): the inverse of flat_idx (row of (t, b) in the stripped order or -1); with it the backward
+    pass writes its outputs destination by destination and needs no zero fill."""
+    return _PartyCombine.apply(E, rank, flat_idx, list(weights), inv, *bases)

@@ -252,3 +252,42 @@ def test_linear2_group_node_against_separate_nodes():
     for ga, gb in zip(g1, g0):
         for a, b in zip(ga, gb):
             assert float((a - b).abs().max() / b.abs().max()) < 3e-6
+
+
+def test_linear2_group_with_the_dropout_folded_in():
+    """masks / scale: y_g = (x_g * mask_g * scale) W^T + b with the dropout's backward in the input-gradient launch's epilogue,
+    against ops.mask_scale followed by the same node."""
+    from mm_dfn_amd import train as T
+    g = torch.Generator(device=DEV).manual_seed(13)
+    mk = lambda *s: (torch.randn(*s, device=DEV, generator=g) * 0.2)
+    groups = []
+    for rows in ((110, 16), (110, 64)):
+        x = mk(*rows, 200).requires_grad_(True)
+        prm = [torch.nn.Parameter(mk(300, 200)), torch.nn.Parameter(mk(300, 200)), torch.nn.Parameter(mk(300)), torch.nn.Parameter(mk(300))]
+        groups.append([x] + prm)
+    masks = [(torch.rand(grp[0].numel(), device=DEV, generator=g) < 0.6).float() for grp in groups]
+    cot = [mk(*grp[0].shape[:-1], 600) for grp in groups]
+
+    def run(folded):
+        for grp in groups:
+            for t in grp:
+                t.grad = None
+        if folded:
+            ys = ops.linear2_group([tuple(grp) for grp in groups], masks=masks, scale=1.0 / 0.6)
+        else:
+            xs = ops.mask_scale([grp[0] for grp in groups], masks, 1.0 / 0.6)
+            ys = ops.linear2_group([(x,) + tuple(grp[1:]) for x, grp in zip(xs, groups)])
+        assert ys is not None
+        T.backward(sum((y * c).sum() for y, c in zip(ys, cot)))
+        return [y.detach().clone() for y in ys], [[t.grad.detach().clone() for t in grp] for grp in groups]
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    for a, b in zip(y1, y0):
+        assert torch.equal(a, b)
+    for ga, gb in zip(g1, g0):
+        for a, b in zip(ga, gb):
+            assert float((a - b).abs().max() / b.abs().max()) < 1e-6
+        # a dropped input element receives no gradient
+    for grp, m, ga in zip(groups, masks, g1):
+        assert float(ga[0].reshape(-1)[m == 0].abs().max()) == 0.0
