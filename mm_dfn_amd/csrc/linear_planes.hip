@@ -171,6 +171,16 @@ __device__ __forceinline__ void linear_planes_body(
     float bv = 0.f;
     if (col < n1) { if (bias) bv = bias[col]; }
     else if (bias2) bv = bias2[col - n1];
+    // keep flags of a folded dropout: requested for all the rows first (a load inside the store loop waits a round trip per row)
+    float mv[RH][16];
+#pragma unroll
+    for (int h = 0; h < RH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + 32 * (RH == 2 ? h : myh) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            mv[h][r] = 1.0f;
+            if (mask) mv[h][r] = mask[(int64_t)(row < R ? row : R - 1) * N + col] * mscale;
+        }
 #pragma unroll
     for (int h = 0; h < RH; ++h)
 #pragma unroll
@@ -180,7 +190,7 @@ __device__ __forceinline__ void linear_planes_body(
                 float* yp = Y + (int64_t)row * ldy + col;
                 float v = (NACC == 2 ? acc[h][0][r] + acc[h][NACC - 1][r] : acc[h][0][r]) + bv;
                 if (act == 1) v = v > 0.f ? v : 0.f;
-                if (mask) v *= mask[(int64_t)row * N + col] * mscale;      // (R x N keep flags: a dropout's backward folded in)
+                v *= mv[h][r];
                 if (accumulate) v += *yp;
                 *yp = v;
             }
