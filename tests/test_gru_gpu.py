@@ -225,6 +225,47 @@ def test_project_gather_node_matches_projection_of_gathered_rows(P, lengths, nac
         assert rel_err(a.grad, b.grad) < 2e-5
 
 
+@pytest.mark.parametrize("stacked_views", [True, False])
+@pytest.mark.parametrize("P,lengths,nact,src", [(2, [15, 9, 1, 6], 2, 1), (2, [110, 64, 80], 3, 2), (3, [1], 1, 0)])
+def test_project_gather_riders(P, lengths, nact, src, stacked_views):
+    """riders: another projection of one of the gathered inputs (the context GRU's first-layer input contraction, model.py:1132)
+    computed in the node's grouped launch -- against the node without riders plus a linear2 of the same input: the rider's
+    output, every weight / bias gradient, and the source input's gradient, which now meets INSIDE the node."""
+    from mm_dfn_amd import ops
+    from mm_dfn_amd import train as T
+    cfg = dict(B=len(lengths), L=max(lengths), P=P, C=6, nlayers=2, D_t=100, D_a=32, D_v=64)
+    q = synthetic.make_batch(4, lengths=lengths, **cfg)["qmask"].to(DEV)
+    L, B = max(lengths), len(lengths)
+    rs = np.random.RandomState(19)
+    t = lambda *sh: torch.from_numpy(rs.randn(*sh).astype(np.float32)).to(DEV)
+    Xs = [t(L, B, 200) for _ in range(nact)]
+    wbuf, bbuf, rwbuf, rbbuf = t(600, 200) * 0.1, t(600), t(600, 200) * 0.1, t(600)
+    Wg, Wp, Wr = t(L, nact * B * P, 600), [t(L, B, 200) for _ in range(nact)], t(L, B, 600)
+
+    def run(with_rider):
+        Xk = [x.clone().requires_grad_(True) for x in Xs]
+        wk, bk, rwk, rbk = wbuf.clone(), bbuf.clone(), rwbuf.clone(), rbbuf.clone()
+        prm = [wk[:300].requires_grad_(True), wk[300:].requires_grad_(True), bk[:300].requires_grad_(True), bk[300:].requires_grad_(True)]
+        rprm = [rwk[:300].requires_grad_(True), rwk[300:].requires_grad_(True), rbk[:300].requires_grad_(True), rbk[300:].requires_grad_(True)]
+        views = (wk, bk) if stacked_views else (None, None)
+        if with_rider:
+            gk, rank, *rest = ops.project_gather(Xk, q, *prm, *views, riders=[(src, *rprm, rwk if stacked_views else None)])
+            passed, (yr,) = rest[:nact], rest[nact:]
+        else:
+            gk, rank, *passed = ops.project_gather(Xk, q, *prm, *views)
+            yr = ops.linear2(passed[src], *rprm, rwk if stacked_views else None, None)
+        loss = (gk * Wg).sum() + (yr * Wr).sum() + sum((x * w).sum() for i, (x, w) in enumerate(zip(passed, Wp)) if i != src)
+        T.backward(loss)
+        return gk.detach(), yr.detach(), [x.grad for x in Xk], [p_.grad for p_ in prm + rprm]
+
+    g1, y1, dx1, dp1 = run(True)
+    g0, y0, dx0, dp0 = run(False)
+    assert torch.equal(g1, g0)
+    assert rel_err(y1, y0) < 2e-6
+    for a, b in zip(dx1 + dp1, dx0 + dp0):
+        assert rel_err(a, b) < 3e-6
+
+
 @pytest.mark.parametrize("R,H", [(7040, 600), (33, 600), (1, 4), (19008, 600), (100, 68), (64, 64)])
 def test_column_sum_kernel(R, H):
     from mm_dfn_amd import ops
