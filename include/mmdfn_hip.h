@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 16: 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 16: 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -432,6 +432,16 @@ int mmdfn_lstm_gate_bwd(const float* gates, const float* c_prev, const float* c_
                         float* dc_prev, float* dq, float* dh_prev, int R, int H, int has_h, int lddres, void* stream);
 int mmdfn_gcnii_layer_fwd(const float* hi, const float* h0, const float* W, const float* q, const float* m, float* out,
                           float* gmask, float theta, float alpha, int R, int H, int ldo, float mscale, void* stream);
+
+/* ABI 16: K6 + K7 forward of one layer in ONE launch for short dialogues (L <= 128, M <= 3, H <= 100, H % 4 == 0, at most 4 096
+ * (dialogue, modality, 32-row strip) workgroups):  hi = A_hat . z (written out: the backward pass contracts against it; z rows
+ * have stride ldz), then mmdfn_gcnii_layer_fwd's update of the same rows.  Same operands as mmdfn_propagate (block-tile
+ * adjacency, layout arrays) and mmdfn_gcnii_layer_fwd (h0, W, q, m: row stride H; out: row stride ldo; gmask).  Returns -2 when
+ * the shape is not covered: the caller runs the two launches.  (csrc/gcn_small.hip; model_GCN.py:178-189) */
+int mmdfn_prop_layer_fwd(const float* tiles, const float* cross, const float* zin, int ldz, const int32_t* dia_len,
+                         const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int max_len,
+                         const float* h0, const float* W, const float* q, const float* m, float* hi, float* out,
+                         float* gmask, float theta, float alpha, int H, int ldo, float mscale, void* stream);
 int mmdfn_gcnii_layer_bwd(const float* dout, const float* gmask, const float* W, float* dP, float* dhi, float* dh0,
                           float theta, float alpha, int R, int H, int lddo, int acc_h0, void* stream);
 /* the same with a row stride lddhi on dhi (the X operand of the stack's single mmdfn_tile_outer, see mmdfn_lstm_gate_fwd_ld) */

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mmdfn_lstm_gate_takes_planes": [_I, _I],
     "mmdfn_lstm_gate_bwd": [_P] * 13 + [_I] * 4 + [_P],
     "mmdfn_gcnii_layer_fwd": [_P] * 7 + [_F, _F, _I, _I, _I, _F, _P],
+    "mmdfn_prop_layer_fwd": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _F, _P],
     "mmdfn_gcnii_layer_bwd": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _P],
     "mmdfn_gcnii_layer_bwd_ld": [_P] * 6 + [_F, _F, _I, _I, _I, _I, _I, _P],
     "mmdfn_linear": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

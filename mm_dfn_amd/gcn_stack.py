@@ -1,6 +1,7 @@
 """The GCNII "dynamic fusion" stack (reference GCNII_lyc.forward, model_GCN.py:444-488) as ONE autograd node.
 
-Forward = 1 + 3 launches per layer (input stage; per layer: LSTM gate K8, propagate K6, GCNII update K7), backward =
+Forward = 1 + 3 launches per layer (input stage; per layer: LSTM gate K8, propagate K6, GCNII update K7 -- K6 + K7 as ONE
+launch for short dialogues, csrc/gcn_small.hip), backward =
 1 + 3 per layer (K7', K6, K8') + ONE adjacency-gradient contraction for the whole stack (round 5: the layers' propagated
 states and their gradients are column blocks of two (R, nl H) buffers) -- every stage is a fused kernel of
 csrc/gcn_stack.hip / propagate.hip / tile_dot.hip.  Written as a single ``torch.autograd.Function`` with a
@@ -15,10 +16,12 @@ than ROW_LIMIT rows (beyond anything measured: the fused node is ahead of the op
 import math
 
 PRECUT = __import__("os").environ.get("MMDFN_GATE_PRECUT", "1") == "1"     # (0: A/B aid, every workgroup cuts the cell's weights itself)
+FUSE_PROP_LAYER = __import__("os").environ.get("MMDFN_FUSE_PROP_LAYER", "1") == "1"   # (0: A/B aid, propagate and the layer update as two launches)
 
 import torch
 
 from . import _hip, ops
+from .ops_pad import _lay_args
 
 ROW_LIMIT = 131072        # measured to 98 304 rows (cfg5 B = 32): the fused node is 8-9 % ahead of the op-by-op path at every size (round 4)
 # test tap: a list to which every forward of the fused node appends references to its ReLU decisions (h0, the per-layer
@@ -81,7 +84,6 @@ class _GcnStack(torch.autograd.Function):
                 zin = h_new
             else:
                 zin = q
-            hi = ops.propagate_raw(tiles, cross, zin, lay)
             last = i == nl - 1
             if last and use_residue:
                 dst, ldo = out[:, F:], F + H
@@ -91,8 +93,18 @@ class _GcnStack(torch.autograd.Function):
                 dst, ldo = new(R, H), H
             gmask = new(R, H)
             theta = math.log(lamda / (i + 1) + 1)
-            _hip.check(lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(convW[i]), P(q if reason else None), P(ml[i]), P(dst),
-                                                 P(gmask), theta, alpha, R, H, ldo, mscale, st), "mmdfn_gcnii_layer_fwd")
+            # short dialogues: propagate + layer update of a strip of rows in ONE launch (csrc/gcn_small.hip; hi is still written
+            # out for the backward pass); -2 = shape not covered: the two launches
+            hi = new(R, H)
+            rc = lib.mmdfn_prop_layer_fwd(P(tiles), P(cross), P(zin), zin.stride(0), *_lay_args(lay), lay.B, lay.M, lay.N,
+                                          lay.max_len, P(h0), P(convW[i]), P(q if reason else None), P(ml[i]), P(hi), P(dst),
+                                          P(gmask), theta, alpha, H, ldo, mscale, st) if FUSE_PROP_LAYER else -2
+            if rc == -2:
+                hi = ops.propagate_raw(tiles, cross, zin, lay, out=hi)
+                _hip.check(lib.mmdfn_gcnii_layer_fwd(P(hi), P(h0), P(convW[i]), P(q if reason else None), P(ml[i]), P(dst),
+                                                     P(gmask), theta, alpha, R, H, ldo, mscale, st), "mmdfn_gcnii_layer_fwd")
+            else:
+                _hip.check(rc, "mmdfn_prop_layer_fwd")
             rec.update(zin=zin, hi=hi, gmask=gmask, theta=theta)
             layers.append(rec)
             cur = dst

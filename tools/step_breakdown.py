@@ -16,7 +16,7 @@ import sys
 FAMILIES = [
     ("gru_recurrence", r"gru_seq_|gru_tab_"),
     ("weight_gradients", r"gemm_tn"),
-    ("gcn_stack_fused", r"lstm_gate_|gcnii_layer_|gcn_input_|lstm_pointwise|gcnii_combine"),
+    ("gcn_stack_fused", r"lstm_gate_|gcnii_layer_|gcn_input_|lstm_pointwise|gcnii_combine|prop_layer_strip"),
     ("propagate_K6", r"propagate_"),
     ("adjacency_K5_K6b", r"tile_dot|unit_cross|rdeg_cross|scale_tiles|symmetrize|bwd_rowsum|bwd_etile|bwd_ecross|cross_dot|unit_bwd|adj_strip|adj_finish"),
     ("projections_hand_written", r"linear_kernel|linear_split|linear_small|linear_lds|linear2|linear_planes|cut_planes"),

@@ -74,12 +74,12 @@ def inventory(B, L, lengths, D_t, D_a, D_v, nl, P, n_act=2, He=200, d=100, C=6, 
         _cls("input layer backward (dX)", 1, 4.0 * MN * (2 * F + 2 * d), 2.0 * MN * F * d),
         _cls("LSTM gate forward (K8)", nl, 4.0 * MN * 9 * d, 2.0 * MN * 2 * d * 4 * d),
         _cls("LSTM gate backward (K8)", nl, 4.0 * MN * 14 * d, 2.0 * MN * 4 * d * 2 * d),
-        _cls("GCNII layer forward (K7)", nl, 4.0 * MN * 5 * d, 2.0 * MN * 2 * d * d),
+        # short dialogues: propagate + layer update of a strip in ONE launch (csrc/gcn_small.hip)
+        _cls("propagate + GCNII layer forward (K6 + K7, one launch)", nl, 4.0 * MN * 6 * d + 4.0 * nnz, 2.0 * MN * 2 * d * d + 2.0 * d * nnz),
         _cls("GCNII layer backward (K7)", nl, 4.0 * MN * 6 * d, 2.0 * MN * 2 * d * d),
     ]
     k6_b = 4.0 * nnz + 8.0 * MN * d
     fam["propagate_K6"] = [
-        _cls("propagate forward (A.H)", nl, k6_b, 2.0 * d * nnz),
         _cls("propagate backward (dH = A.dO)", nl, k6_b, 2.0 * d * nnz),
     ]
     tiles = sum(M * l * l for l in lengths)
