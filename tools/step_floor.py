@@ -105,7 +105,7 @@ def inventory(B, L, lengths, D_t, D_a, D_v, nl, P, n_act=2, He=200, d=100, C=6, 
     ]
     fam["encoder_glue"] = [
         _cls("party gather / scatter-combine, forward + backward (4 launches)", 4, 4.0 * (RP * He + R * He) * 1.0),
-        _cls("dropout masks / flags / column sums (4 launches)", 4, 4.0 * R * He),
+        _cls("dropout flags, the forward mask of the GRU inter-layer dropout (2 launches)", 2, 4.0 * R * He),
     ]
     fam["head_and_loss"] = [
         _cls("head forward (dropout, ReLU, smax_fc, log-softmax)", 1, 4.0 * N * (900 + C)),
