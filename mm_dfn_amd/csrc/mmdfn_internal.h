@@ -63,9 +63,9 @@ __device__ __forceinline__ float half_sum32(float v) {
 // more than 64 KB of dynamic LDS per workgroup needs the attribute raised once per kernel (gfx950: 160 KB per CU)
 template <class Kern>
 inline int mmdfn_allow_big_lds(Kern kern) {
-    static thread_local const void* done[8] = {nullptr};
+    static thread_local const void* done[48] = {nullptr};      // (one table per kernel SIGNATURE: kernels of one type share it)
     const void* key = reinterpret_cast<const void*>(kern);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 48; ++i)
         if (done[i] == key) return 0;
     // (a little below the 160 KB of a CU: kernels may also hold a few hundred bytes of static LDS)
     hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
@@ -73,7 +73,7 @@ inline int mmdfn_allow_big_lds(Kern kern) {
         (void)hipGetLastError();      // do not leave the error for the next launch check to find
         return (int)e;
     }
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 48; ++i)
         if (done[i] == nullptr) { done[i] = key; break; }
     return 0;
 }
