@@ -93,31 +93,43 @@ constexpr int NWS = 26;      // 26 slots x 256 threads x 16 B = 104 KB >= every 
 template <bool KMAJOR>
 struct WeightStager {
     float4 v[NWS];
+    // slot e of a thread holds element i = threadIdx.x + 256 e = (row r, 16-byte unit j) of the slice; (r, j) are stepped from
+    // slot to slot (256 = qa inner + qb) instead of divided out per slot: a division by a runtime value is ~30 instructions,
+    // and 2 x 26 of them were 1 500 instructions in front of every stack kernel's first MFMA
     __device__ __forceinline__ void issue(const float* __restrict__ W, int ldsrc, int n0, int ncols, int K) {
         const int inner = KMAJOR ? (ncols >> 2) : (K >> 2);       // 16-byte slots per source row
         const int total = KMAJOR ? K * inner : ncols * inner;
+        const int qa = 256 / inner, qb = 256 - qa * inner;
+        int r = threadIdx.x / inner, j = threadIdx.x - r * inner;
 #pragma unroll
         for (int e = 0; e < NWS; ++e) {
             const int i = threadIdx.x + 256 * e;
-            const int r = i / inner, j = i - r * inner;
             const float* src = KMAJOR ? W + (int64_t)r * ldsrc + n0 + 4 * j : W + (int64_t)(n0 + r) * ldsrc + 4 * j;
             v[e] = (i < total) ? ld4(src) : zero4();
+            r += qa;
+            j += qb;
+            if (j >= inner) { j -= inner; ++r; }
         }
     }
     __device__ __forceinline__ void commit(float* sW, int ldw, int ncols, int K) const {
         const int inner = KMAJOR ? (ncols >> 2) : (K >> 2);
         const int total = KMAJOR ? K * inner : ncols * inner;
+        const int qa = 256 / inner, qb = 256 - qa * inner;
+        int r = threadIdx.x / inner, j = threadIdx.x - r * inner;
 #pragma unroll
         for (int e = 0; e < NWS; ++e) {
             const int i = threadIdx.x + 256 * e;
-            if (i >= total) continue;
-            const int r = i / inner, j = i - r * inner;
-            if (KMAJOR) {                                         // r = k, columns 4j .. 4j+3
-                float* d = sW + (4 * j) * ldw + r;
-                d[0] = v[e].x; d[ldw] = v[e].y; d[2 * ldw] = v[e].z; d[3 * ldw] = v[e].w;
-            } else {                                              // r = column, k = 4j
-                st4(sW + r * ldw + 4 * j, v[e]);
+            if (i < total) {
+                if (KMAJOR) {                                         // r = k, columns 4j .. 4j+3
+                    float* d = sW + (4 * j) * ldw + r;
+                    d[0] = v[e].x; d[ldw] = v[e].y; d[2 * ldw] = v[e].z; d[3 * ldw] = v[e].w;
+                } else {                                              // r = column, k = 4j
+                    st4(sW + r * ldw + 4 * j, v[e]);
+                }
             }
+            r += qa;
+            j += qb;
+            if (j >= inner) { j -= inner; ++r; }
         }
         zero_pads(sW, ncols, ldw, K);
     }
