@@ -74,11 +74,17 @@ __host__ __device__ inline int lds_stride(int K) {
     return ld;
 }
 
+// i / d for the small non-negative indices of the staging loops (i < 2^21 / d) without the ~30-instruction integer division by a
+// runtime value: (i + 0.5) / d is at least 0.5 / d away from an integer, far more than the float product's rounding error.
+// inv = 1.0f / (float)d, computed once per kernel.
+__device__ __forceinline__ int qdiv(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
+
 // zero columns K .. ld-1 of `nrows` LDS rows (addresses nobody else writes: no barrier needed against the data stores)
 __device__ __forceinline__ void zero_pads(float* base, int nrows, int ld, int K) {
     const int np4 = (ld - K) >> 2;
+    const float rnp4 = 1.0f / (float)(np4 > 0 ? np4 : 1);
     for (int i = threadIdx.x; i < nrows * np4; i += 256) {
-        const int r = i / np4, j = i - r * np4;
+        const int r = qdiv(i, rnp4), j = i - r * np4;
         st4(base + r * ld + K + 4 * j, zero4());
     }
 }
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
     wst.issue(W0, F, 0, H, F);
     const int nrb = (R + RB - 1) / RB;
     const int F4 = F >> 2, H4 = H >> 2;
+    const float rF4 = 1.0f / (float)F4, rH4 = 1.0f / (float)H4;
     int wrow0[2];
     const int nt = wave_tiles<2>(wrow0, (H + 15) >> 4);
     constexpr int NS = 4;                     // float4 slots per thread per block (16 * F / 4 / 256 <= 4 for F <= 256)
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / F4, k = (i - r * F4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rF4), k = (i - r * F4) * 4, row = rb * RB + r;
             const bool ok = i < RB * F4 && row < R;
             rx[s] = ok ? ld4(x + (int64_t)row * F + k) : zero4();
             rm[s] = (ok && mx) ? ld4(mx + (int64_t)row * F + k) : one4();      // raw flags: arithmetic on a value just loaded would wait for it here
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
             if (i >= RB * F4) continue;
-            const int r = i / F4, k = (i - r * F4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rF4), k = (i - r * F4) * 4, row = rb * RB + r;
             const float4 v = mul4(rx[s], scl4(rm[s], mx ? ms : 1.0f));
             st4(dst + r * ldw + k, v);
             if (row < R) st4_nt(xd + (int64_t)row * ldxd + k, v);       // (read again by the weight-gradient batch only)
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < NE; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             em[s] = (ok && m0) ? ld4(m0 + (int64_t)row * H + n) : one4();
             eb[s] = (ok && b0) ? ld4(b0 + n) : zero4();
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256) void gcn_input_fwd_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < NE; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             if (i >= RB * H4 || row >= R) continue;
             float4 v = add4(ld4(sP + r * ldp + n), eb[s]);
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -304,6 +311,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
     wst.issue(W0, F, 0, F, H);
     const int nrb = (R + RB - 1) / RB;
     const int H4 = H >> 2, F4 = F >> 2;
+    const float rF4 = 1.0f / (float)F4, rH4 = 1.0f / (float)H4;
     int wrow0[4];
     const int nt = wave_tiles<4>(wrow0, (F + 15) >> 4);
     constexpr int NS = 2;                     // 16 * H / 4 / 256 <= 2 for H <= 128
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             const int64_t o = (int64_t)row * H + k;
             rd[s] = (ok && dcur0) ? ld4(dcur0 + o) : zero4();
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
             if (i >= RB * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             float4 v = add4(mul4(rd[s], scl4(rmk[s], m0 ? ms : 1.0f)), rdh[s]);
             v.x = rh0[s].x > 0.f ? v.x : 0.f; v.y = rh0[s].y > 0.f ? v.y : 0.f;
             v.z = rh0[s].z > 0.f ? v.z : 0.f; v.w = rh0[s].w > 0.f ? v.w : 0.f;
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < NE; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / F4, n = (i - r * F4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rF4), n = (i - r * F4) * 4, row = rb * RB + r;
             const bool ok = i < RB * F4 && row < R;
             ed[s] = (ok && dxd) ? ld4(dxd + (int64_t)row * lddxd + n) : zero4();
             em[s] = (ok && mx) ? ld4(mx + (int64_t)row * F + n) : one4();
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void gcn_input_bwd_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < NE; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / F4, n = (i - r * F4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rF4), n = (i - r * F4) * 4, row = rb * RB + r;
             if (i >= RB * F4 || row >= R) continue;
             st4(dx + (int64_t)row * F + n, mul4(add4(ld4(sP + r * ldp + n), ed[s]), scl4(em[s], mx ? ms : 1.0f)));
         }
@@ -392,6 +400,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
     wst.issue(W, H, 0, H, K);
     const int nrb = (R + RB - 1) / RB;
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     int wrow0[2];
     const int nt = wave_tiles<2>(wrow0, (H + 15) >> 4);
     constexpr int NS = 2;                     // per source: 16 * H / 4 / 256 <= 2
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             ra[s] = ok ? ld4(hi + (int64_t)row * H + k) : zero4();
             rb_[s] = ok ? ld4(h0 + (int64_t)row * H + k) : zero4();
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
             if (i >= RB * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4;
             st4(dst + r * ldw + k, ra[s]);
             st4(dst + r * ldw + H + k, rb_[s]);
         }
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             eq[s] = (ok && q) ? ld4(q + (int64_t)row * H + n) : zero4();
             em[s] = (ok && m) ? ld4(m + (int64_t)row * H + n) : one4();
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_fwd_kernel(const float* __res
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             if (i >= RB * H4 || row >= R) continue;
             const float4 p = ld4(sP + r * ldp + n), vh = ld4(A + r * ldw + n), v0 = ld4(A + r * ldw + H + n);
             const float4 ems = scl4(em[s], m ? ms : 1.0f);
@@ -481,6 +490,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
     wst.issue(W, H, 0, N, H);
     const int nrb = (R + RB - 1) / RB;
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     int wrow0[4];
     const int nt = wave_tiles<4>(wrow0, (N + 15) >> 4);
     constexpr int NS = 2;
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             rd[s] = ok ? ld4(dout + (int64_t)row * lddo + k) : zero4();
             rg[s] = ok ? ld4(gmask + (int64_t)row * H + k) : zero4();
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
             if (i >= RB * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const float4 v = scl4(mul4(rd[s], rg[s]), theta);
             st4(dst + r * ldw + k, v);
             if (row < R) st4_nt(dP + (int64_t)row * H + k, v);
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             eo[s] = (acc_h0 && i < RB * H4 && row < R) ? ld4(dh0 + (int64_t)row * H + n) : zero4();
         }
         f32x4 acc[4];
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(256) void gcnii_layer_bwd_kernel(const float* __res
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             if (i >= RB * H4 || row >= R) continue;
             const float4 dp = ld4(A + r * ldw + n);
             st4(dhi + (int64_t)row * lddhi + n, fma4(dp, c1, ld4(sP + r * ldp + n)));
@@ -568,6 +578,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_fwd_ws_kernel(const float* __
     float* sP = sA + 2 * RB * ldw;            // [2][16][ldp]
     const int nrb = (R + RB - 1) / RB;
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     const int tid = threadIdx.x & 255;
     const bool producer = threadIdx.x >= 256;
     const int first = blockIdx.x, stride = gridDim.x;
@@ -577,7 +588,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_fwd_ws_kernel(const float* __
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             ra[s] = ok ? ld4(hi + (int64_t)row * H + k) : zero4();
             rb_[s] = ok ? ld4(h0 + (int64_t)row * H + k) : zero4();
@@ -588,7 +599,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_fwd_ws_kernel(const float* __
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
             if (i >= RB * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4;
             st4(dst + r * ldw + k, ra[s]);
             st4(dst + r * ldw + H + k, rb_[s]);
         }
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_fwd_ws_kernel(const float* __
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             eq[s] = (ok && q) ? ld4(q + (int64_t)row * H + n) : zero4();
             em[s] = (ok && m) ? ld4(m + (int64_t)row * H + n) : one4();
@@ -607,7 +618,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_fwd_ws_kernel(const float* __
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             if (i >= RB * H4 || row >= R) continue;
             const float4 p = ld4(P + r * ldp + n), vh = ld4(A + r * ldw + n), v0 = ld4(A + r * ldw + H + n);
             const float4 ems = scl4(em[s], m ? ms : 1.0f);
@@ -676,6 +687,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_bwd_ws_kernel(const float* __
     float* sP = sA + 2 * RB * ldw;            // [2][16][ldp]
     const int nrb = (R + RB - 1) / RB;
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     const int tid = threadIdx.x & 255;
     const bool producer = threadIdx.x >= 256;
     const int first = blockIdx.x, stride = gridDim.x;
@@ -685,7 +697,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_bwd_ws_kernel(const float* __
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             rd[s] = ok ? ld4(dout + (int64_t)row * lddo + k) : zero4();
             rg[s] = ok ? ld4(gmask + (int64_t)row * H + k) : zero4();
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_bwd_ws_kernel(const float* __
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
             if (i >= RB * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const float4 v = scl4(mul4(rd[s], rg[s]), theta);
             st4(dst + r * ldw + k, v);
             if (row < R) st4_nt(dP + (int64_t)row * H + k, v);
@@ -706,7 +718,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_bwd_ws_kernel(const float* __
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             eo[s] = (acc_h0 && i < RB * H4 && row < R) ? ld4(dh0 + (int64_t)row * H + n) : zero4();
         }
     };
@@ -716,7 +728,7 @@ __global__ __launch_bounds__(512) void gcnii_layer_bwd_ws_kernel(const float* __
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
-            const int r = i / H4, n = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), n = (i - r * H4) * 4, row = rb * RB + r;
             if (i >= RB * H4 || row >= R) continue;
             const float4 dp = ld4(A + r * ldw + n);
             st4(dhi + (int64_t)row * lddhi + n, fma4(dp, c1, ld4(P + r * ldp + n)));
@@ -787,6 +799,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
     // weights: LDS row (gate, ul) <- [W_ih | W_hh] row gate * H + u0 + ul; rows of missing units are zero.  All loads
     // of the slice (<= 13 + 13 16-byte slots per thread) go out at once, the first row block's right behind them.
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     constexpr int NW1 = 13;                            // 4 gates x 32 units x (H / 4 <= 25) / 256 threads
     float4 vi[NW1], vh[NW1];
     {
@@ -794,7 +807,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < NW1; ++e) {
             const int i = threadIdx.x + 256 * e;
-            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            const int rowl = qdiv(i, rH4), k = (i - rowl * H4) * 4;
             const int gate = rowl / UB, ul = rowl - gate * UB;
             const bool ok = i < total && ul < nu;
             const int64_t src = (int64_t)(gate * H + u0 + ul) * H + k;
@@ -811,7 +824,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             rq[s] = ok ? ld4(q + (int64_t)row * H + k) : zero4();
             rh[s] = (ok && h) ? ld4(h + (int64_t)row * ldh + k) : zero4();
@@ -822,7 +835,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
         for (int s = 0; s < NS; ++s) {
             const int i = threadIdx.x + 256 * s;
             if (i >= RB * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4;
             st4(dst + r * ldw + k, rq[s]);
             if (h) st4(dst + r * ldw + H + k, rh[s]);
         }
@@ -834,7 +847,7 @@ __global__ __launch_bounds__(256) void lstm_gate_fwd_kernel(const float* __restr
         for (int e = 0; e < NW1; ++e) {
             const int i = threadIdx.x + 256 * e;
             if (i >= total) continue;
-            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            const int rowl = qdiv(i, rH4), k = (i - rowl * H4) * 4;
             st4(sW + rowl * ldw + k, vi[e]);                       // rowl = gate * UB + ul
             if (h) st4(sW + rowl * ldw + H + k, vh[e]);
         }
@@ -934,13 +947,14 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
     const int nt = 16 * w < ncols ? 1 : 0;
     const bool writer = blockIdx.y == 0;
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     constexpr int NS = 2;                              // 16 * H / 4 / 256 <= 2 for H <= 128
     float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdh2[NS], rdc[NS];
     auto issue = [&](int rb) {
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             const int i = threadIdx.x + 256 * s_;
-            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), u = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             const int64_t o = (int64_t)row * H + u;
             const float* gr = gates + (int64_t)row * 4 * H + u;
@@ -960,7 +974,7 @@ __global__ __launch_bounds__(256) void lstm_gate_bwd_kernel(const float* __restr
         for (int s_ = 0; s_ < NS; ++s_) {
             const int i = threadIdx.x + 256 * s_;
             if (i >= RB * H4) continue;
-            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), u = (i - r * H4) * 4, row = rb * RB + r;
             float4 di, df, dg, dO, dcp;
 #define GB1(F)                                                                      \
     {                                                                               \
@@ -1059,6 +1073,7 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
     const int nyb = gridDim.y, yb = blockIdx.y;
     const bool wr_i = (0 % nyb) == yb, wr_f = (1 % nyb) == yb, wr_g = (2 % nyb) == yb, wr_o = (3 % nyb) == yb, wr_c = yb == nyb - 1;
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     // ---- prologue: all 512 threads park the weight slice (k-contiguous rows sW[n][k] from the (K, H) parameter); all of a
     // thread's loads (<= 13 slots) go out before its first LDS store
     {
@@ -1082,9 +1097,10 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
             d[0] = v[e].x; d[ldw] = v[e].y; d[2 * ldw] = v[e].z; d[3 * ldw] = v[e].w;
         }
         const int np4 = (ldw - K) >> 2;                // zero pads of the weight rows and of both A buffers; missing columns
-        for (int i = threadIdx.x; i < ncols * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sW + r * ldw + K + 4 * j, zero4()); }
+        const float rnp4 = 1.0f / (float)(np4 > 0 ? np4 : 1);
+        for (int i = threadIdx.x; i < ncols * np4; i += 512) { const int r = qdiv(i, rnp4), j = i - r * np4; st4(sW + r * ldw + K + 4 * j, zero4()); }
         for (int i = threadIdx.x; i < (CBW - ncols) * (ldw >> 2); i += 512) st4(sW + ncols * ldw + 4 * i, zero4());
-        for (int i = threadIdx.x; i < 2 * RB * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sA + r * ldw + K + 4 * j, zero4()); }
+        for (int i = threadIdx.x; i < 2 * RB * np4; i += 512) { const int r = qdiv(i, rnp4), j = i - r * np4; st4(sA + r * ldw + K + 4 * j, zero4()); }
     }
     constexpr int NS = 2;                              // 16 * H / 4 / 256 <= 2 for H <= 128
     float4 rgi[NS], rgf[NS], rgg[NS], rgo[NS], rcn[NS], rcp[NS], rdh[NS], rdh2[NS], rdc[NS];
@@ -1092,7 +1108,7 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             const int i = tid + 256 * s_;
-            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), u = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = !(ABL & 2) && i < RB * H4 && row < R;
             const int64_t o = (int64_t)row * H + u;
             const float* gr = gates + (int64_t)row * 4 * H + u;
@@ -1131,7 +1147,7 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
 #undef GB1
             odi[s_] = di; odf[s_] = df; odg[s_] = dg; odo[s_] = dO; odc[s_] = dcp;
             if (i >= RB * H4) continue;
-            const int r = i / H4, u = (i - r * H4) * 4;
+            const int r = qdiv(i, rH4), u = (i - r * H4) * 4;
             float* sp = dst + r * ldw + u;               // rows past R carry zeros (their loads were zeroed)
             st4(sp, di); st4(sp + H, df); st4(sp + 2 * H, dg); st4(sp + 3 * H, dO);
         }
@@ -1144,7 +1160,7 @@ __global__ __launch_bounds__(512) void lstm_gate_bwd_ws_kernel(const float* __re
         for (int s_ = 0; s_ < NS; ++s_) {
             const int i = tid + 256 * s_;
             if (i >= RB * H4) continue;
-            const int r = i / H4, u = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), u = (i - r * H4) * 4, row = rb * RB + r;
             if (row >= R) continue;
             float* d = dG + (int64_t)row * 4 * H + u;
             if (wr_i) st4_nt(d, odi[s_]);
@@ -1280,6 +1296,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
     const int u0 = blockIdx.y * UB;
     const int nu = min(UB, H - u0);
     const int H4 = H >> 2;
+    const float rH4 = 1.0f / (float)H4;
     const int tid = threadIdx.x & 255;
     const bool producer = threadIdx.x >= 256;
     // ---- prologue (all 512 threads): weight rows (gate, ul) <- [W_ih | W_hh] row gate * H + u0 + ul; missing units: zeros.
@@ -1292,7 +1309,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < NW2; ++e) {
             const int i0 = threadIdx.x + 512 * e, i = i0 < total ? i0 : total - 1;
-            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            const int rowl = qdiv(i, rH4), k = (i - rowl * H4) * 4;
             const int gate = rowl / UB, ul = rowl - gate * UB;
             const int64_t src = (int64_t)(gate * H + u0 + (ul < nu ? ul : nu - 1)) * H + k;
             vi[e] = ld4(Wih + src);
@@ -1302,14 +1319,15 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
         for (int e = 0; e < NW2; ++e) {
             const int i = threadIdx.x + 512 * e;
             if (i >= total) continue;
-            const int rowl = i / H4, k = (i - rowl * H4) * 4;
+            const int rowl = qdiv(i, rH4), k = (i - rowl * H4) * 4;
             const int ul = rowl - (rowl / UB) * UB;
             st4(sW + rowl * ldw + k, ul < nu ? vi[e] : zero4());
             if (h) st4(sW + rowl * ldw + H + k, ul < nu ? vh[e] : zero4());
         }
         const int np4 = (ldw - K) >> 2;
-        for (int i = threadIdx.x; i < 4 * UB * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sW + r * ldw + K + 4 * j, zero4()); }
-        for (int i = threadIdx.x; i < 2 * RB * np4; i += 512) { const int r = i / np4, j = i - r * np4; st4(sA + r * ldw + K + 4 * j, zero4()); }
+        const float rnp4 = 1.0f / (float)(np4 > 0 ? np4 : 1);
+        for (int i = threadIdx.x; i < 4 * UB * np4; i += 512) { const int r = qdiv(i, rnp4), j = i - r * np4; st4(sW + r * ldw + K + 4 * j, zero4()); }
+        for (int i = threadIdx.x; i < 2 * RB * np4; i += 512) { const int r = qdiv(i, rnp4), j = i - r * np4; st4(sA + r * ldw + K + 4 * j, zero4()); }
     }
     const int nrb = (R + RB - 1) / RB;
     constexpr int NS = 2;
@@ -1318,7 +1336,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
-            const int r = i / H4, k = (i - r * H4) * 4, row = rb * RB + r;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4, row = rb * RB + r;
             const bool ok = i < RB * H4 && row < R;
             rq[s] = ok ? ld4(q + (int64_t)row * H + k) : zero4();
             rh[s] = (ok && h) ? ld4(h + (int64_t)row * ldh + k) : zero4();
@@ -1329,7 +1347,7 @@ __global__ __launch_bounds__(512) void lstm_gate_fwd_ws_kernel(const float* __re
         for (int s = 0; s < NS; ++s) {
             const int i = tid + 256 * s;
             if (i >= RB * H4) continue;
-            const int r = i / H4, k = (i - r * H4) * 4;
+            const int r = qdiv(i, rH4), k = (i - r * H4) * 4;
             st4(dst + r * ldw + k, rq[s]);
             if (h) st4(dst + r * ldw + H + k, rh[s]);
         }
