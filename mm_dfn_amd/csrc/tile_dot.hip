@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void tile_dot_v2_kernel(
     const float* __restrict__ X, const float* __restrict__ Y, float* __restrict__ out_tiles,
     float* __restrict__ out_aux, float* __restrict__ deg, const int32_t* __restrict__ dia_len,
     const int32_t* __restrict__ row_start, const int64_t* __restrict__ tile_base, int B, int M, int N, int K,
-    int ldx, int ldy, int max_rb, int accumulate, float* __restrict__ dcross, int tile_blocks) {
+    int ldx, int ldy, int max_rb, int accumulate, float* __restrict__ dcross, int tile_blocks, int qsplit) {
     constexpr int BM = 64;
     constexpr int LDP = 68;                       // patch row stride (floats), 16-byte aligned rows
     __shared__ __attribute__((aligned(16))) float patch[4][16 * LDP];
@@ -180,14 +180,18 @@ __global__ __launch_bounds__(256) void tile_dot_v2_kernel(
         cross_dot_block<3, KC>((int)blockIdx.x - tile_blocks, X, Y, dcross, M, N, K, ldx, ldy, accumulate);
         return;
     }
-    const int Rd = M * max_rb;
+    // qsplit (EPI 0 only): the column tiles of a row block are dealt to qsplit workgroups in groups of four -- a wave that sweeps
+    // all seven tiles of a 110-column tile row alone is a serial chain of seven operand round trips (96 workgroups at cfg2)
+    const int Rd = M * max_rb * qsplit;
     const int bid = blockIdx.x;
     const int yq = bid >> 3;
     const int i = (yq / Rd) * 8 + (bid & 7);
     if (i >= B) return;
     const int rho = yq % Rd;
-    const int m = rho / max_rb;
-    const int rb = rho - m * max_rb;
+    const int m = rho / (max_rb * qsplit);
+    const int rq = rho - m * (max_rb * qsplit);
+    const int rb = rq / qsplit;
+    const int chunk = rq - rb * qsplit;
     const int L = dia_len[i];
     const int r0 = rb * BM;
     if (r0 >= L) return;
@@ -247,8 +251,10 @@ __global__ __launch_bounds__(256) void tile_dot_v2_kernel(
         _Pragma("unroll") for (int r = 0; r < 4; ++r) pw[(4 * g + r) * LDP + 16 * (SLOT) + fi] = acc[r]; \
     } while (0)
 
-    load_b(0, 0);
-    for (int q0t = 0; q0t < nqt; q0t += 4) {
+    if (4 * chunk >= nqt) return;                  // (no barriers below)
+    load_b(0, 4 * chunk);
+    for (int q0t = 4 * chunk; q0t < nqt; q0t += 4 * qsplit) {
+        if (qsplit > 1 && q0t != 4 * chunk) load_b(0, q0t);      // (the next group of this chunk is not the neighbouring tile)
         TD_TILE(0, q0t, 0);
         if (q0t + 1 < nqt) TD_TILE(1, q0t + 1, 1);
         if (q0t + 2 < nqt) TD_TILE(0, q0t + 2, 2);
@@ -308,14 +314,19 @@ int launch_v2(const float* X, const float* Y, float* out_tiles, float* out_aux, 
               const int32_t* row_start, const int64_t* tile_base, int B, int M, int N, int K, int ldx, int ldy,
               int max_len, int epi, int accumulate, hipStream_t s, float* dcross) {
     const int max_rb = (max_len + 63) / 64;
-    const int tile_blocks = ((B + 7) / 8) * 8 * M * max_rb;
+    int qsplit = 1;
+    if (epi == 0 && max_len > 64 && ((B + 7) / 8) * 8 * M * max_rb <= 512) qsplit = 2;      // few row blocks: two workgroups per row block
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_TILEDOT_QSPLIT")) { const int v = atoi(e); if (epi == 0 && (v == 1 || v == 2)) qsplit = v; }
+#endif
+    const int tile_blocks = ((B + 7) / 8) * 8 * M * max_rb * qsplit;
     if (epi == 0)
         hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 0>), dim3(tile_blocks + (dcross ? (N + 15) / 16 : 0)), dim3(256), 0, s, X, Y,
                            out_tiles, out_aux, deg, dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate,
-                           dcross, tile_blocks);
+                           dcross, tile_blocks, qsplit);
     else
         hipLaunchKernelGGL((tile_dot_v2_kernel<KC, 1>), dim3(tile_blocks), dim3(256), 0, s, X, Y, out_tiles, out_aux, deg,
-                           dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate, nullptr, tile_blocks);
+                           dia_len, row_start, tile_base, B, M, N, K, ldx, ldy, max_rb, accumulate, nullptr, tile_blocks, 1);
     MMDFN_CHECK_LAUNCH();
     return 0;
 }
