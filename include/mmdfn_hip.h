@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 16: 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 17: 16 + the GRU backward launch's weight-gradient riders mmdfn_wgrad_riders_{stage,staged,flush}; 16 = 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -482,6 +482,24 @@ int mmdfn_gemm_tn_batch_ext(int nseg, const float* const* A, const float* const*
                             const float* const* ext_colpart, float* const* ext_C, float* const* ext_colsum, const int* ext_M,
                             const int* ext_N, const int* ext_ldc, const int* ext_splits, const int* ext_accumulate,
                             void* stream);
+
+/* Weight-gradient RIDERS of the GRU backward recurrence launch (ABI 17).  The backward recurrence of nn.GRU (reference
+ * model.py:866-868: autograd of the context / party GRUs) keeps one CU per sequence busy for ~T x 0.75 us and leaves the other
+ * CUs idle (IEMOCAP batch of 16: 160 of 256).  mmdfn_wgrad_riders_stage takes the arguments of mmdfn_gemm_tn_batch, plans the
+ * batch and allocates its slabs exactly as that call would, but -- when the batch runs on the bf16-piece form, has at most 16
+ * segments and nothing is staged yet -- does NOT launch it: the next mmdfn_gru_seq_bwd call on a one-sequence-per-workgroup
+ * launch runs the batch's tiles as extra workgroups of the recurrence launch (never on a CU that holds a recurrence: the
+ * launch's LDS request keeps every CU to one workgroup) and issues the slab reduction behind it.  A batch that cannot ride is
+ * launched by the stage call itself.  mmdfn_wgrad_riders_staged: 1 while a batch waits; mmdfn_wgrad_riders_flush launches a
+ * waiting batch the ordinary way (call it where no GRU backward launch will follow).  The operands and the workspace must stay
+ * valid until the launch that consumes them has been issued on `stream` (the same stream for all three calls).  Results are
+ * those of mmdfn_gemm_tn_batch bit for bit (same tiles, same slab order). */
+int mmdfn_wgrad_riders_stage(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                             const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                             float* const* colsum, float* const* colsum2, const int* M, const int* N, const int* ldc,
+                             const int* accumulate, float* workspace, void* stream);
+int mmdfn_wgrad_riders_staged(void);
+int mmdfn_wgrad_riders_flush(void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused Adam step over flat fp32 buffers (replaces torch.optim.Adam(lr, weight_decay=l2).step(),

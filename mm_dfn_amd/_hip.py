@@ -66,6 +66,9 @@ SIGNATURES = {
     "mmdfn_gemm_tn_grouped": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_gemm_tn_batch_workspace": [_I, _P, _P, _I, _P, _P],
     "mmdfn_gemm_tn_batch": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_wgrad_riders_stage": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mmdfn_wgrad_riders_staged": [],
+    "mmdfn_wgrad_riders_flush": [_P],
     "mmdfn_gemm_tn_batch_ext": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_head_bwd_groups": [],
@@ -92,7 +95,7 @@ SIGNATURES = {
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class HipLibraryError(RuntimeError):

@@ -829,10 +829,30 @@ struct TnExt {
     const int *M, *N, *ldc, *splits, *accumulate;
 };
 
+// A batch staged for the GRU backward launch (see mmdfn_internal.h): its tile table and its reduction table.
+struct RiderPlan {
+    bool valid = false;
+    TnSplitSegs tq;
+    TnOuts oq;
+    int nblk = 0;
+};
+static RiderPlan g_rider;
+
+const TnSplitSegs* mmdfn_riders_pending() { return g_rider.valid ? &g_rider.tq : nullptr; }
+
+int mmdfn_riders_launched(hipStream_t s) {
+    if (!g_rider.valid) return -1;
+    g_rider.valid = false;
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(g_rider.nblk), dim3(256), 0, s, g_rider.oq);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
 static int tn_batch_impl(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
                          const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
                          float* const* colsum, float* const* colsum2, const int* M, const int* N,
-                         const int* ldc, const int* accumulate, float* workspace, const TnExt& ext, void* stream) {
+                         const int* ldc, const int* accumulate, float* workspace, const TnExt& ext, void* stream,
+                         bool stage = false) {
     if (nseg < 0 || nseg > TN_MAXSEG || nout < 0 || nout + ext.n > TN_MAXOUT || (nseg == 0) != (nout == 0) ||
         (nseg == 0 && ext.n == 0)) return -1;
     for (int e = 0; e < ext.n; ++e)
@@ -944,6 +964,13 @@ static int tn_batch_impl(int nseg, const float* const* A, const float* const* B,
             tq.M[k] = tq.N[k] = 0; tq.wide[k] = 0;
             tq.wg_prefix[k + 1] = tq.wg_prefix[nseg];
         }
+        if (stage && nseg <= MMDFN_RIDER_MAXSEG && !g_rider.valid) {
+            g_rider.tq = tq;
+            g_rider.oq = oq;
+            g_rider.nblk = oq.blk_prefix[ntot];
+            g_rider.valid = true;
+            return 0;
+        }
         if (int e = mmdfn_launch_gemm_tn_split(tq, st)) return e;
         hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(oq.blk_prefix[ntot]), dim3(256), 0, st, oq);
         MMDFN_CHECK_LAUNCH();
@@ -1022,6 +1049,27 @@ extern "C" int mmdfn_gemm_tn_batch(int nseg, const float* const* A, const float*
     if (nseg < 1 || nout < 1) return -1;
     const TnExt none = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return tn_batch_impl(nseg, A, B, R, lda, ldb, bshift, out, nout, C, colsum, colsum2, M, N, ldc, accumulate, workspace, none, stream);
+}
+
+// The batch is planned as usual but NOT launched when it can ride in the next GRU backward launch (bf16-piece form, at most
+// MMDFN_RIDER_MAXSEG segments, nothing staged yet); otherwise it is launched now.  mmdfn_wgrad_riders_flush launches whatever is
+// still staged (the GRU launch that followed was of another kind, or there was none).
+extern "C" int mmdfn_wgrad_riders_stage(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,
+                                        const int* ldb, const int* bshift, const int* out, int nout, float* const* C,
+                                        float* const* colsum, float* const* colsum2, const int* M, const int* N,
+                                        const int* ldc, const int* accumulate, float* workspace, void* stream) {
+    if (nseg < 1 || nout < 1) return -1;
+    const TnExt none = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return tn_batch_impl(nseg, A, B, R, lda, ldb, bshift, out, nout, C, colsum, colsum2, M, N, ldc, accumulate, workspace, none, stream,
+                         true);
+}
+
+extern "C" int mmdfn_wgrad_riders_staged() { return g_rider.valid ? 1 : 0; }
+
+extern "C" int mmdfn_wgrad_riders_flush(void* stream) {
+    if (!g_rider.valid) return 0;
+    if (int e = mmdfn_launch_gemm_tn_split(g_rider.tq, (hipStream_t)stream)) { g_rider.valid = false; return e; }
+    return mmdfn_riders_launched((hipStream_t)stream);
 }
 
 extern "C" int mmdfn_gemm_tn_batch_ext(int nseg, const float* const* A, const float* const* B, const int* R, const int* lda,

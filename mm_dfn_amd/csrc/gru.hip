@@ -17,6 +17,7 @@
 //
 // Gate order r, z, n;  n = tanh(gi_n + r * (W_hn h + b_hn));  h = (1-z) n + z h_prev.
 #include "mmdfn_internal.h"
+#include "gemm_tn_split_body.h"
 #include "../../include/mmdfn_hip.h"
 #include <stdlib.h>
 
@@ -1227,8 +1228,11 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 // recurrent gradient is cut (and, for a direction that started from the all-padding sequence's state, the gradient wrt that
 // start state is written to dhinit: one more matvec + exchange per segment); the (t, row) positions a truncated / silent row
 // never visited get zero dgi / dgh afterwards (they are operands of the weight-gradient contractions and column sums).
-template <int NW, int GRP, int SEG>
-__global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G) {
+// The body of one workgroup (bx, by) = (sequence slot, direction).  DYN = false: the kernel's own static LDS; DYN = true: the
+// arrays are carved from `dyn` (the launch's dynamic LDS) -- the form the rider launch needs, whose LDS is shared with the
+// weight-gradient tiles of the rider workgroups (gru_seq_bwd_riders_kernel).
+template <int NW, int GRP, int SEG, bool DYN>
+__device__ __forceinline__ void gru_bwd_kpart_body(const BwdGroups& G, const int bx, const int by, unsigned char* dyn) {
     constexpr int NTK = 64 * NW;
     constexpr int JPW = (3 * GH + NW - 1) / NW;     // gate rows per wave (75 / 38)
     constexpr int NGR = (JPW + 63) / 64;            // gate rows per lane in the gate stage (2 / 1)
@@ -1236,11 +1240,26 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     constexpr int IN4 = 6 * GH / 4;     // staged per step: dy (GH) | r z n ghn (4 GH) | h_prev (GH)
     constexpr int OUT4 = 6 * GH / 4;    // dgi (3 GH) | dgh (3 GH)
     constexpr int NIN = (TB * IN4 + NTK - 1) / NTK;
-    __shared__ __attribute__((aligned(16))) float in_s[2][TB][6 * GH];
-    __shared__ __attribute__((aligned(16))) float out_s[TB][6 * GH];
-    __shared__ __attribute__((aligned(16))) float part[SEG ? 3 : 2][NW][PU];
-    __shared__ uint32_t sched[SEG ? SCHED_MAX : 1];
-    __shared__ int seg_k[MAXSEG];
+    float (*in_s)[TB][6 * GH];
+    float (*out_s)[6 * GH];
+    float (*part)[NW][PU];
+    uint32_t* sched;
+    int* seg_k;
+    if constexpr (DYN) {
+        static_assert(!SEG, "the rider launch carries plain (full-length) recurrences only");
+        in_s = reinterpret_cast<float (*)[TB][6 * GH]>(dyn);
+        out_s = reinterpret_cast<float (*)[6 * GH]>(dyn + sizeof(float) * 2 * TB * 6 * GH);
+        part = reinterpret_cast<float (*)[NW][PU]>(dyn + sizeof(float) * 3 * TB * 6 * GH);
+        sched = nullptr;
+        seg_k = nullptr;
+    } else {
+        __shared__ __attribute__((aligned(16))) float in_static[2][TB][6 * GH];
+        __shared__ __attribute__((aligned(16))) float out_static[TB][6 * GH];
+        __shared__ __attribute__((aligned(16))) float part_static[SEG ? 3 : 2][NW][PU];
+        __shared__ uint32_t sched_static[SEG ? SCHED_MAX : 1];
+        __shared__ int seg_k_static[MAXSEG];
+        in_s = in_static; out_s = out_static; part = part_static; sched = sched_static; seg_k = seg_k_static;
+    }
 
     int gidx = 0;
     int dir_ = 0, row_ = 0, T_ = 0;
@@ -1268,9 +1287,9 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
         seg_schedule<NTK>(G.seg, G.T, ch, sched, seg_k);
         T_ = ch.S;                                 // the time loop runs over the flattened schedule, backwards
     } else {
-        while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-        dir_ = blockIdx.y;
-        row_ = (int)blockIdx.x - G.slice0[gidx];
+        while (gidx + 1 < G.n && bx >= G.slice0[gidx + 1]) ++gidx;
+        dir_ = by;
+        row_ = bx - G.slice0[gidx];
         T_ = G.T[gidx];
     }
     const int dir = dir_;
@@ -1534,6 +1553,41 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
     }
 }
 
+template <int NW, int GRP, int SEG>
+__global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G) {
+    gru_bwd_kpart_body<NW, GRP, SEG, false>(G, (int)blockIdx.x, (int)blockIdx.y, nullptr);
+}
+
+// The recurrence launch WITH RIDERS: workgroups [0, ngru) run the recurrence (bid -> (slot, direction) as the plain launch's
+// grid would), workgroups [ngru8, ...) run weight-gradient tiles of the step's queue (gemm_tn_split_body.h) that do not depend on
+// this recurrence.  The recurrence needs a CU per sequence for ~T x 0.75 us and leaves the other CUs idle (cfg2: 160 of 256 busy);
+// the launch's 108 KB of LDS per workgroup keeps every CU to ONE workgroup, so a rider never shares a CU with a recurrence
+// (whose latency chain a co-resident matrix kernel slows down, profiles/r03_wgrad_overlap.md), and the recurrences, having the
+// lowest block indices, are placed first.
+struct TnRiderSegs {
+    const float* A[MMDFN_RIDER_MAXSEG];
+    const float* B[MMDFN_RIDER_MAXSEG];
+    float* part[MMDFN_RIDER_MAXSEG];
+    float* colpart[MMDFN_RIDER_MAXSEG];
+    int R[MMDFN_RIDER_MAXSEG], lda[MMDFN_RIDER_MAXSEG], ldb[MMDFN_RIDER_MAXSEG], bshift[MMDFN_RIDER_MAXSEG];
+    int rows_per_split[MMDFN_RIDER_MAXSEG], splits[MMDFN_RIDER_MAXSEG], tiles[MMDFN_RIDER_MAXSEG], nblocks[MMDFN_RIDER_MAXSEG];
+    int M[MMDFN_RIDER_MAXSEG], N[MMDFN_RIDER_MAXSEG];
+    int wide[MMDFN_RIDER_MAXSEG];
+    int wg_prefix[MMDFN_RIDER_MAXSEG + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(512) void gru_seq_bwd_riders_kernel(const BwdGroups G, const TnRiderSegs rq, const int nslots,
+                                                                 const int ngru8) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rider_smem[];
+    const int bid = (int)blockIdx.x;
+    if (bid < 2 * nslots) {
+        gru_bwd_kpart_body<8, 4, 0, true>(G, bid % nslots, bid / nslots, rider_smem);
+    } else if (bid >= ngru8) {
+        tnsb::tns_block<0>(rq, bid - ngru8, rider_smem, nullptr);
+    }
+}
+
 // one sequence per workgroup, backward pass: the wave-partitioned kernel (8 waves) unless the tuning build asks for the
 // lane-pair one (MMDFN_GRU_KPART_BWD=0) for A/B runs.  Measured at cfg2 (profiles/r02_gru_kernels.md): lane-pair 110 us,
 // partitioned over 4 waves 126, over 8 waves 84, over 16 waves ~125.  The forward pass keeps the lane-pair kernel (80 us;
@@ -1742,7 +1796,30 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     }
     // (the 8-wave kernel runs one workgroup per CU: it wins while all sequences fit in one round; beyond that the lane-pair
     // kernel, two workgroups per CU, keeps the batch in one round -- cfg4: 320 workgroups, 1.75 vs 1.69 ms per step)
-    if (R == 1 && (2 * sl <= 256 || kpart_any_size()) && use_kpart_bwd()) hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 0>), grid, dim3(512), 0, s, G);
+    if (R == 1 && (2 * sl <= 256 || kpart_any_size()) && use_kpart_bwd()) {
+        if (const TnSplitSegs* rp = mmdfn_riders_pending()) {
+            // a staged weight-gradient batch rides on the CUs this launch leaves idle (gru_seq_bwd_riders_kernel)
+            if (rp->n <= MMDFN_RIDER_MAXSEG && 2 * sl < 256) {
+                TnRiderSegs rq;
+                for (int k = 0; k < MMDFN_RIDER_MAXSEG; ++k) {
+                    rq.A[k] = rp->A[k]; rq.B[k] = rp->B[k]; rq.part[k] = rp->part[k]; rq.colpart[k] = rp->colpart[k];
+                    rq.R[k] = rp->R[k]; rq.lda[k] = rp->lda[k]; rq.ldb[k] = rp->ldb[k]; rq.bshift[k] = rp->bshift[k];
+                    rq.rows_per_split[k] = rp->rows_per_split[k]; rq.splits[k] = rp->splits[k]; rq.tiles[k] = rp->tiles[k];
+                    rq.nblocks[k] = rp->nblocks[k]; rq.M[k] = rp->M[k]; rq.N[k] = rp->N[k]; rq.wide[k] = rp->wide[k];
+                    rq.wg_prefix[k] = rp->wg_prefix[k];
+                }
+                rq.wg_prefix[MMDFN_RIDER_MAXSEG] = rp->wg_prefix[rp->n];
+                rq.n = rp->n;
+                const int ngru8 = (2 * sl + 7) & ~7;
+                if (int e = mmdfn_allow_big_lds(gru_seq_bwd_riders_kernel)) return e;
+                hipLaunchKernelGGL(gru_seq_bwd_riders_kernel, dim3(ngru8 + rp->wg_prefix[rp->n]), dim3(512), tnsb::LDS_B, s, G, rq, sl,
+                                   ngru8);
+                MMDFN_CHECK_LAUNCH();
+                return mmdfn_riders_launched(s);
+            }
+        }
+        hipLaunchKernelGGL((gru_seq_bwd_kpart_kernel<8, 4, 0>), grid, dim3(512), 0, s, G);
+    }
     else if (R == 1) hipLaunchKernelGGL((gru_seq_bwd_kernel<1, 0>), grid, block, 0, s, G);
     else if (R == 2) hipLaunchKernelGGL((gru_seq_bwd_kernel<2, 0>), grid, block, 0, s, G);
     else hipLaunchKernelGGL((gru_seq_bwd_kernel<4, 0>), grid, block, 0, s, G);

@@ -145,6 +145,14 @@ struct TnSplitSegs {
 };
 int mmdfn_launch_gemm_tn_split(const TnSplitSegs& sq, hipStream_t s);
 
+// Riders of the GRU backward launch (gru.hip, gru_seq_bwd_riders_kernel): a weight-gradient batch STAGED by
+// mmdfn_wgrad_riders_stage (gemm_tn.hip) instead of launched; the next plain GRU backward launch of the one-sequence-per-workgroup
+// kind runs its tiles as extra workgroups on the CUs the recurrence leaves idle, then calls mmdfn_riders_launched (the slab
+// reduction).  Whatever is still pending when the host asks (mmdfn_wgrad_riders_flush) is launched the ordinary way.
+constexpr int MMDFN_RIDER_MAXSEG = 16;
+const TnSplitSegs* mmdfn_riders_pending();
+int mmdfn_riders_launched(hipStream_t s);
+
 // MFMA form of the GRU recurrence for launches with very many sequences (gru_mfma.hip): 16 sequences per workgroup, the
 // recurrent products on bf16 pieces.  Same operands and layouts as mmdfn_gru_seq_fwd / _bwd; -2 = not covered.
 int mmdfn_launch_gru_fwd_mfma(int ngroups, const float* const* gi, const float* const* w_hh, const float* const* b_hh,

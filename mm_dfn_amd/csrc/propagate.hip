@@ -491,7 +491,7 @@ int mmdfn_launch_propagate(const float* tiles, const float* cross, const float* 
 }
 #undef V2
 
-extern "C" int mmdfn_abi_version(void) { return 16; }
+extern "C" int mmdfn_abi_version(void) { return 17; }
 
 extern "C" int mmdfn_propagate(const float* tiles, const float* cross, const float* H, float* out,
                                const int32_t* dia_len, const int32_t* row_start, const int64_t* tile_base,

@@ -118,9 +118,14 @@ class _GruRecurrence(torch.autograd.Function):
         Ts = [y.shape[0] for y in ys]
         dyt = None
         if seg is None:
-            rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
-                                              _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
-                                              _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
+            # weight gradients queued so far ride on the CUs this recurrence leaves idle (ops_wgrad.stage_riders)
+            ops.stage_riders()
+            try:
+                rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
+                                                  _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),
+                                                  _hip.int_array(rows), _hip.int_array(Ts), H, _hip.stream())
+            finally:
+                ops.finish_riders()
             _hip.check(rc, "mmdfn_gru_seq_bwd")
         else:
             g0 = seg.group

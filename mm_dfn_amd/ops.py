@@ -22,7 +22,7 @@ from .ops_wgrad import (  # noqa: F401
     _join_side, _GRAPH_DONE_HOOK, set_graph_backward_done_hook, flush_queued_wgrads_now, flush_queued_wgrads_early,
     _GRAD_ADDENDS, _GRAD_ADDENDS_ARMED, drop_grad_addends, add_grad_addends, apply_grad_addends, flush_queued_wgrads,
     _ext_destinations, _flush_outs, _launch_wgrad_batch, _prepare_wgrad_batch, join_weight_grads,
-    set_async_weight_grads, _wgrad_inline, _wgrad,
+    set_async_weight_grads, _wgrad_inline, _wgrad, stage_riders, finish_riders,
 )
 from .ops_linear import (  # noqa: F401
     linear_raw, linear_group_raw, linear_group_supported, dense_nk, dense_kn, linear_supported, linear_preferred,

@@ -116,6 +116,12 @@ _WGQ = {"segs": [], "outs": {}, "ext": [], "armed": False, "scope": 0, "side": N
 # two-part gradient bucket would start its first all-reduce on a multi-GPU node.
 EARLY_WGRAD = __import__("os").environ.get("MMDFN_EARLY_WGRAD", "0") == "1"
 _WG_MAX = 40        # TN_MAXSEG / TN_MAXOUT of csrc/gemm_tn.hip
+# Riders (MMDFN_WGRAD_RIDERS=0 turns them off): what is queued when a GRU backward recurrence is about to be launched -- the
+# graph side's weight gradients in front of the second GRU layer's recurrence, that layer's own in front of the first layer's --
+# does not wait for the end of the pass: its tiles run as extra workgroups of the recurrence launch, on the CUs the recurrence
+# leaves idle (csrc/gru.hip gru_seq_bwd_riders_kernel, include/mmdfn_hip.h mmdfn_wgrad_riders_stage).
+RIDERS = __import__("os").environ.get("MMDFN_WGRAD_RIDERS", "1") == "1"
+_RIDER_MAXSEG = 16  # MMDFN_RIDER_MAXSEG of csrc/mmdfn_internal.h
 
 
 class wgrad_batch:
@@ -127,6 +133,8 @@ class wgrad_batch:
             _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False        # stale entries of a backward that raised
         if _WGQ["scope"] == 0:
             drop_grad_addends()                                             # (same: its callback never ran)
+            if _WGQ.get("rider_keep"):                                      # (a backward that raised between stage and launch)
+                finish_riders()
         _WGQ["scope"] += 1
         return self
 
@@ -239,6 +247,33 @@ def flush_queued_wgrads_now():
         _flush_outs(outs, None, ext)
 
 
+def stage_riders():
+    """In front of a GRU backward recurrence launch: the weight gradients queued so far are staged as riders of that launch
+    (one batch of at most 16 segments; a longer queue keeps its tail for the next launch / the end-of-backward flush).
+    ``finish_riders()`` must follow the launch."""
+    if not (RIDERS and _WGQ["scope"] > 0 and _WGQ["outs"]) or _WGQ.get("rider_keep"):
+        return
+    take, nseg = [], 0
+    for key, o in list(_WGQ["outs"].items()):
+        if nseg + len(o["segs"]) > _RIDER_MAXSEG:
+            break
+        take.append(key)
+        nseg += len(o["segs"])
+    if not take:
+        return
+    outs = [_WGQ["outs"].pop(k) for k in take]      # 'armed' stays set: the end-of-backward callback flushes the rest
+    _flush_outs(outs, None, (), stage=True)
+
+
+def finish_riders():
+    """Behind the GRU backward launch: a staged batch the launch did not take (another kernel form) is issued now; the
+    references that kept its operands and slabs alive are dropped (the launches are in the stream)."""
+    if _WGQ.get("rider_keep"):
+        rc = _hip.lib().mmdfn_wgrad_riders_flush(_hip.stream())
+        _WGQ["rider_keep"] = None
+        _hip.check(rc, "mmdfn_wgrad_riders_flush")
+
+
 def flush_queued_wgrads_early():
     """Called where the graph part of the backward pass ends (the adjacency builder's backward): what is queued so far
     leaves NOW on a side stream, concurrently with the encoder backward that follows on the main stream.  Gradient
@@ -337,7 +372,7 @@ def _ext_destinations(ext):
     return items
 
 
-def _flush_outs(outs, side, ext=()):
+def _flush_outs(outs, side, ext=(), stage=False):
     ext_items = _ext_destinations(ext) if ext else []
     if not outs:
         _prepare_wgrad_batch([], ext_items)(_hip.stream())
@@ -401,7 +436,10 @@ def _flush_outs(outs, side, ext=()):
     # foreign slab stacks ride on the last batch's reduction launch (a launch of their own when it has no room left, or when
     # the batch leaves on the side stream)
     ride = bool(ext_items) and side is None and len(batches[-1]) + len(ext_items) <= _WG_MAX
-    prepared = [_prepare_wgrad_batch(b, ext_items if (ride and b is batches[-1]) else None) for b in batches]          # allocations (workspace) on the current stream
+    prepared = [_prepare_wgrad_batch(b, ext_items if (ride and b is batches[-1]) else None, stage=stage and b is batches[-1])
+                for b in batches]          # allocations (workspace) on the current stream
+    if stage:
+        _WGQ["rider_keep"] = (outs, prepared)
     if ext_items and not ride:
         _prepare_wgrad_batch([], ext_items)(_hip.stream())
     if side is not None:
@@ -417,7 +455,7 @@ def _launch_wgrad_batch(batch):
     _prepare_wgrad_batch(batch)(_hip.stream())
 
 
-def _prepare_wgrad_batch(batch, ext_items=None):
+def _prepare_wgrad_batch(batch, ext_items=None, stage=False):
     lib = _hip.lib()
     ia = _hip.int_array
     pa = lambda ts: (ctypes.c_void_p * max(1, len(ts)))(*[None if t is None else t.data_ptr() for t in ts])
@@ -465,9 +503,10 @@ def _prepare_wgrad_batch(batch, ext_items=None):
                                              pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), *ext_args, stream)
             _hip.check(rc, "mmdfn_gemm_tn_batch_ext")
             return
-        rc = lib.mmdfn_gemm_tn_batch(len(A), pa(A), pa(B), ia(R), ia(lda), ia(ldb), ia(sh), ia(oi), len(C), pa(C), pa(cs1),
-                                     pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), stream)
-        _hip.check(rc, "mmdfn_gemm_tn_batch")
+        fn = lib.mmdfn_wgrad_riders_stage if stage else lib.mmdfn_gemm_tn_batch
+        rc = fn(len(A), pa(A), pa(B), ia(R), ia(lda), ia(ldb), ia(sh), ia(oi), len(C), pa(C), pa(cs1),
+                pa(cs2), ia(M), ia(N), ia(ldc), ia(acc), _hip.ptr(ws), stream)
+        _hip.check(rc, "mmdfn_wgrad_riders_stage" if stage else "mmdfn_gemm_tn_batch")
     return call
 
 

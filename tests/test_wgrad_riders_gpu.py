@@ -1,0 +1,113 @@
+"""Weight-gradient riders of the GRU backward recurrence launch (ops_wgrad.stage_riders, csrc/gru.hip
+gru_seq_bwd_riders_kernel, include/mmdfn_hip.h mmdfn_wgrad_riders_stage): the tiles of the step's weight-gradient queue that do not
+depend on a recurrence run as extra workgroups of its launch.  The recurrence's own results must not change by a bit, every
+parameter gradient must be the one the end-of-backward batch produces (to fp32 summation order: the split of a batch into slabs
+depends on what else is in the batch), and the rider launch must actually be the one that runs."""
+import pytest
+import torch
+
+from mm_dfn_amd import ops, ops_wgrad, synthetic
+from mm_dfn_amd import train as T
+from mm_dfn_amd.loss import FocalLoss
+
+pytestmark = pytest.mark.gpu
+CFG = dict(P=2, C=6, nlayers=2, D_t=100, D_a=100, D_v=512)
+
+
+def _step(m, b, flat, riders):
+    prev = ops_wgrad.RIDERS
+    ops_wgrad.RIDERS = riders
+    try:
+        m.zero_grad(set_to_none=True)
+        for k in ("textf", "acouf", "visuf"):
+            b[k].grad = None
+        logp = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+        T.backward(FocalLoss(gamma=0.5)(logp, flat))
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, \
+               {k: b[k].grad.clone() for k in ("textf", "acouf", "visuf")}
+    finally:
+        ops_wgrad.RIDERS = prev
+
+
+@pytest.mark.parametrize("lengths", [(20, 13, 7), tuple([110] * 16), (110, 64, 27, 110, 90, 33)], ids=["small", "cfg2", "ragged"])
+def test_riders_leave_every_gradient_as_the_batch_computes_it(lengths):
+    from torch.profiler import ProfilerActivity, profile
+    m = synthetic.build_model(dropout=0.0, **CFG)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 7))
+    m = m.cuda().train()
+    b = synthetic.make_batch(13, lengths=list(lengths), device="cuda", B=len(lengths), L=max(lengths), **CFG)
+    for k in ("textf", "acouf", "visuf"):
+        b[k] = b[k].detach().requires_grad_(True)
+    flat = T.flatten_labels(b["label"], b["lengths"])
+    want, wantx = _step(m, b, flat, False)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        got, gotx = _step(m, b, flat, True)
+    names = [e.key for e in prof.key_averages()]
+    assert any("gru_seq_bwd_riders_kernel" in n for n in names), names
+    assert set(got) == set(want)
+    for k in want:
+        scale = float(want[k].abs().max()) + 1e-30
+        assert float((got[k] - want[k]).abs().max()) <= 2e-5 * scale, k
+    # the recurrence itself (and everything downstream of it) is bit-identical: the input gradients pass through both GRU layers
+    for k in wantx:
+        assert torch.equal(gotx[k], wantx[k]), k
+    # a second pass with riders reproduces itself bit for bit
+    again, _ = _step(m, b, flat, True)
+    for k in got:
+        assert torch.equal(again[k], got[k]), k
+
+
+def _batch_call(A, Bm, C, cs, stage):
+    o = dict(M=A.shape[1], N=Bm.shape[1])
+    return ops_wgrad._prepare_wgrad_batch([(o, C, [cs], 0, [(A, Bm, 0)])], stage=stage)
+
+
+def _gru_bwd(T_, rows, seed):
+    from mm_dfn_amd import _hip
+    H = 100
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    dy, y, gates = r(T_, rows, 2 * H), torch.tanh(r(T_, rows, 2 * H)), torch.sigmoid(r(T_, rows, 2, 4, H))
+    whh = [0.1 * r(3 * H, H), 0.1 * r(3 * H, H)]
+    dgi = torch.full((T_, rows, 6 * H), float("nan"), device="cuda")
+    dgh = torch.full_like(dgi, float("nan"))
+    rc = _hip.lib().mmdfn_gru_seq_bwd(1, _hip.ptr_array([dy]), _hip.ptr_array([y]), _hip.ptr_array([gates]), _hip.ptr_array(whh),
+                                      _hip.ptr_array([dgi]), _hip.ptr_array([dgh]), _hip.int_array([rows]), _hip.int_array([T_]),
+                                      H, _hip.stream())
+    _hip.check(rc, "mmdfn_gru_seq_bwd")
+    return dgi, dgh
+
+
+@pytest.mark.parametrize("rows,T_", [(80, 110), (3, 17), (127, 40)])
+def test_rider_launch_is_bit_equal_to_the_two_plain_launches(rows, T_):
+    """C-ABI level: (stage a batch, GRU backward) == (GRU backward, mmdfn_gemm_tn_batch) bit for bit, for the recurrence's
+    outputs and for the batch's; and a staged batch that no GRU launch takes is flushed by mmdfn_wgrad_riders_flush."""
+    from mm_dfn_amd import _hip
+    lib = _hip.lib()
+    torch.manual_seed(3)
+    A = torch.randn(4100, 300, device="cuda")
+    Bm = torch.randn(4100, 200, device="cuda")
+    C0, c0 = torch.empty(300, 200, device="cuda"), torch.empty(300, device="cuda")
+    _batch_call(A, Bm, C0, c0, False)(_hip.stream())
+    dgi0, dgh0 = _gru_bwd(T_, rows, 5)
+    C1, c1 = torch.empty(300, 200, device="cuda"), torch.empty(300, device="cuda")
+    call = _batch_call(A, Bm, C1, c1, True)
+    call(_hip.stream())
+    assert lib.mmdfn_wgrad_riders_staged() == 1
+    dgi1, dgh1 = _gru_bwd(T_, rows, 5)
+    assert lib.mmdfn_wgrad_riders_staged() == 0          # the launch took it
+    torch.cuda.synchronize()
+    assert torch.equal(dgi0, dgi1) and torch.equal(dgh0, dgh1)
+    assert torch.equal(C0, C1) and torch.equal(c0, c1)
+    ref = A.double().t() @ Bm.double()
+    assert float((C1.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # staged, no GRU launch: the flush launches it
+    C2, c2 = torch.empty(300, 200, device="cuda"), torch.empty(300, device="cuda")
+    call2 = _batch_call(A, Bm, C2, c2, True)
+    call2(_hip.stream())
+    assert lib.mmdfn_wgrad_riders_staged() == 1
+    _hip.check(lib.mmdfn_wgrad_riders_flush(_hip.stream()), "mmdfn_wgrad_riders_flush")
+    assert lib.mmdfn_wgrad_riders_staged() == 0
+    torch.cuda.synchronize()
+    assert torch.equal(C0, C2) and torch.equal(c0, c2)
