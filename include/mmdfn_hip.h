@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 17: 16 + the GRU backward launch's weight-gradient riders mmdfn_wgrad_riders_{stage,staged,flush}; 16 = 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 17: 16 + the GRU backward launch's weight-gradient riders mmdfn_wgrad_riders_{stage,staged,flush,drain}, mmdfn_gru_seq_bwd_idle_cus; 16 = 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -489,7 +489,7 @@ int mmdfn_gemm_tn_batch_ext(int nseg, const float* const* A, const float* const*
  * batch and allocates its slabs exactly as that call would, but -- when the batch runs on the bf16-piece form, has at most 16
  * segments and nothing is staged yet -- does NOT launch it: the next mmdfn_gru_seq_bwd call on a one-sequence-per-workgroup
  * launch runs the batch's tiles as extra workgroups of the recurrence launch (never on a CU that holds a recurrence: the
- * launch's LDS request keeps every CU to one workgroup) and issues the slab reduction behind it.  A batch that cannot ride is
+ * launch's LDS request keeps every CU to one workgroup); the slab reduction follows later (mmdfn_wgrad_riders_drain).  A batch that cannot ride is
  * launched by the stage call itself.  mmdfn_wgrad_riders_staged: 1 while a batch waits; mmdfn_wgrad_riders_flush launches a
  * waiting batch the ordinary way (call it where no GRU backward launch will follow).  The operands and the workspace must stay
  * valid until the launch that consumes them has been issued on `stream` (the same stream for all three calls).  Results are
@@ -499,7 +499,16 @@ int mmdfn_wgrad_riders_stage(int nseg, const float* const* A, const float* const
                              float* const* colsum, float* const* colsum2, const int* M, const int* N, const int* ldc,
                              const int* accumulate, float* workspace, void* stream);
 int mmdfn_wgrad_riders_staged(void);
+/* CUs the mmdfn_gru_seq_bwd launch of these groups leaves idle if it is of the kind that takes riders, else 0: stage a batch
+ * only when this is > 0, and size it for that many CUs over the recurrence's ~0.75 us x T. */
+int mmdfn_gru_seq_bwd_idle_cus(int ngroups, const int* rows);
 int mmdfn_wgrad_riders_flush(void* stream);
+/* The slab reduction of a batch that rode (or that mmdfn_wgrad_riders_flush launched) is not a launch of its own either: it joins the reduction launch of the next
+ * mmdfn_gemm_tn_batch / _ext call on the stream (unless that call writes one of the same gradients: then it goes first, alone).
+ * mmdfn_wgrad_riders_drain(stream, 0) reduces what is still waiting -- call it once at the end of the backward pass, behind the
+ * last batch; the slabs (the staged batches' workspaces) must stay valid until then.  discard != 0 forgets staged and waiting
+ * work instead (after a backward pass that raised). */
+int mmdfn_wgrad_riders_drain(void* stream, int discard);
 
 /* ---------------------------------------------------------------------------
  * Fused Adam step over flat fp32 buffers (replaces torch.optim.Adam(lr, weight_decay=l2).step(),

@@ -840,9 +840,61 @@ static RiderPlan g_rider;
 
 const TnSplitSegs* mmdfn_riders_pending() { return g_rider.valid ? &g_rider.tq : nullptr; }
 
+// Slab stacks of rider batches whose reduction waits for the NEXT reduction launch of the backward pass (the end-of-backward
+// batch's, normally): a reduction launch of their own behind every recurrence costs the chain ~12 us each.
+struct DeferredOut {
+    const float* part; const float* colpart; float* C; float* colsum; float* colsum2;
+    int M, N, ldc, splits, accumulate;
+};
+static DeferredOut g_deferred[TN_MAXOUT];
+static int g_ndeferred = 0;
+
+static int reduce_blocks(int M, int N, int splits) {
+    int nblk = (int)((((int64_t)M * N + M) * (splits > TN_REDUCE_WIDE ? 8 : 1) + 255) / 256);
+    return nblk > 256 ? 256 : nblk;
+}
+
+static void put_out(TnOuts& oq, int o, const DeferredOut& d) {
+    oq.part[o] = d.part; oq.colpart[o] = d.colpart; oq.C[o] = d.C; oq.colsum[o] = d.colsum; oq.colsum2[o] = d.colsum2;
+    oq.M[o] = d.M; oq.N[o] = d.N; oq.ldc[o] = d.ldc; oq.splits[o] = d.splits; oq.accumulate[o] = d.accumulate;
+    oq.blk_prefix[o + 1] = oq.blk_prefix[o] + reduce_blocks(d.M, d.N, d.splits);
+}
+
+static int launch_deferred(hipStream_t s) {
+    if (g_ndeferred == 0) return 0;
+    TnOuts oq;
+    oq.blk_prefix[0] = 0;
+    for (int o = 0; o < g_ndeferred; ++o) put_out(oq, o, g_deferred[o]);
+    oq.n = g_ndeferred;
+    for (int o = g_ndeferred; o < TN_MAXOUT; ++o) {
+        oq.part[o] = oq.colpart[o] = nullptr; oq.C[o] = oq.colsum[o] = oq.colsum2[o] = nullptr;
+        oq.M[o] = oq.N[o] = oq.ldc[o] = oq.splits[o] = oq.accumulate[o] = 0;
+        oq.blk_prefix[o + 1] = oq.blk_prefix[g_ndeferred];
+    }
+    const int nblk = oq.blk_prefix[g_ndeferred];
+    g_ndeferred = 0;
+    hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(nblk), dim3(256), 0, s, oq);
+    MMDFN_CHECK_LAUNCH();
+    return 0;
+}
+
+static bool riders_defer_reduce() {
+#ifdef MMDFN_TUNING
+    if (const char* e = getenv("MMDFN_RIDER_DEFER")) return atoi(e) != 0;     // A/B aid
+#endif
+    return true;
+}
+
 int mmdfn_riders_launched(hipStream_t s) {
     if (!g_rider.valid) return -1;
     g_rider.valid = false;
+    const TnOuts& oq = g_rider.oq;
+    if (riders_defer_reduce() && g_ndeferred + oq.n <= TN_MAXOUT) {
+        for (int o = 0; o < oq.n; ++o)
+            g_deferred[g_ndeferred++] = DeferredOut{oq.part[o], oq.colpart[o], oq.C[o], oq.colsum[o], oq.colsum2[o],
+                                                    oq.M[o], oq.N[o], oq.ldc[o], oq.splits[o], oq.accumulate[o]};
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_tn_batch_reduce_kernel, dim3(g_rider.nblk), dim3(256), 0, s, g_rider.oq);
     MMDFN_CHECK_LAUNCH();
     return 0;
@@ -909,8 +961,7 @@ static int tn_batch_impl(int nseg, const float* const* A, const float* const* B,
         if (nblk > 256) nblk = 256;
         oq.blk_prefix[o + 1] = oq.blk_prefix[o] + nblk;
     }
-    const int ntot = nout + ext.n;
-    oq.n = ntot;
+    int ntot = nout + ext.n;
     for (int e = 0; e < ext.n; ++e) {
         const int o = nout + e;
         oq.part[o] = ext.part[e]; oq.colpart[o] = ext.colpart[e];
@@ -922,6 +973,26 @@ static int tn_batch_impl(int nseg, const float* const* A, const float* const* B,
         if (nblk > 256) nblk = 256;
         oq.blk_prefix[o + 1] = oq.blk_prefix[o] + nblk;
     }
+    // deferred slab stacks of rider batches join this launch's reduction -- unless a destination of theirs is also written here
+    // (two entries of one launch may not touch the same gradient: theirs is reduced first, by a launch of its own)
+    if (g_ndeferred > 0 && !stage) {
+        bool clash = ntot + g_ndeferred > TN_MAXOUT;
+        for (int d = 0; d < g_ndeferred && !clash; ++d)
+            for (int o = 0; o < ntot && !clash; ++o) {
+                const DeferredOut& q = g_deferred[d];
+                clash = (q.C != nullptr && q.C == oq.C[o]) ||
+                        (q.colsum != nullptr && (q.colsum == oq.colsum[o] || q.colsum == oq.colsum2[o])) ||
+                        (q.colsum2 != nullptr && (q.colsum2 == oq.colsum[o] || q.colsum2 == oq.colsum2[o]));
+            }
+        if (clash) {
+            if (int e = launch_deferred((hipStream_t)stream)) return e;
+        } else {
+            for (int d = 0; d < g_ndeferred; ++d) put_out(oq, ntot + d, g_deferred[d]);
+            ntot += g_ndeferred;
+            g_ndeferred = 0;
+        }
+    }
+    oq.n = ntot;
     for (int o = ntot; o < TN_MAXOUT; ++o) {
         oq.part[o] = oq.colpart[o] = nullptr; oq.C[o] = oq.colsum[o] = oq.colsum2[o] = nullptr;
         oq.M[o] = oq.N[o] = oq.ldc[o] = oq.splits[o] = oq.accumulate[o] = 0;
@@ -1065,6 +1136,13 @@ extern "C" int mmdfn_wgrad_riders_stage(int nseg, const float* const* A, const f
 }
 
 extern "C" int mmdfn_wgrad_riders_staged() { return g_rider.valid ? 1 : 0; }
+
+// End of the backward pass: slab stacks of rider batches that no later reduction launch took are reduced now (discard != 0:
+// forgotten instead -- a backward pass that raised left them behind).
+extern "C" int mmdfn_wgrad_riders_drain(void* stream, int discard) {
+    if (discard) { g_ndeferred = 0; g_rider.valid = false; return 0; }
+    return launch_deferred((hipStream_t)stream);
+}
 
 extern "C" int mmdfn_wgrad_riders_flush(void* stream) {
     if (!g_rider.valid) return 0;

@@ -1827,6 +1827,23 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
     return 0;
 }
 
+// CUs the plain backward launch of these groups would leave idle IF it is of the kind that takes weight-gradient riders (one
+// sequence per workgroup on the wave-partitioned kernel, fewer workgroups than CUs); 0 otherwise.  The host stages a rider
+// batch (mmdfn_wgrad_riders_stage) only in front of such a launch, and sizes it by this number.
+extern "C" int mmdfn_gru_seq_bwd_idle_cus(int ngroups, const int* rows) {
+    if (ngroups <= 0 || ngroups > MAXG) return 0;
+    const int R = pick_r(ngroups, rows);
+    int sl = 0, chains = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        if (rows[g] <= 0) return 0;
+        sl += (rows[g] + R - 1) / R;
+        chains += 2 * rows[g];
+    }
+    if (chains > mfma_min_chains()) return 0;
+    if (R == 1 && 2 * sl < 256 && use_kpart_bwd()) return 256 - 2 * sl;
+    return 0;
+}
+
 extern "C" int mmdfn_gru_seq_fwd_seg(int ngroups, const float* const* gi, const float* const* w_hh,
                                      const float* const* b_hh, float* const* y, float* const* gates, const int* rows,
                                      const int* T, int H, const int32_t* const* rank, const int* P, const int* BP,

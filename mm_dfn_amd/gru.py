@@ -119,7 +119,7 @@ class _GruRecurrence(torch.autograd.Function):
         dyt = None
         if seg is None:
             # weight gradients queued so far ride on the CUs this recurrence leaves idle (ops_wgrad.stage_riders)
-            ops.stage_riders()
+            ops.stage_riders(rows, Ts)
             try:
                 rc = _hip.lib().mmdfn_gru_seq_bwd(n, _hip.ptr_array(dys), _hip.ptr_array(ys), _hip.ptr_array(gates),
                                                   _hip.ptr_array(whh), _hip.ptr_array(dgi), _hip.ptr_array(dgh),

@@ -133,8 +133,8 @@ class wgrad_batch:
             _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False        # stale entries of a backward that raised
         if _WGQ["scope"] == 0:
             drop_grad_addends()                                             # (same: its callback never ran)
-            if _WGQ.get("rider_keep"):                                      # (a backward that raised between stage and launch)
-                finish_riders()
+            if _WGQ.get("rider_keep") or _WGQ.get("rider_held"):            # (a backward that raised with riders under way)
+                _drain_riders(discard=True)
         _WGQ["scope"] += 1
         return self
 
@@ -144,9 +144,11 @@ class wgrad_batch:
             if exc_type is None:
                 if _WGQ["outs"] or _WGQ["ext"]:
                     flush_queued_wgrads()                  # a backward driven without the engine callback
+                _drain_riders()
             else:
                 _WGQ["outs"], _WGQ["ext"], _WGQ["armed"] = {}, [], False    # the callback never ran: drop the half-built batch
                 drop_grad_addends()
+                _drain_riders(discard=True)
             _join_side()
         return False
 
@@ -247,18 +249,33 @@ def flush_queued_wgrads_now():
         _flush_outs(outs, None, ext)
 
 
-def stage_riders():
-    """In front of a GRU backward recurrence launch: the weight gradients queued so far are staged as riders of that launch
-    (one batch of at most 16 segments; a longer queue keeps its tail for the next launch / the end-of-backward flush).
-    ``finish_riders()`` must follow the launch."""
+# what a CU delivers on the bf16-piece weight-gradient tiles (the cfg2 batch: 10.4 GFLOP in 96 us on 256 CUs) and what a
+# recurrence step takes: the rider batch is sized so that its tiles end with the recurrence (tiles that outlast it run on a
+# chip whose other CUs have nothing left to do: cfg2's first-layer launch took 100 us instead of 84 with everything aboard)
+_RIDER_FLOPS_PER_CU_S = 4.2e11
+_RIDER_STEP_S = 0.75e-6
+RIDER_BUDGET = float(__import__("os").environ.get("MMDFN_RIDER_BUDGET", "1.0"))
+
+
+def stage_riders(rows, T):
+    """In front of the plain GRU backward recurrence launch of groups with ``rows`` sequences and ``T`` steps: weight gradients
+    queued so far are staged as riders of that launch -- if it is of the kind that takes riders, as many (in queue order, at
+    most 16 segments) as the CUs it leaves idle can finish while it runs; the rest stays queued for the next launch / the
+    end-of-backward flush.  ``finish_riders()`` must follow the launch."""
     if not (RIDERS and _WGQ["scope"] > 0 and _WGQ["outs"]) or _WGQ.get("rider_keep"):
         return
-    take, nseg = [], 0
+    idle = _hip.lib().mmdfn_gru_seq_bwd_idle_cus(len(rows), _hip.int_array(rows))
+    if idle <= 0:
+        return
+    budget = RIDER_BUDGET * idle * max(T) * _RIDER_STEP_S * _RIDER_FLOPS_PER_CU_S
+    take, nseg, work = [], 0, 0.0
     for key, o in list(_WGQ["outs"].items()):
-        if nseg + len(o["segs"]) > _RIDER_MAXSEG:
-            break
+        f = sum(2.0 * a.shape[0] * o["M"] * o["N"] for a, _, _ in o["segs"])
+        if nseg + len(o["segs"]) > _RIDER_MAXSEG or work + f > 1.1 * budget:
+            continue
         take.append(key)
         nseg += len(o["segs"])
+        work += f
     if not take:
         return
     outs = [_WGQ["outs"].pop(k) for k in take]      # 'armed' stays set: the end-of-backward callback flushes the rest
@@ -270,8 +287,20 @@ def finish_riders():
     references that kept its operands and slabs alive are dropped (the launches are in the stream)."""
     if _WGQ.get("rider_keep"):
         rc = _hip.lib().mmdfn_wgrad_riders_flush(_hip.stream())
+        # the slabs are read again by the reduction launch that takes them in (the end-of-backward batch's): held until then
+        _WGQ.setdefault("rider_held", []).append(_WGQ["rider_keep"])
         _WGQ["rider_keep"] = None
         _hip.check(rc, "mmdfn_wgrad_riders_flush")
+
+
+def _drain_riders(discard=False):
+    """End of the backward pass: the rider batches' slab stacks that no reduction launch took in are reduced now."""
+    if _WGQ.get("rider_held") or _WGQ.get("rider_keep"):
+        if _WGQ.get("rider_keep") and not discard:
+            finish_riders()
+        rc = _hip.lib().mmdfn_wgrad_riders_drain(_hip.stream(), 1 if discard else 0)
+        _WGQ["rider_held"], _WGQ["rider_keep"] = [], None
+        _hip.check(rc, "mmdfn_wgrad_riders_drain")
 
 
 def flush_queued_wgrads_early():
@@ -348,6 +377,7 @@ def flush_queued_wgrads():
     _join_side()             # first: a parameter may collect contributions from both batches (the later one accumulates)
     if outs or ext:
         _flush_outs(outs, None, ext)
+    _drain_riders()
 
 
 def _ext_destinations(ext):

@@ -44,7 +44,8 @@ def test_riders_leave_every_gradient_as_the_batch_computes_it(lengths):
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         got, gotx = _step(m, b, flat, True)
     names = [e.key for e in prof.key_averages()]
-    assert any("gru_seq_bwd_riders_kernel" in n for n in names), names
+    if len(set(lengths)) == 1 or max(lengths) < 32:      # (ragged long dialogues may take the valid-length launches: no riders)
+        assert any("gru_seq_bwd_riders_kernel" in n for n in names), names
     assert set(got) == set(want)
     for k in want:
         scale = float(want[k].abs().max()) + 1e-30
@@ -97,6 +98,7 @@ def test_rider_launch_is_bit_equal_to_the_two_plain_launches(rows, T_):
     assert lib.mmdfn_wgrad_riders_staged() == 1
     dgi1, dgh1 = _gru_bwd(T_, rows, 5)
     assert lib.mmdfn_wgrad_riders_staged() == 0          # the launch took it
+    _hip.check(lib.mmdfn_wgrad_riders_drain(_hip.stream(), 0), "mmdfn_wgrad_riders_drain")      # (its slab reduction)
     torch.cuda.synchronize()
     assert torch.equal(dgi0, dgi1) and torch.equal(dgh0, dgh1)
     assert torch.equal(C0, C1) and torch.equal(c0, c1)
@@ -109,5 +111,16 @@ def test_rider_launch_is_bit_equal_to_the_two_plain_launches(rows, T_):
     assert lib.mmdfn_wgrad_riders_staged() == 1
     _hip.check(lib.mmdfn_wgrad_riders_flush(_hip.stream()), "mmdfn_wgrad_riders_flush")
     assert lib.mmdfn_wgrad_riders_staged() == 0
+    _hip.check(lib.mmdfn_wgrad_riders_drain(_hip.stream(), 0), "mmdfn_wgrad_riders_drain")
     torch.cuda.synchronize()
     assert torch.equal(C0, C2) and torch.equal(c0, c2)
+    # a later batch that writes the same gradient: the waiting reduction goes first, the later batch accumulates onto it
+    C3, c3 = torch.empty(300, 200, device="cuda"), torch.empty(300, device="cuda")
+    _batch_call(A, Bm, C3, c3, True)(_hip.stream())
+    _gru_bwd(T_, rows, 5)
+    o = dict(M=300, N=200)
+    ops_wgrad._prepare_wgrad_batch([(o, C3, [c3], 1, [(A, Bm, 0)])])(_hip.stream())
+    _hip.check(lib.mmdfn_wgrad_riders_drain(_hip.stream(), 0), "mmdfn_wgrad_riders_drain")
+    torch.cuda.synchronize()
+    assert float((C3 - 2 * C0).abs().max()) <= 1e-5 * float(C0.abs().max())
+    assert float((c3 - 2 * c0).abs().max()) <= 1e-5 * float(c0.abs().max())
