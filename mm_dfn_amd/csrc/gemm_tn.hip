@@ -772,7 +772,7 @@ static int tns_tiles(int M, int N, int* nblocks, int* wide = nullptr) {
     if (wide) *wide = w ? 1 : 0;
     return ((M + MMDFN_TNS_TM - 1) / MMDFN_TNS_TM) * nb;
 }
-static int tns_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N) {
+static int tns_rows_target(int nseg, const int* R, const int* out, int nout, const int* M, const int* N, bool riders = false) {
     double units = 0.0;
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
@@ -782,8 +782,12 @@ static int tns_rows_target(int nseg, const int* R, const int* out, int nout, con
         units += (wd ? 1.5 : 1.0) * tiles * R[s];              // (a 224-column tile holds about 1.5 narrow tiles of work)
     }
     double wgs = 384.0;          // (round 5, with the 224-column tiles: 256 .. 768 swept on the cfg2-cfg5 batches)
+    // a rider batch has a third of the chip for the length of a recurrence: fewer, longer workgroups (and fewer slabs for the
+    // end-of-backward reduction launch, which sums the rider batches' stacks as well)
+    if (riders) wgs = 160.0;     // (96 .. 192 measure the same on the cfg2 step, 224 +0.3 %, 384 +1.4 %)
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_TNS_WGS")) wgs = atof(e);
+    if (riders) { if (const char* e = getenv("MMDFN_RIDER_WGS")) wgs = atof(e); }
 #endif
     int rt = (int)(units / wgs);
     rt = rt < 256 ? 256 : (rt > 4096 ? 4096 : rt);
@@ -928,7 +932,7 @@ static int tn_batch_impl(int nseg, const float* const* A, const float* const* B,
         if ((((uintptr_t)A[s] | (uintptr_t)B[s]) & 15) != 0 || (int64_t)R[s] * lda[s] >= (1ll << 30) ||
             (int64_t)R[s] * ldb[s] >= (1ll << 30) || R[s] >= (1 << 24))
             split_form = false;               // (its loads address rows by 32-bit byte offsets from the operand bases)
-    const int rt_split = tns_rows_target(nseg, R, out, nout, M, N);
+    const int rt_split = tns_rows_target(nseg, R, out, nout, M, N, stage);
     for (int s = 0; s < nseg; ++s) {
         const int o = out[s];
         if (o < 0 || o >= nout || R[s] <= 0 || (lda[s] & 3) || (ldb[s] & 3) || lda[s] < M[o] || ldb[s] < N[o]) return -1;

@@ -479,9 +479,9 @@ def test_slab_stacks_of_the_head_and_the_gather_bias_ride_on_the_batch_reduction
     seen = []
     orig = ops_wgrad._prepare_wgrad_batch
 
-    def spy(batch, ext_items=None):
+    def spy(batch, ext_items=None, **kw):
         seen.append((len(batch), len(ext_items or [])))
-        return orig(batch, ext_items)
+        return orig(batch, ext_items, **kw)
     ops_wgrad._prepare_wgrad_batch = spy
     try:
         torch.manual_seed(3)
