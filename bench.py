@@ -425,20 +425,22 @@ def streamed_leg(cfgname, dropout, nbatches=32, passes=2):
         for w in range(3):
             unseen = make(9000 + 100 * w, nbatches)
             pre.loader = unseen
-            h0, m0 = cache.hits, cache.misses
+            h0, m0, f0 = cache.hits, cache.misses, cache.fallbacks
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             train.train_or_eval_graph_model(model, loss_f, pre, 0, True, opt, False, graph_cache=cache)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             nu = sum(int(b[4].sum()) for b in unseen)
-            passes_out.append({"replayed": cache.hits - h0, "captured": cache.misses - m0, "ms_per_step": dt / nbatches * 1e3,
+            passes_out.append({"replayed": cache.hits - h0, "captured": cache.misses - m0,
+                               "served_by_a_larger_bucket": cache.fallbacks - f0, "ms_per_step": dt / nbatches * 1e3,
                                "utterances_per_s": nu / dt})
         res["bucketed_unseen_tuples_flat_adam"] = {
             "bucket_rows": 32, "entries": len(cache.entries), "precaptured_entries": made, "precapture_s": precapture_s,
             "note": "the bucket set is captured ahead of the first pass (StepGraphCache.precapture over 4 x %d batches drawn like "
                     "the timed ones: precapture_s); every timed pass -- the FIRST one included -- streams length tuples the cache has "
-                    "never seen; a pass that still meets a new bucket (the draws do not cover all ~40 possible ones) pays ~90 ms for it; "
+                    "never seen; a batch whose own bucket was not drawn is served by a larger captured bucket of its (B, L) when one is within "
+                    "reach of the padding dialogue (served_by_a_larger_bucket), and captured (55-90 ms) only otherwise; "
                     "tools/streamed_gap.py splits a replayed step: 0.96 ms device time of the real dialogues (exact-signature replays, "
                     "resident inputs), +0.02 for the bucket (padding dialogue, rounding, index retarget), +0.10-0.14 for what the pass "
                     "loop adds on the device around a replay (gradient pack, FlatAdam step, plane refresh, metrics copies, one graph "

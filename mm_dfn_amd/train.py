@@ -77,7 +77,7 @@ class StepGraphCache:
 
     IGNORE = -100                  # label of the padding dialogue's utterances (bucketed entries)
 
-    def __init__(self, model, loss_f, max_entries=96, warmup=2, bucket_rows=0):
+    def __init__(self, model, loss_f, max_entries=96, warmup=2, bucket_rows=0, larger_bucket_fallback=True):
         """``bucket_rows`` = g > 0: BUCKETED entries -- one captured step per (train / eval, B, padded length L, ceil((N + 1) /
         g) g) instead of per exact tuple of dialogue lengths (N = the batch's utterances).  The batch is padded to its
         bucket with ONE extra dialogue of 1..g utterances (fixed random features, labels IGNORE: dialogues never interact
@@ -87,6 +87,10 @@ class StepGraphCache:
         offsets, pad-strip and label gather indices) are rewritten for the new lengths (layout.IndexScope): the kernels
         read them from device memory and their grids depend on (B, N, L) only.  A loader that reshuffles every epoch
         (run_train_erc.py:165-212 with a different seed per pass, any sampler but the reference's) then stays on replays.
+        ``larger_bucket_fallback``: a batch whose own bucket has no entry yet is served by the smallest LARGER captured bucket
+        of the same (B, L) that its padding dialogue can fill (at most L utterances: up to ~L / g buckets above its own)
+        instead of being captured in the middle of a pass (55-90 ms at cfg2 against a few percent more rows for that step);
+        ``fallbacks`` counts them, ``precapture`` still captures every bucket it meets exactly.
         Needs a mm_dfn_amd FocalLoss (its ignore_index form) and a model without use_speaker / use_modal (they slice by
         dialogue length on the host); anything else falls back to exact signatures."""
         from collections import OrderedDict
@@ -95,7 +99,9 @@ class StepGraphCache:
         self.bucket_rows = int(bucket_rows or 0)
         self.entries = OrderedDict()
         self.queued = {}           # signature -> batches a staging loader has announced (claim_static) and not stepped yet
-        self.hits = self.misses = self.recaptures = 0
+        self.hits = self.misses = self.recaptures = self.fallbacks = 0
+        self.larger_bucket_fallback = bool(larger_bucket_fallback)
+        self._exact_buckets = False        # (precapture: every bucket it meets gets its own entry)
         self._loss_ign = None
         if self.bucket_rows:
             from .loss import FocalLoss
@@ -146,6 +152,19 @@ class StepGraphCache:
         the storages and is captured again when they move."""
         grads = [(p, p.grad) for p in self.model.parameters()]
         made = 0
+        self._exact_buckets = True
+        try:
+            made = self._precapture_walk(loader, train_flag, device)
+        finally:
+            self._exact_buckets = False
+        if hasattr(loader, "bind_graph_cache"):
+            self.forget_queued()
+        for p, g in grads:
+            p.grad = g
+        return made
+
+    def _precapture_walk(self, loader, train_flag, device):
+        made = 0
         for data in loader:
             tensors = list(data[:6])
             if device is not None:
@@ -157,10 +176,6 @@ class StepGraphCache:
                 continue
             self.step(tuple(tensors), lengths, train_flag)
             made += 1
-        if hasattr(loader, "bind_graph_cache"):
-            self.forget_queued()
-        for p, g in grads:
-            p.grad = g
         return made
 
     def _step_bucketed(self, inputs, lengths, train_flag):
@@ -175,6 +190,15 @@ class StepGraphCache:
         lens2 = lengths + [pad]
         key = self._bucket_key(inputs, lengths, train_flag)
         ent = self.entries.get(key)
+        if ent is None and self.larger_bucket_fallback and not self._exact_buckets:
+            # the smallest larger captured bucket of the same (B, L) that a padding dialogue of <= L utterances reaches
+            for nb2 in range(Nb + g, N + L + 1, g):
+                k2 = key[:4] + (nb2,) + key[5:]
+                if k2 in self.entries:
+                    key, ent, Nb, pad = k2, self.entries[k2], nb2, nb2 - N
+                    lens2 = lengths + [pad]
+                    self.fallbacks += 1
+                    break
         dev = inputs[0].device
         Lp = int(inputs[5].shape[1])
 

@@ -827,7 +827,7 @@ def test_bucketed_step_cache_serves_unseen_length_tuples(cfg_name):
     m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 31))
     m = m.cuda().train()
     loss_f = FocalLoss(gamma=0.5)
-    cache = T.StepGraphCache(m, loss_f, bucket_rows=g)
+    cache = T.StepGraphCache(m, loss_f, bucket_rows=g, larger_bucket_fallback=False)    # (every bucket gets its own entry)
     tuples = [[23, 9, 17], [23, 17, 9], [19, 23, 4], [23, 2, 21], [8, 15, 23], [23, 23, 1], [23, 12, 12], [23, 11, 15], [5, 23, 6]]
     keys = set()
     for i, lengths in enumerate(tuples):
@@ -864,6 +864,34 @@ def test_bucketed_step_cache_serves_unseen_length_tuples(cfg_name):
     loss, logp, _ = cache.step(inp, [20, 9, 17], True)
     assert cache.misses == before + 1 and sum(1 for k in cache.entries if k[0] != "bucket") == 1
     assert tuple(logp.shape) == (46, cfg["C"])
+
+
+def test_a_batch_without_its_own_bucket_is_served_by_a_larger_captured_one():
+    """larger_bucket_fallback (the default): no capture in the middle of a pass when a larger bucket of the same (B, L) is within
+    reach of the padding dialogue (<= L utterances); the results are still those of the batch alone."""
+    cfg, g, L, B = CFG, 8, 23, 3
+    m = synthetic.build_model(dropout=0.0, **cfg)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 33))
+    m = m.cuda().train()
+    loss_f = FocalLoss(gamma=0.5)
+    cache = T.StepGraphCache(m, loss_f, bucket_rows=g)
+    # N = 63 -> bucket 64 (captured); N = 49 -> bucket 56: served by 64 (15 padding utterances); N = 62 -> 64 itself;
+    # N = 30 -> bucket 32: 64 is out of reach (30 + 23 < 64): captured
+    plan = [([23, 20, 20], (1, 0, 0)), ([23, 17, 9], (1, 1, 1)), ([23, 19, 20], (1, 2, 1)), ([23, 3, 4], (2, 2, 1)),
+            ([23, 9, 17], (2, 3, 2))]
+    for i, (lengths, (misses, hits, fallbacks)) in enumerate(plan):
+        b = synthetic.make_batch(160 + i, lengths=lengths, device="cuda", B=B, L=L, **cfg)
+        want_loss, want_logp, want_g = _eager_step(m, loss_f, b)
+        loss, logp, flat = cache.step((b["textf"], b["visuf"], b["acouf"], b["qmask"], b["umask"], b["label"]), lengths, True)
+        assert (cache.misses, cache.hits, cache.fallbacks) == (misses, hits, fallbacks), (lengths, cache.misses, cache.hits, cache.fallbacks)
+        assert tuple(logp.shape) == (sum(lengths), cfg["C"])
+        assert torch.equal(flat, T.flatten_labels(b["label"], lengths))
+        assert torch.equal(logp, want_logp), float((logp - want_logp).abs().max())
+        assert abs(float(loss) - want_loss) < 2e-6 * max(1.0, abs(want_loss))
+        got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        for k in want_g:
+            den = float(want_g[k].abs().max())
+            assert float((got[k] - want_g[k]).abs().max()) <= 2e-5 * den + 1e-9, (k, lengths)
 
 
 def test_reshuffled_epochs_stay_on_replays_with_the_bucketed_cache(tmp_path):
