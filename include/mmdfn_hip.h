@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 17: 16 + the GRU backward launch's weight-gradient riders mmdfn_wgrad_riders_{stage,staged,flush,drain}, mmdfn_gru_seq_bwd_idle_cus; 16 = 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 17: 16 + the GRU backward launch's weight-gradient riders mmdfn_wgrad_riders_{stage,staged,flush,drain}, mmdfn_gru_seq_bwd_idle_cus, mmdfn_gru_seq_bwd_step_ns; 16 = 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -502,6 +502,7 @@ int mmdfn_wgrad_riders_staged(void);
 /* CUs the mmdfn_gru_seq_bwd launch of these groups leaves idle if it is of the kind that takes riders, else 0: stage a batch
  * only when this is > 0, and size it for that many CUs over the recurrence's ~0.75 us x T. */
 int mmdfn_gru_seq_bwd_idle_cus(int ngroups, const int* rows);
+int mmdfn_gru_seq_bwd_step_ns(int ngroups, const int* rows);    /* ns per recurrence step of that launch (750 / 2300: the two forms) */
 int mmdfn_wgrad_riders_flush(void* stream);
 /* The slab reduction of a batch that rode (or that mmdfn_wgrad_riders_flush launched) is not a launch of its own either: it joins the reduction launch of the next
  * mmdfn_gemm_tn_batch / _ext call on the stream (unless that call writes one of the same gradients: then it goes first, alone).

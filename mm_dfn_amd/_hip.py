@@ -71,6 +71,7 @@ SIGNATURES = {
     "mmdfn_wgrad_riders_flush": [_P],
     "mmdfn_wgrad_riders_drain": [_P, _I],
     "mmdfn_gru_seq_bwd_idle_cus": [_I, _P],
+    "mmdfn_gru_seq_bwd_step_ns": [_I, _P],
     "mmdfn_gemm_tn_batch_ext": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P,
                                 _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mmdfn_head_bwd_groups": [],

@@ -1564,18 +1564,6 @@ __global__ __launch_bounds__(64 * NW) void gru_seq_bwd_kpart_kernel(BwdGroups G)
 // the launch's 108 KB of LDS per workgroup keeps every CU to ONE workgroup, so a rider never shares a CU with a recurrence
 // (whose latency chain a co-resident matrix kernel slows down, profiles/r03_wgrad_overlap.md), and the recurrences, having the
 // lowest block indices, are placed first.
-struct TnRiderSegs {
-    const float* A[MMDFN_RIDER_MAXSEG];
-    const float* B[MMDFN_RIDER_MAXSEG];
-    float* part[MMDFN_RIDER_MAXSEG];
-    float* colpart[MMDFN_RIDER_MAXSEG];
-    int R[MMDFN_RIDER_MAXSEG], lda[MMDFN_RIDER_MAXSEG], ldb[MMDFN_RIDER_MAXSEG], bshift[MMDFN_RIDER_MAXSEG];
-    int rows_per_split[MMDFN_RIDER_MAXSEG], splits[MMDFN_RIDER_MAXSEG], tiles[MMDFN_RIDER_MAXSEG], nblocks[MMDFN_RIDER_MAXSEG];
-    int M[MMDFN_RIDER_MAXSEG], N[MMDFN_RIDER_MAXSEG];
-    int wide[MMDFN_RIDER_MAXSEG];
-    int wg_prefix[MMDFN_RIDER_MAXSEG + 1];
-    int n;
-};
 
 __global__ __launch_bounds__(512) void gru_seq_bwd_riders_kernel(const BwdGroups G, const TnRiderSegs rq, const int nslots,
                                                                  const int ngru8) {
@@ -1800,16 +1788,7 @@ extern "C" int mmdfn_gru_seq_bwd(int ngroups, const float* const* dy, const floa
         if (const TnSplitSegs* rp = mmdfn_riders_pending()) {
             // a staged weight-gradient batch rides on the CUs this launch leaves idle (gru_seq_bwd_riders_kernel)
             if (rp->n <= MMDFN_RIDER_MAXSEG && 2 * sl < 256) {
-                TnRiderSegs rq;
-                for (int k = 0; k < MMDFN_RIDER_MAXSEG; ++k) {
-                    rq.A[k] = rp->A[k]; rq.B[k] = rp->B[k]; rq.part[k] = rp->part[k]; rq.colpart[k] = rp->colpart[k];
-                    rq.R[k] = rp->R[k]; rq.lda[k] = rp->lda[k]; rq.ldb[k] = rp->ldb[k]; rq.bshift[k] = rp->bshift[k];
-                    rq.rows_per_split[k] = rp->rows_per_split[k]; rq.splits[k] = rp->splits[k]; rq.tiles[k] = rp->tiles[k];
-                    rq.nblocks[k] = rp->nblocks[k]; rq.M[k] = rp->M[k]; rq.N[k] = rp->N[k]; rq.wide[k] = rp->wide[k];
-                    rq.wg_prefix[k] = rp->wg_prefix[k];
-                }
-                rq.wg_prefix[MMDFN_RIDER_MAXSEG] = rp->wg_prefix[rp->n];
-                rq.n = rp->n;
+                const TnRiderSegs rq = mmdfn_rider_table(*rp);
                 const int ngru8 = (2 * sl + 7) & ~7;
                 if (int e = mmdfn_allow_big_lds(gru_seq_bwd_riders_kernel)) return e;
                 hipLaunchKernelGGL(gru_seq_bwd_riders_kernel, dim3(ngru8 + rp->wg_prefix[rp->n]), dim3(512), tnsb::LDS_B, s, G, rq, sl,
@@ -1839,9 +1818,20 @@ extern "C" int mmdfn_gru_seq_bwd_idle_cus(int ngroups, const int* rows) {
         sl += (rows[g] + R - 1) / R;
         chains += 2 * rows[g];
     }
-    if (chains > mfma_min_chains()) return 0;
+    if (chains > mfma_min_chains()) {           // the MFMA form: 16 sequences per workgroup (gru_mfma.hip)
+        int slm = 0;
+        for (int g = 0; g < ngroups; ++g) slm += (rows[g] + 15) / 16;
+        return 2 * slm < 256 ? 256 - 2 * slm : 0;
+    }
     if (R == 1 && 2 * sl < 256 && use_kpart_bwd()) return 256 - 2 * sl;
     return 0;
+}
+
+// nanoseconds per recurrence step of that launch (what the rider batch's size is priced with)
+extern "C" int mmdfn_gru_seq_bwd_step_ns(int ngroups, const int* rows) {
+    int chains = 0;
+    for (int g = 0; g < ngroups && g < MAXG; ++g) chains += 2 * rows[g];
+    return chains > mfma_min_chains() ? 2300 : 750;
 }
 
 extern "C" int mmdfn_gru_seq_fwd_seg(int ngroups, const float* const* gi, const float* const* w_hh,

@@ -22,6 +22,7 @@
 // mfma_min_chains() = 1 024 sequence-directions (gru.hip); H = 100 like every kernel of this path.  Measurements and the tuning
 // log: profiles/r05_gru_mfma_form.md.
 #include "mmdfn_internal.h"
+#include "gemm_tn_split_body.h"
 #include <stdlib.h>
 
 namespace {
@@ -294,15 +295,15 @@ __global__ __launch_bounds__(FWD_THREADS) void gru_seq_fwd_mfma_kernel(const MfF
 
 // Backward: same split.  The I/O wave moves 38 float4 per lane and step (dy | r z n ghn | h_prev of 16 sequences) through ONE
 // register set: requested at step k for step k + 2, dropped at step k + 1.
-__global__ __launch_bounds__(BWD_THREADS) void gru_seq_bwd_mfma_kernel(const MfBwd G) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+// (the body of workgroup (bx, by) = (slot of 16 sequences, direction); gm_smem: BWD_LDS bytes of LDS)
+__device__ __forceinline__ void gru_bwd_mfma_body(const MfBwd& G, const int bx, const int by, unsigned char* gm_smem) {
     unsigned char* dp = gm_smem;
     float* bs = reinterpret_cast<float*>(gm_smem + 2 * 3 * DPLANE);
     int gidx = 0;
-    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-    const int dir = blockIdx.y;
+    while (gidx + 1 < G.n && bx >= G.slice0[gidx + 1]) ++gidx;
+    const int dir = by;
     const int rows = G.rows[gidx], T = G.T[gidx];
-    const int row0 = ((int)blockIdx.x - G.slice0[gidx]) * MS;
+    const int row0 = (bx - G.slice0[gidx]) * MS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * 3 * DPLANE / 16; i += BWD_THREADS) reinterpret_cast<float4*>(dp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -465,6 +466,26 @@ __global__ __launch_bounds__(BWD_THREADS) void gru_seq_bwd_mfma_kernel(const MfB
     }
 }
 
+__global__ __launch_bounds__(BWD_THREADS) void gru_seq_bwd_mfma_kernel(const MfBwd G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+    gru_bwd_mfma_body(G, (int)blockIdx.x, (int)blockIdx.y, gm_smem);
+}
+
+// The backward launch WITH weight-gradient RIDERS (see gru.hip gru_seq_bwd_riders_kernel): the launch holds sequences / 16
+// workgroups per direction (cfg3: 112 on 256 CUs) for T x ~2.4 us; workgroups behind them run tiles of a staged weight-gradient
+// batch (gemm_tn_split_body.h: 512 threads and 108 KB of LDS, both inside this kernel's 512 / 137 KB), one workgroup per CU.
+static_assert(BWD_THREADS == 512 && BWD_LDS >= tnsb::LDS_B, "the rider tiles run in this launch's workgroup shape");
+__global__ __launch_bounds__(BWD_THREADS) void gru_seq_bwd_mfma_riders_kernel(const MfBwd G, const TnRiderSegs rq, const int nslots,
+                                                                               const int ngru8) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+    const int bid = (int)blockIdx.x;
+    if (bid < 2 * nslots) {
+        gru_bwd_mfma_body(G, bid % nslots, bid / nslots, gm_smem);
+    } else if (bid >= ngru8) {
+        tnsb::tns_block<0>(rq, bid - ngru8, gm_smem, nullptr);
+    }
+}
+
 }  // namespace
 
 int mmdfn_launch_gru_fwd_mfma(int ngroups, const float* const* gi, const float* const* w_hh, const float* const* b_hh,
@@ -511,6 +532,18 @@ int mmdfn_launch_gru_bwd_mfma(int ngroups, const float* const* dy, const float* 
     G.slice0[MAXG] = sl;
     for (int g = ngroups; g < MAXG; ++g) G.slice0[g] = sl;
     G.abl = 0;
+    if (const TnSplitSegs* rp = mmdfn_riders_pending()) {
+        // a staged weight-gradient batch rides on the CUs this launch leaves idle
+        if (rp->n <= MMDFN_RIDER_MAXSEG && 2 * sl < 256) {
+            const TnRiderSegs rq = mmdfn_rider_table(*rp);
+            const int ngru8 = (2 * sl + 7) & ~7;
+            if (int e = mmdfn_allow_big_lds(gru_seq_bwd_mfma_riders_kernel)) return e;
+            hipLaunchKernelGGL(gru_seq_bwd_mfma_riders_kernel, dim3(ngru8 + rp->wg_prefix[rp->n]), dim3(BWD_THREADS), BWD_LDS, s, G, rq,
+                               sl, ngru8);
+            MMDFN_CHECK_LAUNCH();
+            return mmdfn_riders_launched(s);
+        }
+    }
     if (int e = mmdfn_allow_big_lds(gru_seq_bwd_mfma_kernel)) return e;
     hipLaunchKernelGGL(gru_seq_bwd_mfma_kernel, dim3(sl, 2), dim3(BWD_THREADS), BWD_LDS, s, G);
     MMDFN_CHECK_LAUNCH();

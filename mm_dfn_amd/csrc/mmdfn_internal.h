@@ -150,6 +150,31 @@ int mmdfn_launch_gemm_tn_split(const TnSplitSegs& sq, hipStream_t s);
 // kind runs its tiles as extra workgroups on the CUs the recurrence leaves idle, then calls mmdfn_riders_launched (the slab
 // reduction).  Whatever is still pending when the host asks (mmdfn_wgrad_riders_flush) is launched the ordinary way.
 constexpr int MMDFN_RIDER_MAXSEG = 16;
+struct TnRiderSegs {
+    const float* A[MMDFN_RIDER_MAXSEG];
+    const float* B[MMDFN_RIDER_MAXSEG];
+    float* part[MMDFN_RIDER_MAXSEG];
+    float* colpart[MMDFN_RIDER_MAXSEG];
+    int R[MMDFN_RIDER_MAXSEG], lda[MMDFN_RIDER_MAXSEG], ldb[MMDFN_RIDER_MAXSEG], bshift[MMDFN_RIDER_MAXSEG];
+    int rows_per_split[MMDFN_RIDER_MAXSEG], splits[MMDFN_RIDER_MAXSEG], tiles[MMDFN_RIDER_MAXSEG], nblocks[MMDFN_RIDER_MAXSEG];
+    int M[MMDFN_RIDER_MAXSEG], N[MMDFN_RIDER_MAXSEG];
+    int wide[MMDFN_RIDER_MAXSEG];
+    int wg_prefix[MMDFN_RIDER_MAXSEG + 1];
+    int n;
+};
+inline TnRiderSegs mmdfn_rider_table(const TnSplitSegs& t) {      // (t.n <= MMDFN_RIDER_MAXSEG)
+    TnRiderSegs rq;
+    for (int k = 0; k < MMDFN_RIDER_MAXSEG; ++k) {
+        rq.A[k] = t.A[k]; rq.B[k] = t.B[k]; rq.part[k] = t.part[k]; rq.colpart[k] = t.colpart[k];
+        rq.R[k] = t.R[k]; rq.lda[k] = t.lda[k]; rq.ldb[k] = t.ldb[k]; rq.bshift[k] = t.bshift[k];
+        rq.rows_per_split[k] = t.rows_per_split[k]; rq.splits[k] = t.splits[k]; rq.tiles[k] = t.tiles[k];
+        rq.nblocks[k] = t.nblocks[k]; rq.M[k] = t.M[k]; rq.N[k] = t.N[k]; rq.wide[k] = t.wide[k];
+        rq.wg_prefix[k] = t.wg_prefix[k];
+    }
+    rq.wg_prefix[MMDFN_RIDER_MAXSEG] = t.wg_prefix[t.n];
+    rq.n = t.n;
+    return rq;
+}
 const TnSplitSegs* mmdfn_riders_pending();
 int mmdfn_riders_launched(hipStream_t s);
 

@@ -253,7 +253,6 @@ def flush_queued_wgrads_now():
 # recurrence step takes: the rider batch is sized so that its tiles end with the recurrence (tiles that outlast it run on a
 # chip whose other CUs have nothing left to do: cfg2's first-layer launch took 100 us instead of 84 with everything aboard)
 _RIDER_FLOPS_PER_CU_S = 4.2e11
-_RIDER_STEP_S = 0.75e-6
 RIDER_BUDGET = float(__import__("os").environ.get("MMDFN_RIDER_BUDGET", "0.8"))    # (0.65 .. 0.9 measure the same, 1.0 .. 1.5 +0.4 %)
 
 
@@ -267,7 +266,8 @@ def stage_riders(rows, T):
     idle = _hip.lib().mmdfn_gru_seq_bwd_idle_cus(len(rows), _hip.int_array(rows))
     if idle <= 0:
         return
-    budget = RIDER_BUDGET * idle * max(T) * _RIDER_STEP_S * _RIDER_FLOPS_PER_CU_S
+    step_s = 1e-9 * _hip.lib().mmdfn_gru_seq_bwd_step_ns(len(rows), _hip.int_array(rows))     # (0.75 us; the MFMA form 2.3)
+    budget = RIDER_BUDGET * idle * max(T) * step_s * _RIDER_FLOPS_PER_CU_S
     take, nseg, work = [], 0, 0.0
     for key, o in list(_WGQ["outs"].items()):
         f = sum(2.0 * a.shape[0] * o["M"] * o["N"] for a, _, _ in o["segs"])

@@ -30,8 +30,13 @@ def _step(m, b, flat, riders):
         ops_wgrad.RIDERS = prev
 
 
-@pytest.mark.parametrize("lengths", [(20, 13, 7), tuple([110] * 16), (110, 64, 27, 110, 90, 33)], ids=["small", "cfg2", "ragged"])
-def test_riders_leave_every_gradient_as_the_batch_computes_it(lengths):
+CFG3 = dict(P=9, C=7, nlayers=4, D_t=600, D_a=300, D_v=342)            # BASELINE cfg3 (MELD-like): the MFMA-form recurrence
+RAGGED_CFG3 = (33, 3, 17, 31, 9, 27, 12, 33, 5, 21, 30, 8, 16, 2, 25, 11, 33, 7, 19, 29, 4, 14, 23, 10, 32, 6, 18, 28, 13, 22, 1, 26)
+
+
+@pytest.mark.parametrize("lengths,CFG", [((20, 13, 7), CFG), (tuple([110] * 16), CFG), ((110, 64, 27, 110, 90, 33), CFG),
+                                         (RAGGED_CFG3, CFG3)], ids=["small", "cfg2", "ragged", "cfg3"])
+def test_riders_leave_every_gradient_as_the_batch_computes_it(lengths, CFG):
     from torch.profiler import ProfilerActivity, profile
     m = synthetic.build_model(dropout=0.0, **CFG)
     m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 7))
@@ -44,7 +49,9 @@ def test_riders_leave_every_gradient_as_the_batch_computes_it(lengths):
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         got, gotx = _step(m, b, flat, True)
     names = [e.key for e in prof.key_averages()]
-    if len(set(lengths)) == 1 or max(lengths) < 32:      # (ragged long dialogues may take the valid-length launches: no riders)
+    if CFG is CFG3:
+        assert any("gru_seq_bwd_mfma_riders_kernel" in n for n in names), names
+    elif len(set(lengths)) == 1 or max(lengths) < 32:    # (ragged long dialogues may take the valid-length launches: no riders)
         assert any("gru_seq_bwd_riders_kernel" in n for n in names), names
     assert set(got) == set(want)
     for k in want:
@@ -80,7 +87,7 @@ def _gru_bwd(T_, rows, seed):
     return dgi, dgh
 
 
-@pytest.mark.parametrize("rows,T_", [(80, 110), (3, 17), (127, 40)])
+@pytest.mark.parametrize("rows,T_", [(80, 110), (3, 17), (127, 40), (600, 20)])     # (600: the MFMA form)
 def test_rider_launch_is_bit_equal_to_the_two_plain_launches(rows, T_):
     """C-ABI level: (stage a batch, GRU backward) == (GRU backward, mmdfn_gemm_tn_batch) bit for bit, for the recurrence's
     outputs and for the batch's; and a staged batch that no GRU launch takes is flushed by mmdfn_wgrad_riders_flush."""
