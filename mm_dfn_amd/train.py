@@ -175,6 +175,10 @@ class StepGraphCache:
             if self.entry_key(tensors, lengths, train_flag) in self.entries:
                 continue
             self.step(tuple(tensors), lengths, train_flag)
+            if self.bucket_rows and self.entry_key(tensors, lengths, train_flag) in self.entries:
+                # the first REPLAY-path step of a bucketed entry (index retarget through fresh staging buffers, the input copies)
+                # costs ~10-35 ms once: paid here, not by the first batch of a pass that lands in the bucket
+                self.step(tuple(tensors), lengths, train_flag)
             made += 1
         return made
 
