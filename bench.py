@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the other_workloads legs (cfg2 ragged, cfg3, cfg4 shard, cfg5, streamed)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the K6 roofline legs (profiling runs of the step alone)")
     ap.add_argument("--only-roofline", action="store_true", help="profiling aid: run only the K6 roofline legs (clean rocprof traces)")
-    ap.add_argument("--roofline-legs", default="fwd,bwd,stack,d512",
+    ap.add_argument("--roofline-legs", default="fwd,bwd,stack,d512,b64",
                     help="profiling aid: which cfg5 legs to run (tools/collect_traffic.py separates the per-call legs from the "
                          "stack leg, whose launches share kernel names and grids with them)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
@@ -854,6 +854,29 @@ def roofline_legs(out, a, dev, n_utt, lengths):
             "note": "useful fp32 flop (2 d nnz) per launch / launch time; the kernel's issue-side accounting (MFMA ~20 us + "
                     "piece cutting and other issue 25 us + epilogue per workgroup pair, no overlap between them on a SIMD) "
                     "is in DESIGN.md 4g / 4k, profiles/r03_k6_memory_path.md, profiles/r05_k6_levers_upper_bounds.md"}
+        # the same launch with 64 dialogues: 1 536 workgroups = three FULL rounds of the chip's 512 workgroup slots (32 dialogues:
+        # 768 = one and a half) -- what the round quantisation of the figure above is worth; not the figure of merit
+        if "b64" in set(a.roofline_legs.split(",")):
+            try:
+                l6 = [512] * 64
+
+                def mk6(i):
+                    g = torch.Generator(device=dev).manual_seed(600 + i)
+                    adj = ops.build_adjacency(torch.randn(6, sum(l6), 200, device=dev, generator=g), l6)
+                    return adj, torch.randn(6 * sum(l6), d, device=dev, generator=g)
+
+                ms6 = time_propagate(mk6, nsets=2, iters=10, warm_replays=10, timed_replays=5)
+                b6 = ops.DialogueLayout.get(l6, 6, dev).propagate_bytes(d)
+                out["roofline_cfg5_b64"] = {"workload": "cfg5 shapes, B=64: L=512, M=6, d=100 (three full rounds of workgroups)",
+                                            "bound": "hbm", "kernel": out["roofline_cfg5"]["kernel"],
+                                            "achieved": b6 / (ms6 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": b6 / (ms6 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b6,
+                                            "avg_launch_us": ms6 * 1e3, "traffic": None,
+                                            "buffers": "2 rotating (adjacency, H, out) sets = %.0f MB > 256 MB MALL" % (2 * b6 / 1e6)}
+                del mk6
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                out["roofline_cfg5_b64"] = {"skipped": "%s: %s" % (type(exc).__name__, exc)}
         # K6 backward at the same workload, reported separately: dH = A^T dO (the forward kernel, A is
         # symmetric) + dA = dO . H^T on the tile pattern (tile_dot + cross_dot); bytes_bwd = 8 nnz + 16 M N d
         legs5 = set(a.roofline_legs.split(","))
