@@ -122,6 +122,7 @@ _WG_MAX = 40        # TN_MAXSEG / TN_MAXOUT of csrc/gemm_tn.hip
 # leaves idle (csrc/gru.hip gru_seq_bwd_riders_kernel, include/mmdfn_hip.h mmdfn_wgrad_riders_stage).
 RIDERS = __import__("os").environ.get("MMDFN_WGRAD_RIDERS", "1") == "1"
 _RIDER_MAXSEG = 16  # MMDFN_RIDER_MAXSEG of csrc/mmdfn_internal.h
+RIDER_LOG = None    # a list: stage_riders appends what it found queued and what it took (tools/rider_log.py)
 
 
 class wgrad_batch:
@@ -276,6 +277,10 @@ def stage_riders(rows, T):
         take.append(key)
         nseg += len(o["segs"])
         work += f
+    if RIDER_LOG is not None:
+        RIDER_LOG.append(dict(idle=idle, T=max(T), budget_gflop=budget / 1e9, taken_gflop=work / 1e9, taken_segments=nseg,
+                              queued=[(o["M"], o["N"], len(o["segs"]), sum(a.shape[0] for a, _, _ in o["segs"]), k in take)
+                                      for k, o in _WGQ["outs"].items()]))
     if not take:
         return
     outs = [_WGQ["outs"].pop(k) for k in take]      # 'armed' stays set: the end-of-backward callback flushes the rest
