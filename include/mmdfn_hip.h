@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version (currently 17: 16 + the GRU backward launch's weight-gradient riders mmdfn_wgrad_riders_{stage,staged,flush,drain}, mmdfn_gru_seq_bwd_idle_cus, mmdfn_gru_seq_bwd_step_ns; 16 = 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
+/* Library / device sanity: returns the ABI version (currently 17: 16 + the GRU backward launch's weight-gradient riders mmdfn_wgrad_riders_{stage,staged,flush,drain}, mmdfn_gru_seq_bwd_idle_cus, mmdfn_gru_seq_bwd_step_ns, and the dropout-flag draw as a rider of the GRU forward launch mmdfn_keep_flags_{stage,flush}, mmdfn_gru_seq_fwd_takes_flags; 16 = 15 + mmdfn_linear_planes_group, mmdfn_party_gather_bwd_colsum, mmdfn_party_combine_bwd_dst, mmdfn_prop_layer_fwd; 15 = 14 + mmdfn_weight_planes_workspace, mmdfn_cut_weight_planes, mmdfn_linear_planes; 14 = 13 + mmdfn_lstm_gate_{planes_workspace,cut_weights,fwd_pre,takes_planes}; 13 = 12 + mmdfn_gemm_tn_batch_ext, mmdfn_head_bwd_partial / _groups, mmdfn_colsum_partial; 12 = 11 + the segmented GRU recurrence mmdfn_gru_seq_{fwd,bwd}_seg, mmdfn_gru_tab_reduce, the strided forms mmdfn_lstm_gate_fwd_ld, mmdfn_gcnii_layer_bwd_ld, mmdfn_focal_loss_{fwd,bwd}_ignore and mmdfn_focal_loss_fwd_grad). */
 int mmdfn_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -221,6 +221,16 @@ int mmdfn_party_gather_bwd_colsum(int Mn, const float* dS, const int32_t* rank, 
  * state[0] (seed) at counter state[1] + i / 8 (16 random bits per flag: the rate is exact to 2^-16).  `state`: three 64-bit words
  * in DEVICE memory (seed, offset, 0); the launch adds ceil(n / 8) rounded up to a multiple of 64 to the offset itself, so replays of a captured graph draw fresh flags. */
 int mmdfn_keep_flags(float* out, int64_t n, float keep, void* state, void* stream);
+/* ABI 17: the same draw as a RIDER of the first GRU layer's forward recurrence launch.  mmdfn_keep_flags_stage takes the arguments
+ * of mmdfn_keep_flags and does not launch (a second staged draw is launched at once); the next mmdfn_gru_seq_fwd launch of the kind
+ * mmdfn_gru_seq_fwd_takes_flags answers 1 for (one sequence per workgroup, fewer workgroups than CUs) runs the draw as extra
+ * workgroups on the CUs the recurrence leaves idle -- the same flags bit for bit (which counter yields which flag depends on
+ * neither the grid nor the block size); mmdfn_keep_flags_flush launches a draw that is still staged.  The flags must not be read
+ * before the launch that carries them (their first consumer in the reference is the dropout behind that GRU layer,
+ * model.py:866). */
+int mmdfn_keep_flags_stage(float* out, int64_t n, float keep, void* state, void* stream);
+int mmdfn_keep_flags_flush(void* stream);
+int mmdfn_gru_seq_fwd_takes_flags(int ngroups, const int* rows);
 int64_t mmdfn_colsum_workspace(int H);
 int mmdfn_colsum(const float* A, int64_t R, int H, int lda, float* out, float* workspace, void* stream);
 /* The first launch of mmdfn_colsum alone (ABI 13): returns the number (> 0) of [H] slabs left in `workspace` for

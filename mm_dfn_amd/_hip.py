@@ -94,6 +94,9 @@ SIGNATURES = {
     "mmdfn_party_combine_bwd_dst": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "mmdfn_mask_scale": [_I, _P, _P, _P, _P, _F, _P],
     "mmdfn_keep_flags": [_P, _L, _F, _P, _P],
+    "mmdfn_keep_flags_stage": [_P, _L, ctypes.c_float, _P, _P],
+    "mmdfn_keep_flags_flush": [_P],
+    "mmdfn_gru_seq_fwd_takes_flags": [_I, _P],
     "mmdfn_colsum_workspace": [_I],
     "mmdfn_colsum": [_P, _L, _I, _I, _P, _P, _P],
 }

@@ -12,6 +12,7 @@
 //                        the reference scatters speaker by speaker so the last one wins);
 //   and their backward counterparts (single writer per output element, no atomics).
 #include "mmdfn_internal.h"
+#include "keep_flags_body.h"
 #include "../../include/mmdfn_hip.h"
 
 namespace {
@@ -376,51 +377,8 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restric
 // replay without the per-replay seed / offset fill launches of the framework generator, and one 6 M-flag draw costs 5 us instead
 // of 11 us for `bernoulli_` + 9 us for those fills.
 // ---------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)M0 * ctr.x, p1 = (unsigned long long)M1 * ctr.z;   // one v_mad_u64_u32 each
-        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += W0;
-        key.y += W1;
-    }
-    return ctr;
-}
-
-__global__ __launch_bounds__(1024) void keep_flags_kernel(float* __restrict__ out, int64_t n8, int64_t n4, uint32_t threshold,
-                                                          int all, unsigned long long* __restrict__ state) {
-    const unsigned long long seed = state[0], offset = state[1];
-    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
-    // one Philox call = 128 random bits = EIGHT flags (16 bits each: the keep rate is exact to 2^-16, the generator is the
-    // multiplier-bound part of the kernel: 19 v_mad_u64_u32 per call)
-    // (whole waves: n8 is a multiple of 64 -- the launcher rounds the counter range up, the slot guards below cut the tail)
-    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 1024) {
-        const unsigned long long c = offset + (unsigned long long)i;
-        const uint4 r = philox4x32_10(make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0u, 0u), key);
-        float4 v, u;
-        v.x = (all || (r.x & 0xFFFFu) < threshold) ? 1.f : 0.f; v.y = (all || (r.x >> 16) < threshold) ? 1.f : 0.f;
-        v.z = (all || (r.y & 0xFFFFu) < threshold) ? 1.f : 0.f; v.w = (all || (r.y >> 16) < threshold) ? 1.f : 0.f;
-        u.x = (all || (r.z & 0xFFFFu) < threshold) ? 1.f : 0.f; u.y = (all || (r.z >> 16) < threshold) ? 1.f : 0.f;
-        u.z = (all || (r.w & 0xFFFFu) < threshold) ? 1.f : 0.f; u.w = (all || (r.w >> 16) < threshold) ? 1.f : 0.f;
-        // the wave's 128 float4 slots as two contiguous 1 KB stores (which flag lands where is immaterial)
-        const int lane = threadIdx.x & 63;
-        const int64_t sa = 2 * (i - lane) + lane, sb = sa + 64;
-        if (sa < n4) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(out + 4 * sa));
-        if (sb < n4) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, u), reinterpret_cast<f32x4*>(out + 4 * sb));
-    }
-    __shared__ int last_s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned done = atomicAdd(reinterpret_cast<unsigned*>(&state[2]), 1u);
-        last_s = (done == gridDim.x - 1u) ? 1 : 0;
-    }
-    __syncthreads();
-    if (last_s && threadIdx.x == 0) {
-        state[1] = offset + (unsigned long long)n8;
-        state[2] = 0ull;
-    }
+__global__ __launch_bounds__(1024) void keep_flags_kernel(const kfb::FlagJob J) {
+    kfb::keep_flags_block<1024>(J, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace
@@ -584,18 +542,52 @@ extern "C" int mmdfn_colsum_partial(const float* A, int64_t R, int H, int lda, f
     return nsl;
 }
 
-extern "C" int mmdfn_keep_flags(float* out, int64_t n, float keep, void* state, void* stream) {
+// A draw STAGED for the next plain GRU forward launch (gru.hip: its tiles of counters run as rider workgroups of the recurrence
+// launch) instead of launched; mmdfn_keep_flags_flush launches a staged draw the ordinary way.
+static kfb::FlagJob g_flag_job;
+static bool g_flag_job_valid = false;
+const kfb::FlagJob* mmdfn_flag_job_pending() { return g_flag_job_valid ? &g_flag_job : nullptr; }
+void mmdfn_flag_job_taken() { g_flag_job_valid = false; }
+
+static int flag_job(kfb::FlagJob& J, float* out, int64_t n, float keep, void* state) {
     if (n <= 0 || (n & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || state == nullptr || !(keep >= 0.f) || keep > 1.f) return -1;
-    const int64_t n4 = n >> 2, n8 = (((n4 + 1) >> 1) + 63) & ~(int64_t)63;      // Philox counters consumed: whole waves
+    J.out = out;
+    J.n4 = n >> 2;
+    J.n8 = (((J.n4 + 1) >> 1) + 63) & ~(int64_t)63;      // Philox counters consumed: whole waves
     // keep = 1: every flag is 1 whatever the draw
-    const int all = keep >= 1.f ? 1 : 0;
-    const uint32_t threshold = all ? 65536u : (uint32_t)((double)keep * 65536.0 + 0.5);
+    J.all = keep >= 1.f ? 1 : 0;
+    J.threshold = J.all ? 65536u : (uint32_t)((double)keep * 65536.0 + 0.5);
+    J.state = reinterpret_cast<unsigned long long*>(state);
+    return 0;
+}
+
+static int launch_flag_job(const kfb::FlagJob& J, hipStream_t s) {
     // one workgroup per CU at most: the end-of-launch counter is one L2 atomic per workgroup on ONE address (2 048 of them
     // serialised into 20 us); 1 024 threads each, so that four waves per SIMD hide the 10-round dependent chain of a Philox call
-    int64_t grid = (n8 + 1023) / 1024;
+    int64_t grid = (J.n8 + 1023) / 1024;
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(keep_flags_kernel, dim3((unsigned)grid), dim3(1024), 0, (hipStream_t)stream, out, n8, n4, threshold, all,
-                       reinterpret_cast<unsigned long long*>(state));
+    hipLaunchKernelGGL(keep_flags_kernel, dim3((unsigned)grid), dim3(1024), 0, s, J);
     MMDFN_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mmdfn_keep_flags(float* out, int64_t n, float keep, void* state, void* stream) {
+    kfb::FlagJob J;
+    if (int e = flag_job(J, out, n, keep, state)) return e;
+    return launch_flag_job(J, (hipStream_t)stream);
+}
+
+extern "C" int mmdfn_keep_flags_stage(float* out, int64_t n, float keep, void* state, void* stream) {
+    kfb::FlagJob J;
+    if (int e = flag_job(J, out, n, keep, state)) return e;
+    if (g_flag_job_valid) return launch_flag_job(J, (hipStream_t)stream);       // one staged draw at a time: this one goes now
+    g_flag_job = J;
+    g_flag_job_valid = true;
+    return 0;
+}
+
+extern "C" int mmdfn_keep_flags_flush(void* stream) {
+    if (!g_flag_job_valid) return 0;
+    g_flag_job_valid = false;
+    return launch_flag_job(g_flag_job, (hipStream_t)stream);
 }

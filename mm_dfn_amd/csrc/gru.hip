@@ -18,6 +18,7 @@
 // Gate order r, z, n;  n = tanh(gi_n + r * (W_hn h + b_hn));  h = (1-z) n + z h_prev.
 #include "mmdfn_internal.h"
 #include "gemm_tn_split_body.h"
+#include "keep_flags_body.h"
 #include "../../include/mmdfn_hip.h"
 #include <stdlib.h>
 
@@ -588,8 +589,9 @@ __global__ __launch_bounds__(NT) void gru_seq_fwd_kernel(FwdGroups G) {
 // SEG = 1: segmented launch (see SegInfo): 1-D grid of chains, the time loop runs over the chain's flattened schedule
 // (S steps, each naming its row and t), the state is re-initialised at segment starts (one extra barrier there), and the
 // positions a truncated / silent row does not visit are filled afterwards (copies of the all-padding sequence, or zeros).
+// (the body of workgroup (bx, by) = (sequence slot, direction) of the plain launch; SEG launches decode their chain themselves)
 template <int SCALAR_FMA, int ABL, int SEG>
-__global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
+__device__ __forceinline__ void gru_fwd_io_body(const FwdGroups& G, const int bx, const int by) {
     constexpr int TB = 4;                          // steps per block
     constexpr int NLD = (TB * 3 * GH / 4 + 63) / 64;   // float4 loads per I/O lane and block (5)
     __shared__ __attribute__((aligned(16))) float hs[2][GH + 4];
@@ -631,9 +633,9 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
         seg_schedule<320>(G.seg, G.T, ch, sched, seg_k);
         T_ = ch.S;                                 // the time loop runs over the flattened schedule
     } else {
-        while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-        dir_ = blockIdx.y;
-        row_ = (int)blockIdx.x - G.slice0[gidx];
+        while (gidx + 1 < G.n && bx >= G.slice0[gidx + 1]) ++gidx;
+        dir_ = by;
+        row_ = bx - G.slice0[gidx];
         T_ = G.T[gidx];
     }
     const int dir = dir_;
@@ -927,6 +929,22 @@ __global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
             if (!(ABL & 8)) __syncthreads();
         }
     }
+}
+
+template <int SCALAR_FMA, int ABL, int SEG>
+__global__ __launch_bounds__(320) void gru_seq_fwd_io_kernel(FwdGroups G) {
+    gru_fwd_io_body<SCALAR_FMA, ABL, SEG>(G, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// The plain forward launch WITH the step's dropout-flag draw aboard: workgroups [0, 2 x slots) run the recurrences, the
+// workgroups behind them (at most one per idle CU: the kernel's register budget keeps a CU to one workgroup) draw the keep flags
+// of the whole step (keep_flags_body.h) -- the flags' first consumer is the dropout BEHIND this recurrence (nn.GRU's
+// inter-layer dropout, reference model.py:866), so the generator launch that used to sit between the two GRU layers (7.7 us at
+// cfg2) is gone.  Same flags as the launch of its own: which counter yields which flag depends on neither the grid nor the block size.
+__global__ __launch_bounds__(320) void gru_seq_fwd_io_flags_kernel(const FwdGroups G, const kfb::FlagJob J, const int nslots) {
+    const int bid = (int)blockIdx.x;
+    if (bid < 2 * nslots) gru_fwd_io_body<0, 0, 0>(G, bid % nslots, bid / nslots);
+    else kfb::keep_flags_block<320>(J, bid - 2 * nslots, (int)gridDim.x - 2 * nslots);
 }
 
 // Backward through time.  dh_prev[u] = sum_j dgh[j] W_hh[j][u] + dh z: lane (u, half) keeps W_hh[j][u] for
@@ -1750,6 +1768,18 @@ extern "C" int mmdfn_gru_seq_fwd(int ngroups, const float* const* gi, const floa
     GRU_IO_ABL(1) GRU_IO_ABL(2) GRU_IO_ABL(4) GRU_IO_ABL(8) GRU_IO_ABL(16) GRU_IO_ABL(3) GRU_IO_ABL(11) GRU_IO_ABL(31) GRU_IO_ABL(23) GRU_IO_ABL(64)
 #undef GRU_IO_ABL
 #endif
+    if (io_wave && !scalar_fma && 2 * sl < 256) {
+        if (const kfb::FlagJob* fj = mmdfn_flag_job_pending()) {
+            // a staged dropout-flag draw rides on the CUs this launch leaves idle (gru_seq_fwd_io_flags_kernel)
+            int64_t nr = (fj->n8 + 319) / 320;
+            if (nr > 256 - 2 * sl) nr = 256 - 2 * sl;
+            const kfb::FlagJob J = *fj;
+            mmdfn_flag_job_taken();
+            hipLaunchKernelGGL(gru_seq_fwd_io_flags_kernel, dim3(2 * sl + (int)nr), dim3(320), 0, s, G, J, sl);
+            MMDFN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (io_wave && scalar_fma) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<1, 0, 0>), grid, dim3(320), 0, s, G);
     else if (io_wave) hipLaunchKernelGGL((gru_seq_fwd_io_kernel<0, 0, 0>), grid, dim3(320), 0, s, G);
     else if (R == 1) hipLaunchKernelGGL((gru_seq_fwd_kernel<1, 0>), grid, block, 0, s, G);
@@ -1825,6 +1855,20 @@ extern "C" int mmdfn_gru_seq_bwd_idle_cus(int ngroups, const int* rows) {
     }
     if (R == 1 && 2 * sl < 256 && use_kpart_bwd()) return 256 - 2 * sl;
     return 0;
+}
+
+// 1 if the plain FORWARD launch of these groups is of the kind that carries a staged dropout-flag draw (mmdfn_keep_flags_stage)
+extern "C" int mmdfn_gru_seq_fwd_takes_flags(int ngroups, const int* rows) {
+    if (ngroups <= 0 || ngroups > MAXG) return 0;
+    const int R = pick_r(ngroups, rows);
+    int sl = 0, chains = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        if (rows[g] <= 0) return 0;
+        sl += (rows[g] + R - 1) / R;
+        chains += 2 * rows[g];
+    }
+    if (chains > mfma_min_chains()) return 0;
+    return (R == 1 && 2 * sl < 256) ? 1 : 0;
 }
 
 // nanoseconds per recurrence step of that launch (what the rider batch's size is priced with)

@@ -60,6 +60,9 @@ class _Seg:
         return _hip.ptr_array(ranks), _hip.int_array(P), _hip.int_array(BP), _hip.int_array(tdir)
 
 
+_FLAG_RIDER_P = [None]     # bigru2 -> _GruRecurrence.forward: the dropout rate whose flags the NEXT plain forward launch may carry
+
+
 class _GruRecurrence(torch.autograd.Function):
     """args = (seg, ytab, then per group (gi, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev), flattened) -> (y_0, y_1, ...).  The
     recurrent weights are the module's own parameters (no stack / cat per step): the kernels take one pointer per direction
@@ -82,9 +85,17 @@ class _GruRecurrence(torch.autograd.Function):
             rows.append(R)
             Ts.append(T)
         if seg is None:
-            rc = _hip.lib().mmdfn_gru_seq_fwd(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
-                                              _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
-                                              _hip.int_array(Ts), H, _hip.stream())
+            # (the first layer of a training-mode bigru2: the step's dropout flags are drawn as riders of this launch)
+            flag_p, _FLAG_RIDER_P[0] = _FLAG_RIDER_P[0], None
+            if flag_p is not None:
+                ops.stage_flag_draw(flag_p, gis[0].device, rows)
+            try:
+                rc = _hip.lib().mmdfn_gru_seq_fwd(n, _hip.ptr_array(gis), _hip.ptr_array(whh), _hip.ptr_array(bhh),
+                                                  _hip.ptr_array(ys), _hip.ptr_array(gates), _hip.int_array(rows),
+                                                  _hip.int_array(Ts), H, _hip.stream())
+            finally:
+                if flag_p is not None:
+                    ops.finish_flag_draw()
             _hip.check(rc, "mmdfn_gru_seq_fwd")
         else:
             if ytab is not None:
@@ -401,6 +412,7 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
         args = []
         for gi, p in zip(gis, prm):
             args += [gi] + p[2]
+        _FLAG_RIDER_P[0] = dropout if (layer == 0 and training and dropout > 0) else None
         if party is None:
             cur = list(_GruRecurrence.apply(None, None, *args))
         elif layer == 0 and party[2] is None and not L1_SKIPS_SILENT:
@@ -412,6 +424,7 @@ def bigru2(xs, grus, dropout=0.0, training=False, gi0=None, party=None):
             cur = list(_GruRecurrence.apply(_Seg(party[0], party[1], 1), party[2].join(), *args))
         else:
             cur = list(_GruRecurrence.apply(_Seg(party[0], party[1], 0), None, *args))
+        _FLAG_RIDER_P[0] = None
         if layer == 0 and training and dropout > 0:
             # nn.GRU's dropout between the layers: 0 / 1 keep flags from the step's flag pool (no generator launch of its
             # own) applied to every group's output by ONE launch each way -- at the head of the next layer (see there)

@@ -41,6 +41,7 @@ from .ops_fusion import (  # noqa: F401
 from .ops_flags import (  # noqa: F401
     _FLAG_SCOPE, _FLAG_HINT, flag_pool, keep_scale, _FLAG_STATE, _FLAG_CONSUMED, flags_consumed, flag_state_snapshot,
     flag_state_restore, flag_state_sync, flags_advance_host, draw_flags, keep_flags, _MaskScale, mask_scale,
+    stage_flag_draw, finish_flag_draw,
 )
 from .ops_head import (  # noqa: F401
     _Head, _head_width, head_supported, head,

@@ -101,7 +101,43 @@ def flags_advance_host(idx, counters):
     ent[1] = (int(gen.initial_seed()), int(gen.get_offset()))
 
 
-def draw_flags(n, p, device):
+# The step's draw as a RIDER of the first GRU layer's forward recurrence launch (MMDFN_FLAG_RIDER=0 turns it off): the first
+# consumer of a step's flags is the dropout behind that layer, and the recurrence leaves CUs idle (cfg2: 96 of 256 for 69 us), so the
+# generator launch (7.7 us at cfg2, a link of the step's dependent chain) runs as extra workgroups of the recurrence launch
+# instead (csrc/gru.hip gru_seq_fwd_io_flags_kernel, include/mmdfn_hip.h mmdfn_keep_flags_stage).
+FLAG_RIDER = __import__("os").environ.get("MMDFN_FLAG_RIDER", "1") == "1"
+_FLAG_STAGED = [False]
+
+
+def stage_flag_draw(p, device, rows):
+    """In front of the plain forward launch of the first GRU layer (groups of ``rows`` sequences): if the step's flag pool has no
+    buffer for (device, p) yet and the previous step with the same scope key says how many flags the step uses, draw them NOW
+    as riders of that launch.  ``finish_flag_draw()`` must follow the launch."""
+    scope = _FLAG_SCOPE
+    if not FLAG_RIDER or scope is None or _FLAG_STAGED[0]:
+        return
+    device = torch.device(device)
+    k = (device, float(p))
+    if k in scope.bufs:
+        return
+    want = _FLAG_HINT.get((scope.key,) + k, 0)
+    if want <= 0 or not _hip.lib().mmdfn_gru_seq_fwd_takes_flags(len(rows), _hip.int_array(rows)):
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if _FLAG_STATE.get(idx) is None:
+        return                        # (the first draw on a device sets the generator state up: the ordinary way)
+    scope.bufs[k] = [draw_flags(want, p, device, stage=True), 0, 0]
+    _FLAG_STAGED[0] = True
+
+
+def finish_flag_draw():
+    """Behind that launch: a staged draw the launch did not take (another kernel form) is launched now."""
+    if _FLAG_STAGED[0]:
+        _FLAG_STAGED[0] = False
+        _hip.check(_hip.lib().mmdfn_keep_flags_flush(_hip.stream()), "mmdfn_keep_flags_flush")
+
+
+def draw_flags(n, p, device, stage=False):
     """n (a multiple of 4) fresh fp32 keep flags from the package's Philox kernel (csrc/encoder_glue.hip).  The generator state
     lives on the device and every launch advances it, so replays of a captured graph draw new flags.  In eager mode the state
     follows torch's CUDA generator: it is re-seeded from (initial_seed, offset) whenever those differ from what this function
@@ -127,7 +163,8 @@ def draw_flags(n, p, device):
         ent[1] = (now[0], int(gen.get_offset()))
     _FLAG_CONSUMED[idx] = _FLAG_CONSUMED.get(idx, 0) + 4 * ((n8 + 3) // 4)
     out = torch.empty(n, dtype=torch.float32, device=device)
-    _hip.check(_hip.lib().mmdfn_keep_flags(_hip.ptr(out), n, float(1.0 - p), _hip.ptr(ent[0]), _hip.stream()), "mmdfn_keep_flags")
+    fn = _hip.lib().mmdfn_keep_flags_stage if stage else _hip.lib().mmdfn_keep_flags
+    _hip.check(fn(_hip.ptr(out), n, float(1.0 - p), _hip.ptr(ent[0]), _hip.stream()), "mmdfn_keep_flags")
     return out
 
 

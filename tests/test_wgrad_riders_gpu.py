@@ -131,3 +131,61 @@ def test_rider_launch_is_bit_equal_to_the_two_plain_launches(rows, T_):
     torch.cuda.synchronize()
     assert float((C3 - 2 * C0).abs().max()) <= 1e-5 * float(C0.abs().max())
     assert float((c3 - 2 * c0).abs().max()) <= 1e-5 * float(c0.abs().max())
+
+
+@pytest.mark.parametrize("lengths", [(20, 13, 7), tuple([110] * 16)], ids=["small", "cfg2"])
+def test_dropout_flags_drawn_as_riders_of_the_gru_forward_launch_are_the_same_flags(lengths):
+    """The step's keep flags drawn by rider workgroups of the first GRU layer's forward launch (ops_flags.stage_flag_draw,
+    gru_seq_fwd_io_flags_kernel) are the flags the generator launch of its own draws -- same seed, same step: bit-identical
+    log-probabilities and gradients --, the generator launch is gone from the trace, and a captured step keeps drawing fresh
+    flags at every replay."""
+    from torch.profiler import ProfilerActivity, profile
+    from mm_dfn_amd import ops_flags
+    from mm_dfn_amd.graphs import CapturedStep
+    m = synthetic.build_model(dropout=0.5, **CFG)
+    m.load_state_dict(synthetic.seeded_state_dict(m.state_dict(), 9))
+    m = m.cuda().train()
+    b = synthetic.make_batch(17, lengths=list(lengths), device="cuda", B=len(lengths), L=max(lengths), **CFG)
+    flat = T.flatten_labels(b["label"], b["lengths"])
+    loss_f = FocalLoss(gamma=0.5)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        logp = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+        T.backward(loss_f(logp, flat))
+        return logp.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    step()                                          # (every later step finds the hint: one draw per step)
+
+    def two_steps(rider):
+        prev, ops_flags.FLAG_RIDER = ops_flags.FLAG_RIDER, rider
+        try:
+            torch.manual_seed(1234)
+            step()                                  # (leaves the hint: how many flags a step uses)
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                out = step()
+                torch.cuda.synchronize()
+            return out, [e.key for e in prof.key_averages()]
+        finally:
+            ops_flags.FLAG_RIDER = prev
+    (lp0, g0), names0 = two_steps(False)
+    (lp1, g1), names1 = two_steps(True)
+    assert any("keep_flags_kernel" in n for n in names0) and not any("fwd_io_flags" in n for n in names0), names0
+    assert any("gru_seq_fwd_io_flags_kernel" in n for n in names1) and not any("keep_flags_kernel" in n for n in names1), names1
+    assert torch.equal(lp0, lp1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    # captured: replays differ from each other (fresh flags), and the flags are Bernoulli(0.5)
+    out = {}
+
+    def fn():
+        out["logp"] = m(b["textf"], b["qmask"], b["umask"], b["lengths"], b["acouf"], b["visuf"])[0]
+        loss = loss_f(out["logp"], flat)
+        T.backward(loss)
+        return loss
+    cap = CapturedStep(m, fn, warmup=2)
+    cap.replay(); a = out["logp"].clone()
+    cap.replay(); c = out["logp"].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(a, c)
+    cap.close()
