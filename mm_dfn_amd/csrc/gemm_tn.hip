@@ -893,6 +893,18 @@ int mmdfn_riders_launched(hipStream_t s) {
     if (!g_rider.valid) return -1;
     g_rider.valid = false;
     const TnOuts& oq = g_rider.oq;
+    // (two waiting stacks may not share a destination either: an earlier rider batch that wrote one of these gradients is
+    // reduced first, by a launch of its own)
+    bool clash = false;
+    for (int d = 0; d < g_ndeferred && !clash; ++d)
+        for (int o = 0; o < oq.n && !clash; ++o) {
+            const DeferredOut& q = g_deferred[d];
+            clash = (q.C != nullptr && q.C == oq.C[o]) ||
+                    (q.colsum != nullptr && (q.colsum == oq.colsum[o] || q.colsum == oq.colsum2[o])) ||
+                    (q.colsum2 != nullptr && (q.colsum2 == oq.colsum[o] || q.colsum2 == oq.colsum2[o]));
+        }
+    if (clash)
+        if (int e = launch_deferred(s)) return e;
     if (riders_defer_reduce() && g_ndeferred + oq.n <= TN_MAXOUT) {
         for (int o = 0; o < oq.n; ++o)
             g_deferred[g_ndeferred++] = DeferredOut{oq.part[o], oq.colpart[o], oq.C[o], oq.colsum[o], oq.colsum2[o],

@@ -131,6 +131,17 @@ def test_rider_launch_is_bit_equal_to_the_two_plain_launches(rows, T_):
     torch.cuda.synchronize()
     assert float((C3 - 2 * C0).abs().max()) <= 1e-5 * float(C0.abs().max())
     assert float((c3 - 2 * c0).abs().max()) <= 1e-5 * float(c0.abs().max())
+    # two rider batches in a row that write the same gradient: the first one's waiting reduction goes first as well
+    C4, c4 = torch.empty(300, 200, device="cuda"), torch.empty(300, device="cuda")
+    _batch_call(A, Bm, C4, c4, True)(_hip.stream())
+    _gru_bwd(T_, rows, 5)
+    ops_wgrad._prepare_wgrad_batch([(o, C4, [c4], 1, [(A, Bm, 0)])], stage=True)(_hip.stream())
+    _gru_bwd(T_, rows, 5)
+    assert lib.mmdfn_wgrad_riders_staged() == 0
+    _hip.check(lib.mmdfn_wgrad_riders_drain(_hip.stream(), 0), "mmdfn_wgrad_riders_drain")
+    torch.cuda.synchronize()
+    assert float((C4 - 2 * C0).abs().max()) <= 1e-5 * float(C0.abs().max())
+    assert float((c4 - 2 * c0).abs().max()) <= 1e-5 * float(c0.abs().max())
 
 
 @pytest.mark.parametrize("lengths", [(20, 13, 7), tuple([110] * 16)], ids=["small", "cfg2"])
