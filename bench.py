@@ -856,7 +856,7 @@ def roofline_legs(out, a, dev, n_utt, lengths):
                     "is in DESIGN.md 4g / 4k, profiles/r03_k6_memory_path.md, profiles/r05_k6_levers_upper_bounds.md"}
         # the same launch with 64 dialogues: 1 536 workgroups = three FULL rounds of the chip's 512 workgroup slots (32 dialogues:
         # 768 = one and a half) -- what the round quantisation of the figure above is worth; not the figure of merit
-        if "b64" in set(a.roofline_legs.split(",")):
+        if "b64" in set(a.roofline_legs.split(",")) and int(os.environ.get("WORLD_SIZE", "1")) == 1:
             try:
                 l6 = [512] * 64
 
