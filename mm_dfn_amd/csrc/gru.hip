@@ -1867,7 +1867,11 @@ extern "C" int mmdfn_gru_seq_fwd_takes_flags(int ngroups, const int* rows) {
         sl += (rows[g] + R - 1) / R;
         chains += 2 * rows[g];
     }
-    if (chains > mfma_min_chains()) return 0;
+    if (chains > mfma_min_chains()) {           // the MFMA form: 16 sequences per workgroup (gru_mfma.hip)
+        int slm = 0;
+        for (int g = 0; g < ngroups; ++g) slm += (rows[g] + 15) / 16;
+        return 2 * slm < 256 ? 1 : 0;
+    }
     return (R == 1 && 2 * sl < 256) ? 1 : 0;
 }
 

@@ -23,6 +23,7 @@
 // log: profiles/r05_gru_mfma_form.md.
 #include "mmdfn_internal.h"
 #include "gemm_tn_split_body.h"
+#include "keep_flags_body.h"
 #include <stdlib.h>
 
 namespace {
@@ -126,15 +127,15 @@ constexpr int BWD_LDS = 2 * 3 * DPLANE + 2 * BSLOT;      // 140 288 B
 // "everything" (vmcnt counts both): the recurrence waves therefore ONLY store (results, never waited for) and a separate wave
 // only loads: the gi rows of step k + 3 are requested at step k into one of two register sets and dropped into the LDS slot of
 // their step parity at step k + 2 (two steps of cover; its waits count loads only).
-__global__ __launch_bounds__(FWD_THREADS) void gru_seq_fwd_mfma_kernel(const MfFwd G) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+// (the body of workgroup (bx, by) = (slot of 16 sequences, direction); gm_smem: FWD_LDS bytes of LDS)
+__device__ __forceinline__ void gru_fwd_mfma_body(const MfFwd& G, const int bx, const int by, unsigned char* gm_smem) {
     unsigned char* hp = gm_smem;
     float* gs = reinterpret_cast<float*>(gm_smem + 2 * 3 * HPLANE);
     int gidx = 0;
-    while (gidx + 1 < G.n && (int)blockIdx.x >= G.slice0[gidx + 1]) ++gidx;
-    const int dir = blockIdx.y;
+    while (gidx + 1 < G.n && bx >= G.slice0[gidx + 1]) ++gidx;
+    const int dir = by;
     const int rows = G.rows[gidx], T = G.T[gidx];
-    const int row0 = ((int)blockIdx.x - G.slice0[gidx]) * MS;
+    const int row0 = (bx - G.slice0[gidx]) * MS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef MMDFN_TUNING
@@ -291,6 +292,20 @@ __global__ __launch_bounds__(FWD_THREADS) void gru_seq_fwd_mfma_kernel(const MfF
             __builtin_nontemporal_store(f32x4{ghn[0], ghn[1], ghn[2], ghn[3]}, reinterpret_cast<f32x4*>(gp + 3 * GH));
         }
     }
+}
+
+__global__ __launch_bounds__(FWD_THREADS) void gru_seq_fwd_mfma_kernel(const MfFwd G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+    gru_fwd_mfma_body(G, (int)blockIdx.x, (int)blockIdx.y, gm_smem);
+}
+
+// The forward launch with the step's dropout-flag draw aboard (see gru.hip gru_seq_fwd_io_flags_kernel): the workgroups behind the
+// recurrences draw the keep flags of the whole step (keep_flags_body.h), one per idle CU at most.
+__global__ __launch_bounds__(FWD_THREADS) void gru_seq_fwd_mfma_flags_kernel(const MfFwd G, const kfb::FlagJob J, const int nslots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+    const int bid = (int)blockIdx.x;
+    if (bid < 2 * nslots) gru_fwd_mfma_body(G, bid % nslots, bid / nslots, gm_smem);
+    else kfb::keep_flags_block<FWD_THREADS>(J, bid - 2 * nslots, (int)gridDim.x - 2 * nslots);
 }
 
 // Backward: same split.  The I/O wave moves 38 float4 per lane and step (dy | r z n ghn | h_prev of 16 sequences) through ONE
@@ -508,6 +523,19 @@ int mmdfn_launch_gru_fwd_mfma(int ngroups, const float* const* gi, const float* 
 #ifdef MMDFN_TUNING
     if (const char* e = getenv("MMDFN_GRU_MF_ABL")) G.abl = atoi(e);
 #endif
+    if (G.abl == 0 && 2 * sl < 256) {
+        if (const kfb::FlagJob* fj = mmdfn_flag_job_pending()) {
+            // a staged dropout-flag draw rides on the CUs this launch leaves idle
+            int64_t nr = (fj->n8 + FWD_THREADS - 1) / FWD_THREADS;
+            if (nr > 256 - 2 * sl) nr = 256 - 2 * sl;
+            const kfb::FlagJob J = *fj;
+            mmdfn_flag_job_taken();
+            if (int e = mmdfn_allow_big_lds(gru_seq_fwd_mfma_flags_kernel)) return e;
+            hipLaunchKernelGGL(gru_seq_fwd_mfma_flags_kernel, dim3(2 * sl + (int)nr), dim3(FWD_THREADS), FWD_LDS, s, G, J, sl);
+            MMDFN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (int e = mmdfn_allow_big_lds(gru_seq_fwd_mfma_kernel)) return e;
     hipLaunchKernelGGL(gru_seq_fwd_mfma_kernel, dim3(sl, 2), dim3(FWD_THREADS), FWD_LDS, s, G);
     MMDFN_CHECK_LAUNCH();

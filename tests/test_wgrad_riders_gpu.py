@@ -144,8 +144,8 @@ def test_rider_launch_is_bit_equal_to_the_two_plain_launches(rows, T_):
     assert float((c4 - 2 * c0).abs().max()) <= 1e-5 * float(c0.abs().max())
 
 
-@pytest.mark.parametrize("lengths", [(20, 13, 7), tuple([110] * 16)], ids=["small", "cfg2"])
-def test_dropout_flags_drawn_as_riders_of_the_gru_forward_launch_are_the_same_flags(lengths):
+@pytest.mark.parametrize("lengths,CFG", [((20, 13, 7), CFG), (tuple([110] * 16), CFG), (RAGGED_CFG3, CFG3)], ids=["small", "cfg2", "cfg3"])
+def test_dropout_flags_drawn_as_riders_of_the_gru_forward_launch_are_the_same_flags(lengths, CFG):
     """The step's keep flags drawn by rider workgroups of the first GRU layer's forward launch (ops_flags.stage_flag_draw,
     gru_seq_fwd_io_flags_kernel) are the flags the generator launch of its own draws -- same seed, same step: bit-identical
     log-probabilities and gradients --, the generator launch is gone from the trace, and a captured step keeps drawing fresh
@@ -181,8 +181,9 @@ def test_dropout_flags_drawn_as_riders_of_the_gru_forward_launch_are_the_same_fl
             ops_flags.FLAG_RIDER = prev
     (lp0, g0), names0 = two_steps(False)
     (lp1, g1), names1 = two_steps(True)
-    assert any("keep_flags_kernel" in n for n in names0) and not any("fwd_io_flags" in n for n in names0), names0
-    assert any("gru_seq_fwd_io_flags_kernel" in n for n in names1) and not any("keep_flags_kernel" in n for n in names1), names1
+    carrier = "gru_seq_fwd_mfma_flags_kernel" if CFG is CFG3 else "gru_seq_fwd_io_flags_kernel"
+    assert any("keep_flags_kernel" in n for n in names0) and not any("_flags_kernel" in n and "keep" not in n for n in names0), names0
+    assert any(carrier in n for n in names1) and not any("keep_flags_kernel" in n for n in names1), names1
     assert torch.equal(lp0, lp1)
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
