@@ -286,10 +286,17 @@ __device__ __forceinline__ void gru_fwd_mfma_body(const MfFwd& G, const int bx, 
         if (uok && rok && !(abl & 2)) {
             *reinterpret_cast<float4*>(y + t * ystep) = make_float4(hn[0], hn[1], hn[2], hn[3]);
             float* gp = gates + t * sstep;
+            if (abl & 8) {      // (A/B, tuning build: plain stores -- the L2 may combine the waves' 64-byte pieces of a line)
+                *reinterpret_cast<f32x4*>(gp) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+                *reinterpret_cast<f32x4*>(gp + GH) = f32x4{zz[0], zz[1], zz[2], zz[3]};
+                *reinterpret_cast<f32x4*>(gp + 2 * GH) = f32x4{nn[0], nn[1], nn[2], nn[3]};
+                *reinterpret_cast<f32x4*>(gp + 3 * GH) = f32x4{ghn[0], ghn[1], ghn[2], ghn[3]};
+            } else {
             __builtin_nontemporal_store(f32x4{rr[0], rr[1], rr[2], rr[3]}, reinterpret_cast<f32x4*>(gp));
             __builtin_nontemporal_store(f32x4{zz[0], zz[1], zz[2], zz[3]}, reinterpret_cast<f32x4*>(gp + GH));
             __builtin_nontemporal_store(f32x4{nn[0], nn[1], nn[2], nn[3]}, reinterpret_cast<f32x4*>(gp + 2 * GH));
             __builtin_nontemporal_store(f32x4{ghn[0], ghn[1], ghn[2], ghn[3]}, reinterpret_cast<f32x4*>(gp + 3 * GH));
+            }
         }
     }
 }

@@ -38,7 +38,7 @@ def run(T, rows, iters=30):
 
 
 for T, rows in ((33, 960), (33, 16)):
-    for mode, abl in (("scalar", 0), ("mfma", 0), ("mfma", 1), ("mfma", 2), ("mfma", 3), ("mfma", 4), ("mfma", 7)):
+    for mode, abl in (("scalar", 0), ("mfma", 0), ("mfma", 1), ("mfma", 2), ("mfma", 3), ("mfma", 4), ("mfma", 7), ("mfma", 8), ("mfma", 0), ("mfma", 8)):
         os.environ["MMDFN_GRU_MFMA_MIN"] = "100000000" if mode == "scalar" else "0"
         os.environ["MMDFN_GRU_MF_ABL"] = str(abl)
         f, b = run(T, rows)
